@@ -1,0 +1,78 @@
+"""Shared fixture plumbing for the parity tests (CPU and GPU)."""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import torch_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def case_names(kind="case"):
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
+        n = os.path.basename(p)[:-4]
+        if kind == "case" and not (n.startswith("kmeans") or n.startswith("train")):
+            out.append(n)
+        elif kind == "kmeans" and n.startswith("kmeans"):
+            out.append(n)
+        elif kind == "train" and n.startswith("train"):
+            out.append(n)
+    return out
+
+
+def load(name):
+    fx = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    desc = json.loads(str(fx["desc"]))
+    return fx, desc
+
+
+def cfg_of(desc):
+    return O.Cfg(**desc["cfg"])
+
+
+def inputs_of(desc):
+    cfg = cfg_of(desc)
+    P = O.formula_params(cfg, seed=desc.get("param_seed", 100), with_tags=True)
+    x, te, ti = O.formula_batch(cfg, desc["B"], seed=desc.get("batch_seed", 7), tagged=desc["tagged"])
+    if desc.get("invalid_level") is not None:
+        ti[:, desc["invalid_level"]] = -1
+    return cfg, P, x, te, ti
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def close(a, b, rtol, atol):
+    """max|a-b| <= rtol * max|b| + atol  (atol covers gradients that are mathematically zero,
+    e.g. a bias feeding a LayerNorm, where both sides hold only cancellation noise)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return bool(np.abs(a - b).max() <= rtol * np.abs(b).max() + atol)
+
+
+def sample(t, n=64):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].cpu().numpy().copy()
+
+
+def zero_grad_keys(cfg):
+    """Linear biases that feed a BatchNorm/LayerNorm directly: their gradient is mathematically 0, so
+    what autograd leaves there is cancellation noise (~1e-10) that Adam then amplifies to ~lr per step
+    (g/(sqrt(v)+eps) with |g| << eps).  No two implementations agree on those; compare them loosely."""
+    ks = []
+    for i in range(cfg.n_layers):
+        if cfg.use_batch_norm:
+            ks.append(f"tag_projectors.{i}.0.bias")
+            for n in ("feature_extractor.0", "residual_block1.0", "residual_block2.0", "classifier.0"):
+                ks.append(f"tag_predictors.{i}.{n}.bias")
+        if cfg.codebook_normalize:
+            ks.append(f"tag_projectors.{i}.4.bias")
+    return set(ks)

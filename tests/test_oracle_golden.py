@@ -1,0 +1,111 @@
+"""CPU: pin the oracle (oracle/torch_oracle.py) to the reference's own outputs (tests/golden/*.npz).
+
+Tolerances: ids bit-exact; every float within 1e-5 relative (north_star) -- gradients within 2e-5 of
+the tensor's max magnitude (they are sums over the batch of fp32 products in a different order)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from tests import helpers as H
+
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("name", H.case_names("case"))
+def test_forward_backward_matches_reference(name):
+    fx, desc = H.load(name)
+    cfg, P, x, te, ti = H.inputs_of(desc)
+    rand = O.FormulaRand(**desc["rand"])
+    bn = None
+    if desc["tagged"] and desc["training"] and cfg.use_batch_norm:
+        bn = {}
+        for i in range(cfg.n_layers):
+            bn[f"tag_projectors.{i}.1.running_mean"] = torch.zeros(cfg.hidden_dims[0])
+            bn[f"tag_projectors.{i}.1.running_var"] = torch.ones(cfg.hidden_dims[0])
+    kw = dict(gumbel_t=0.2, training=desc["training"], rand=rand, bn_buffers=bn)
+    if desc["training"]:
+        out, g = O.grads(P, cfg, x, te, ti, **kw)
+    else:
+        if desc["tagged"] and cfg.use_batch_norm:
+            for i in range(cfg.n_layers):
+                P[f"tag_projectors.{i}.1.running_mean"] = torch.zeros(cfg.hidden_dims[0])
+                P[f"tag_projectors.{i}.1.running_var"] = torch.ones(cfg.hidden_dims[0])
+        with torch.no_grad():
+            out = O.forward(P, cfg, x, te, ti, **kw)
+    assert np.array_equal(out["sem_ids"].numpy(), fx["sem_ids"]), "semantic ids differ from the reference"
+    for k in ("loss", "tag_align_loss", "tag_pred_loss", "tag_pred_accuracy", "p_unique_ids", "sem_id_uniqueness_loss"):
+        assert abs(float(out[k]) - float(fx[k])) <= TOL * max(1.0, abs(float(fx[k]))), k
+    for k in ("rqvae_loss", "reconstruction_loss", "embs_norm"):
+        assert H.rel_err(out[k].detach().numpy(), fx[k]) <= TOL, k
+    for k in ("tag_align_loss_by_layer", "tag_pred_loss_by_layer", "tag_pred_accuracy_by_layer"):
+        if k in fx:
+            assert H.rel_err(out[k].detach().numpy(), fx[k]) <= TOL, k
+    if "z" in fx:
+        for k in ("z", "embeddings", "residuals"):
+            assert H.rel_err(out[k].detach().numpy(), fx[k]) <= TOL, k
+    if bn is not None:
+        for i in range(cfg.n_layers):
+            assert H.rel_err(bn[f"tag_projectors.{i}.1.running_mean"].numpy(), fx[f"bn_mean_{i}"]) <= TOL
+            assert H.rel_err(bn[f"tag_projectors.{i}.1.running_var"].numpy(), fx[f"bn_var_{i}"]) <= TOL
+    if desc["training"]:
+        norms = json.loads(str(fx["grad_norms"]))
+        for k, n in norms.items():
+            got = float(g[k].double().norm())
+            assert abs(got - n) <= 2e-5 * max(n, 1e-6) + 1e-9, (k, got, n)
+        for k in fx:
+            if k.startswith("grad/"):
+                assert H.close(g[k[5:]].numpy(), fx[k], 2e-5, 1e-8), k
+            if k.startswith("gsample/"):
+                assert H.close(H.sample(g[k[8:]]), fx[k], 2e-5, 1e-8), k
+
+
+@pytest.mark.parametrize("name", H.case_names("train"))
+def test_train_loop_matches_reference(name):
+    """AdamW param groups + cosine schedule + grad accumulation (train_hidvae.py:533-563,698-766)."""
+    fx, desc = H.load(name)
+    cfg = H.cfg_of(desc)
+    P = O.formula_params(cfg, seed=100, with_tags=True)
+    L = cfg.n_layers
+    bn = {}
+    for i in range(L):
+        bn[f"tag_projectors.{i}.1.running_mean"] = torch.zeros(cfg.hidden_dims[0])
+        bn[f"tag_projectors.{i}.1.running_var"] = torch.ones(cfg.hidden_dims[0])
+
+    def group_of(k):
+        if k.startswith("tag_predictors.") or k.startswith("tag_projectors."):
+            i = int(k.split(".")[1])
+            return desc["lr"] * (1 + 0.1 * i), desc["pwd"] / (1 + 0.2 * i)
+        return desc["lr"], desc["wd"]
+
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    rand = O.FormulaRand(**desc["rand"])
+    losses = []
+    for it in range(desc["iters"]):
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        total = 0
+        for a in range(desc["ga"]):
+            x, te, ti = O.formula_batch(cfg, desc["B"], seed=1000 + 37 * (it * desc["ga"] + a), tagged=True)
+            out = O.forward(Pg, cfg, x, te, ti, gumbel_t=0.2, training=True, rand=rand, bn_buffers=bn)
+            total = total + out["loss"] / desc["ga"]
+        total.backward()
+        losses.append(float(total))
+        for k in P:
+            g = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(P[k])
+            base_lr, wd = group_of(k)
+            lr = O.cosine_lr(base_lr, desc["eta_min"], it, desc["T_max"])
+            P[k], M[k], V[k] = O.adamw_step(P[k], g, M[k], V[k], it + 1, lr, wd)
+    assert H.rel_err(np.array(losses), fx["losses"]) <= TOL
+    for k in fx:
+        if k.startswith("param/"):
+            assert H.rel_err(P[k[6:]].numpy(), fx[k]) <= TOL, k
+        if k.startswith("psample/"):
+            if k[8:] in H.zero_grad_keys(cfg):
+                assert H.close(H.sample(P[k[8:]]), fx[k], TOL, 2 * desc["lr"] * desc["iters"]), k
+            else:
+                assert H.rel_err(H.sample(P[k[8:]]), fx[k]) <= TOL, k
+    for i in range(L):
+        assert H.rel_err(bn[f"tag_projectors.{i}.1.running_mean"].numpy(), fx[f"bn_mean_{i}"]) <= TOL
