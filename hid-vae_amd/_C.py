@@ -1,0 +1,245 @@
+"""ctypes binding of include/hidvae.h (the C-ABI drop-in boundary).
+
+Every wrapper passes raw device pointers + sizes + the current HIP stream, checks the int return code and
+raises RuntimeError(hidvae_last_error()).  There is NO fallback: if libhidvae_hip.so is missing or a tensor
+is not a contiguous fp32 CUDA(HIP) tensor, the call fails loudly."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhidvae_hip.so")
+_lib = None
+
+MODE_GUMBEL, MODE_STE, MODE_ROTATION = 1, 2, 3
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_SILU, EPI_RELU, EPI_GELU, EPI_SIGMOID = 0, 1, 2, 3, 4
+EPI_DSILU, EPI_DRELU, EPI_DGELU, EPI_DSIGMOID = 16, 17, 18, 19
+MAX_LEVELS = 8
+EMBED_DIM = 32
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+_SIGNATURES = {
+    "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp],
+    "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
+    "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
+    "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp],
+    "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp],
+    "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_l2norm_fwd": [_vp, _i64, _i64, _i64, _f, _vp, _i64, _vp, _vp],
+    "hidvae_l2norm32_fwd": [_vp, _i64, _i64, _f, _vp, _i64, _vp, _vp],
+    "hidvae_l2norm_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _f, _vp, _i64, _i, _vp],
+    "hidvae_id_stats": [_vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp],
+    "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _i, _f, _f, _f, _f, _i64, _f, _vp],
+}
+
+
+def lib():
+    """Load the HIP extension; raise (never fall back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"HIP extension missing: {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback on the product path.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.hidvae_last_error.restype = ctypes.c_char_p
+        L.hidvae_version.restype = ctypes.c_char_p
+        for name, sig in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = sig
+            fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return ["hidvae_version", "hidvae_last_error"] + list(_SIGNATURES)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().hidvae_last_error().decode()}")
+
+
+def _p(t):
+    """device pointer of a tensor (None -> NULL); refuses anything the kernels cannot take."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("hidvae HIP kernels need device tensors (got a CPU tensor); there is no CPU fallback")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a float32 device tensor, got {t.dtype} on {t.device}")
+    return t
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _row_stride(t, name):
+    """Row stride in elements of a 2-D tensor whose last dim is contiguous (views over wider rows are fine)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError(f"{name}: expected a 2-D tensor with a contiguous last dim, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _host_ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k=1, accumulate=False):
+    """C = epilogue(op(A) op(B) + bias).  NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
+    _f32(A, "A"), _f32(B, "B")
+    lda, ldb = _row_stride(A, "A"), _row_stride(B, "B")
+    if layout == GEMM_NT:
+        M, K = A.shape
+        N, K2 = B.shape
+    elif layout == GEMM_NN:
+        M, K = A.shape
+        K2, N = B.shape
+    else:
+        K, M = A.shape
+        K2, N = B.shape
+    if K != K2:
+        raise RuntimeError(f"gemm: inner dimensions differ ({K} vs {K2})")  # the reference's shape assert (encoder.py:35)
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    ws = None
+    if split_k > 1:
+        ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32)
+    ldaux = _row_stride(aux, "aux") if aux is not None else 0
+    _check(lib().hidvae_gemm_f32(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(out), _row_stride(out, "C"),
+                                 epilogue, _p(aux), ldaux, split_k, _p(ws), int(accumulate), _stream()), "hidvae_gemm_f32")
+    return out
+
+
+def colsum(X, out=None, accumulate=False):
+    _f32(X, "X")
+    M, N = X.shape
+    if out is None:
+        out = torch.empty((N,), device=X.device, dtype=torch.float32)
+    ws = torch.empty(((M + 63) // 64 * N,), device=X.device, dtype=torch.float32)
+    _check(lib().hidvae_colsum(_p(X), M, N, _row_stride(X, "X"), _p(out), int(accumulate), _p(ws), _stream()), "hidvae_colsum")
+    return out
+
+
+def codebook_prepare(tables, normalize_flags):
+    """tables: list of L raw [K,32] tensors -> (cb_eff [L,K,32], cc [L,K])."""
+    L = len(tables)
+    K, D = tables[0].shape
+    if D != EMBED_DIM:
+        raise RuntimeError(f"the fused RQ kernels are specialised for embed_dim=32 (got {D})")
+    for t in tables:
+        _f32(t, "codebook")
+        if tuple(t.shape) != (K, D) or not t.is_contiguous():
+            raise RuntimeError("codebooks must be contiguous and share one shape")
+    cb = torch.empty((L, K, D), device=tables[0].device, dtype=torch.float32)
+    cc = torch.empty((L, K), device=tables[0].device, dtype=torch.float32)
+    flags = (ctypes.c_int32 * L)(*[int(bool(f)) for f in normalize_flags])
+    _check(lib().hidvae_codebook_prepare(_host_ptr_array(tables), flags, L, K, _p(cb), _p(cc), _stream()), "hidvae_codebook_prepare")
+    return cb, cc
+
+
+def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=False, want_z=True):
+    _f32(y, "y")
+    if y.dim() != 2 or y.shape[1] != EMBED_DIM or not y.is_contiguous():
+        raise RuntimeError(f"rq_forward: expected contiguous [B,32] input, got {tuple(y.shape)}")  # quantize.py:101
+    B = y.shape[0]
+    L, K, _ = cb_eff.shape
+    dev = y.device
+    z = torch.empty((B, EMBED_DIM), device=dev, dtype=torch.float32) if (want_z or normalize_input) else None
+    ids = torch.empty((B, L), device=dev, dtype=torch.int64)
+    emb_cat = torch.empty((B, L * EMBED_DIM), device=dev, dtype=torch.float32)
+    emb_sum = torch.empty((B, EMBED_DIM), device=dev, dtype=torch.float32)
+    res = torch.empty((B, L * EMBED_DIM), device=dev, dtype=torch.float32) if want_res else None
+    qloss = torch.empty((B,), device=dev, dtype=torch.float32)
+    _check(lib().hidvae_rq_forward(_p(y), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, int(mode), int(bool(training)),
+                                   float(beta), _p(z), _p(ids), _p(emb_cat), L * EMBED_DIM, _p(emb_sum), _p(res), _p(qloss),
+                                   _stream()), "hidvae_rq_forward")
+    return z if z is not None else y, ids, emb_cat, emb_sum, res, qloss
+
+
+def rq_backward(y, z, cb_eff, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z_in, gq, gq_items):
+    B = z.shape[0]
+    L, K, _ = cb_eff.shape
+    g_y = torch.empty_like(z)
+    dE = torch.empty((B, L * EMBED_DIM), device=z.device, dtype=torch.float32)
+    ldg = _row_stride(g_cat, "g_cat") if g_cat is not None else 0
+    _check(lib().hidvae_rq_backward(_p(y), _p(z), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, int(mode), float(beta),
+                                    _p(ids), _p(g_cat), ldg, _p(g_sum), _p(g_z_in), float(gq), _p(gq_items), _p(g_y), _p(dE),
+                                    _stream()), "hidvae_rq_backward")
+    return g_y, dE
+
+
+def codebook_grad(ids, dE_rows, tables, cb_eff, normalize_flags, grads=None, accumulate=False):
+    B, L = ids.shape
+    K = tables[0].shape[0]
+    if grads is None:
+        grads = [torch.empty_like(t) for t in tables]
+    flags = (ctypes.c_int32 * L)(*[int(bool(f)) for f in normalize_flags])
+    _check(lib().hidvae_codebook_grad(_p(ids), _p(dE_rows), B, L, K, _host_ptr_array(tables), _p(cb_eff), flags,
+                                      _host_ptr_array(grads), int(accumulate), _stream()), "hidvae_codebook_grad")
+    return grads
+
+
+def recon_fwd_bwd(y, x, gscale=0.0, gscale_items=None, want_xhat=False, want_grad=False):
+    _f32(y, "y"), _f32(x, "x")
+    if y.shape != x.shape or not y.is_contiguous() or not x.is_contiguous():
+        raise RuntimeError(f"recon: shapes differ or not contiguous ({tuple(y.shape)} vs {tuple(x.shape)})")
+    B, N = y.shape
+    x_hat = torch.empty_like(y) if want_xhat else None
+    recon = torch.empty((B,), device=y.device, dtype=torch.float32)
+    g_y = torch.empty_like(y) if want_grad else None
+    _check(lib().hidvae_recon_fwd_bwd(_p(y), _p(x), B, N, float(gscale), _p(gscale_items), _p(x_hat), _p(recon), _p(g_y), _stream()),
+           "hidvae_recon_fwd_bwd")
+    return recon, x_hat, g_y
+
+
+def l2norm_fwd(x, eps=1e-12):
+    _f32(x, "x")
+    M, N = x.shape
+    out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    norms = torch.empty((M,), device=x.device, dtype=torch.float32)
+    ldx = _row_stride(x, "x")
+    if N == EMBED_DIM and ldx % 4 == 0 and x.data_ptr() % 16 == 0:
+        _check(lib().hidvae_l2norm32_fwd(_p(x), M, ldx, float(eps), _p(out), N, _p(norms), _stream()), "hidvae_l2norm32_fwd")
+    else:
+        _check(lib().hidvae_l2norm_fwd(_p(x), M, N, ldx, float(eps), _p(out), N, _p(norms), _stream()), "hidvae_l2norm_fwd")
+    return out, norms
+
+
+def l2norm_bwd(g, out, norms, eps=1e-12, gx=None, accumulate=False):
+    M, N = out.shape
+    if gx is None:
+        gx = torch.empty((M, N), device=out.device, dtype=torch.float32)
+    _check(lib().hidvae_l2norm_bwd(_p(g), _row_stride(g, "g"), _p(out), _row_stride(out, "out"), _p(norms), M, N, float(eps), _p(gx),
+                                   _row_stride(gx, "gx"), int(accumulate), _stream()), "hidvae_l2norm_bwd")
+    return gx
+
+
+def id_stats(emb_cat, ids, want_norms=True):
+    B, L = ids.shape
+    dev = ids.device
+    norms = torch.empty((B, L), device=dev, dtype=torch.float32) if want_norms else None
+    pu = torch.empty((), device=dev, dtype=torch.float32)
+    scratch = torch.empty((4 * B,), device=dev, dtype=torch.int64)
+    ld = _row_stride(emb_cat, "emb_cat") if emb_cat is not None else 0
+    _check(lib().hidvae_id_stats(_p(emb_cat if want_norms else None), ld, _p(ids), B, L, _p(norms), _p(pu), _p(scratch), _stream()),
+           "hidvae_id_stats")
+    return norms, pu
+
+
+def adamw_step(desc, step_dev, bump_step, beta1, beta2, eps, eta_min, T_max, grad_scale):
+    """desc: dict of device arrays built by optim.HidvaeAdamW (p/g/m/v pointer tables, numel, lr, wd)."""
+    _check(lib().hidvae_adamw_step(_p(desc["p"]), _p(desc["g"]), _p(desc["m"]), _p(desc["v"]), _p(desc["numel"]), _p(desc["lr"]),
+                                   _p(desc["wd"]), int(desc["n"]), int(desc["max_numel"]), _p(step_dev), int(bump_step), float(beta1),
+                                   float(beta2), float(eps), float(eta_min), int(T_max), float(grad_scale), _stream()), "hidvae_adamw_step")

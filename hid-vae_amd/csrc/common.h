@@ -1,0 +1,66 @@
+// Shared host/device helpers for the HiD-VAE gfx950 kernels (wave = 64 lanes, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hidvae.h"
+
+int hv_fail(int code, const char *fmt, ...);  // records the thread's last error, returns `code`
+
+#define HV_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return hv_fail(HIDVAE_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define HV_LAUNCH_CHECK(name)                                                                     \
+    do {                                                                                          \
+        hipError_t e__ = hipGetLastError();                                                       \
+        if (e__ != hipSuccess) return hv_fail(HIDVAE_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int64_t hv_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#define HV_WAVE 64
+
+// ---- device math with a FIXED operation order (the files are built with -ffp-contract=off, so only
+// explicit fmaf fuses).  expE / silu mirror oracle/exact.c's specification bit for bit.
+__device__ __forceinline__ float hv_expE(float x) {
+    x = fminf(fmaxf(x, -87.3f), 88.7f);
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.428606765330187e-06f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p, r * r, r) + 1.0f;
+    return ldexpf(y, (int)n);
+}
+__device__ __forceinline__ float hv_sigmoid(float a) { return 1.0f / (1.0f + hv_expE(-a)); }
+__device__ __forceinline__ float hv_silu(float a) { return a / (1.0f + hv_expE(-a)); }
+__device__ __forceinline__ float hv_dsilu(float a) {
+    float s = hv_sigmoid(a);
+    return s * (1.0f + a * (1.0f - s));
+}
+__device__ __forceinline__ float hv_gelu(float a) { return 0.5f * a * (1.0f + erff(a * 0.70710678118654752f)); }
+__device__ __forceinline__ float hv_dgelu(float a) {
+    float cdf = 0.5f * (1.0f + erff(a * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * __expf(-0.5f * a * a);
+    return cdf + a * pdf;
+}
+
+__device__ __forceinline__ float hv_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float hv_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

@@ -1,0 +1,288 @@
+// Core-path row kernels, optimizer and id statistics for the HiD-VAE tokenizer step (gfx950).
+//   recon_fwd_bwd : decoder tail  l2norm -> sum (x_hat - x)^2 (+ gradient)   encoder.py:32, loss.py:11-12
+//   adamw_step    : multi-tensor AdamW with an on-device cosine schedule     train_hidvae.py:533-563,636-640
+//   id_stats      : embs_norm and p_unique_ids                               h_rqvae.py:643-648
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// one wave per row; rows are short (768 floats), so a row is read once into registers (float4 x MAXV)
+// ---------------------------------------------------------------------------------------------------
+constexpr int MAXV = 4;  // N <= 64 lanes * 4 floats * MAXV = 1024 on the vector path
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void recon_kernel(const float *y, const float *x, int64_t B, int64_t N, float gscale_all,
+                                                    const float *gscale_items, float *x_hat, float *recon, float *g_y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float *yr = y + row * N, *xr = x + row * N;
+    const float gscale = gscale_items != nullptr ? gscale_items[row] : gscale_all;
+    if (VEC) {
+        const int nv = (int)(N / 4);
+        float4 yv[MAXV], xv[MAXV];
+        float ss = 0.0f;
+#pragma unroll
+        for (int s = 0; s < MAXV; s++) {
+            const int i = lane + 64 * s;
+            yv[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[s] = yv[s];
+            if (i < nv) {
+                yv[s] = reinterpret_cast<const float4 *>(yr)[i];
+                xv[s] = reinterpret_cast<const float4 *>(xr)[i];
+            }
+            ss += (yv[s].x * yv[s].x + yv[s].y * yv[s].y) + (yv[s].z * yv[s].z + yv[s].w * yv[s].w);
+        }
+        ss = hv_wave_sum(ss);
+        const float nrm = sqrtf(ss), den = fmaxf(nrm, 1e-12f);
+        float rs = 0.0f, t = 0.0f;
+        float4 dv[MAXV];
+#pragma unroll
+        for (int s = 0; s < MAXV; s++) {
+            const float4 h = make_float4(yv[s].x / den, yv[s].y / den, yv[s].z / den, yv[s].w / den);
+            dv[s] = make_float4(h.x - xv[s].x, h.y - xv[s].y, h.z - xv[s].z, h.w - xv[s].w);
+            rs += (dv[s].x * dv[s].x + dv[s].y * dv[s].y) + (dv[s].z * dv[s].z + dv[s].w * dv[s].w);
+            t += (h.x * dv[s].x + h.y * dv[s].y) + (h.z * dv[s].z + h.w * dv[s].w);
+            yv[s] = h;
+            const int i = lane + 64 * s;
+            if (x_hat != nullptr && i < nv) reinterpret_cast<float4 *>(x_hat + row * N)[i] = h;
+        }
+        rs = hv_wave_sum(rs);
+        t = hv_wave_sum(t);
+        if (lane == 0 && recon != nullptr) recon[row] = rs;
+        if (g_y != nullptr) {
+            // g_xhat = 2 gscale (x_hat - x);  g_y = (g_xhat - x_hat (x_hat . g_xhat)) / den   (den = |y| unless clamped)
+            const float c = 2.0f * gscale / den;
+            const float proj = nrm > 1e-12f ? t : 0.0f;
+#pragma unroll
+            for (int s = 0; s < MAXV; s++) {
+                const int i = lane + 64 * s;
+                if (i < nv)
+                    reinterpret_cast<float4 *>(g_y + row * N)[i] =
+                        make_float4(c * (dv[s].x - yv[s].x * proj), c * (dv[s].y - yv[s].y * proj),
+                                    c * (dv[s].z - yv[s].z * proj), c * (dv[s].w - yv[s].w * proj));
+            }
+        }
+    } else {
+        float ss = 0.0f;
+        for (int64_t i = lane; i < N; i += 64) ss += yr[i] * yr[i];
+        ss = hv_wave_sum(ss);
+        const float nrm = sqrtf(ss), den = fmaxf(nrm, 1e-12f);
+        float rs = 0.0f, t = 0.0f;
+        for (int64_t i = lane; i < N; i += 64) {
+            const float h = yr[i] / den, d = h - xr[i];
+            rs += d * d;
+            t += h * d;
+            if (x_hat != nullptr) x_hat[row * N + i] = h;
+        }
+        rs = hv_wave_sum(rs);
+        t = hv_wave_sum(t);
+        if (lane == 0 && recon != nullptr) recon[row] = rs;
+        if (g_y != nullptr) {
+            const float c = 2.0f * gscale / den, proj = nrm > 1e-12f ? t : 0.0f;
+            for (int64_t i = lane; i < N; i += 64) {
+                const float h = yr[i] / den;
+                g_y[row * N + i] = c * ((h - xr[i]) - h * proj);
+            }
+        }
+    }
+}
+
+// generic row L2 normalise: out = x / max(|x|, eps); saves |x| for the backward.  One wave per row.
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float *x, int64_t M, int64_t N, int64_t ldx, float eps,
+                                                         float *out, int64_t ldo, float *norms) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float ss = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) ss += x[row * ldx + i] * x[row * ldx + i];
+    ss = hv_wave_sum(ss);
+    const float nrm = sqrtf(ss), den = fmaxf(nrm, eps);
+    for (int64_t i = lane; i < N; i += 64) out[row * ldo + i] = x[row * ldx + i] / den;
+    if (lane == 0 && norms != nullptr) norms[row] = nrm;
+}
+
+// gx (+)= (g - out (out . g)) / |x|   (or g / eps where the norm was clamped)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *g, int64_t ldg, const float *out, int64_t ldo,
+                                                         const float *norms, int64_t M, int64_t N, float eps, float *gx,
+                                                         int64_t ldgx, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float t = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) t += out[row * ldo + i] * g[row * ldg + i];
+    t = hv_wave_sum(t);
+    const float nrm = norms[row];
+    const float den = fmaxf(nrm, eps), proj = nrm > eps ? t : 0.0f;
+    for (int64_t i = lane; i < N; i += 64) {
+        const float v = (g[row * ldg + i] - out[row * ldo + i] * proj) / den;
+        float *d = gx + row * ldgx + i;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AdamW.  blockIdx.y = tensor, blockIdx.x strides over its elements.
+// ---------------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float *const *p;
+    const float *const *g;
+    float *const *m;
+    float *const *v;
+    const int64_t *numel;
+    const float *base_lr;
+    const float *wd;
+    const int64_t *step;
+    float beta1, beta2, eps, eta_min, grad_scale;
+    int64_t T_max;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    const int t = blockIdx.y;
+    const int64_t n = a.numel[t];
+    const int64_t step = *a.step + 1;  // torch counts the step being taken from 1
+    double lr = (double)a.base_lr[t];
+    if (a.T_max > 0)  // CosineAnnealingLR after (step-1) scheduler steps, closed form
+        lr = (double)a.eta_min + (lr - (double)a.eta_min) * (1.0 + cos(M_PI * (double)(step - 1) / (double)a.T_max)) * 0.5;
+    const double bc1 = 1.0 - pow((double)a.beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)a.beta2, (double)step);
+    const float decay = (float)(1.0 - lr * (double)a.wd[t]);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    float *p = a.p[t], *m = a.m[t], *v = a.v[t];
+    const float *g = a.g[t];
+    const float w1 = 1.0f - a.beta1, w2 = 1.0f - a.beta2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * a.grad_scale;
+        float pi = p[i] * decay;
+        const float mi = m[i] + (gi - m[i]) * w1;  // lerp
+        const float vi = v[i] * a.beta2 + (gi * gi) * w2;
+        const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ void bump_step_kernel(int64_t *step) { *step += 1; }
+
+// ---------------------------------------------------------------------------------------------------
+// id statistics
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void id_stats_init_kernel(const float *emb_cat, int64_t ld_cat, int64_t B, int L,
+                                                            float *embs_norm, int64_t *table, int64_t tsize) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < tsize) table[idx] = -1;
+    if (idx == 0) table[tsize] = 0;  // distinct counter
+    if (embs_norm != nullptr && idx < B * L) {
+        const int64_t b = idx / L;
+        const int i = (int)(idx - b * L);
+        const float4 *p = reinterpret_cast<const float4 *>(emb_cat + b * ld_cat + i * 32);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float4 v = p[j];
+            s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        embs_norm[idx] = sqrtf(s);
+    }
+}
+
+__global__ __launch_bounds__(256) void id_stats_insert_kernel(const int64_t *ids, int64_t B, int L, int64_t *table,
+                                                              int64_t tsize) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < L; i++) {
+        h ^= (unsigned long long)ids[b * L + i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 29;
+    }
+    int64_t slot = (int64_t)(h % (unsigned long long)tsize);
+    for (int64_t probe = 0; probe < tsize; probe++) {
+        const long long prev = (long long)atomicCAS(reinterpret_cast<unsigned long long *>(table + slot),
+                                                    (unsigned long long)-1ll, (unsigned long long)b);
+        if (prev == -1ll) {  // first item with this tuple
+            atomicAdd(reinterpret_cast<unsigned long long *>(table + tsize), 1ull);
+            return;
+        }
+        bool same = true;
+        for (int i = 0; i < L; i++) same = same && (ids[prev * L + i] == ids[b * L + i]);
+        if (same) return;  // duplicate of an already counted tuple
+        slot = slot + 1 == tsize ? 0 : slot + 1;
+    }
+}
+
+__global__ void id_stats_final_kernel(const int64_t *table, int64_t tsize, int64_t B, float *p_unique) {
+    *p_unique = (float)table[tsize] / (float)B;
+}
+
+}  // namespace
+
+extern "C" int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, int64_t N, float gscale,
+                                    const float *gscale_items, float *x_hat, float *recon, float *g_y, void *stream) {
+    HV_REQUIRE(y && x && B >= 1 && N >= 1, "recon: bad arguments");
+    const unsigned grid = (unsigned)hv_cdiv(B, 4);
+    const bool vec = (N % 4 == 0) && N <= 256 * MAXV && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x) |
+                                                          reinterpret_cast<uintptr_t>(x_hat) | reinterpret_cast<uintptr_t>(g_y)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(recon_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, gscale, gscale_items, x_hat, recon, g_y);
+    else hipLaunchKernelGGL(recon_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, gscale, gscale_items, x_hat, recon, g_y);
+    HV_LAUNCH_CHECK("recon_fwd_bwd");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_adamw_step(float *const *p_dev, const float *const *g_dev, float *const *m_dev, float *const *v_dev,
+                                 const int64_t *numel_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
+                                 int64_t max_numel, int64_t *step_dev, int bump_step, float beta1, float beta2, float eps,
+                                 float eta_min, int64_t T_max, float grad_scale, void *stream) {
+    HV_REQUIRE(p_dev && g_dev && m_dev && v_dev && numel_dev && base_lr_dev && wd_dev && step_dev, "adamw: null pointer");
+    HV_REQUIRE(n_tensors >= 1 && n_tensors <= 65535 && max_numel >= 1, "adamw: bad tensor count / size");
+    AdamArgs a{p_dev, g_dev, m_dev, v_dev, numel_dev, base_lr_dev, wd_dev, step_dev, beta1, beta2, eps, eta_min, grad_scale, T_max};
+    int64_t gx = hv_cdiv(max_numel, 256 * 4);
+    if (gx > 256) gx = 256;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)gx, (unsigned)n_tensors), dim3(256), 0, s, a);
+    HV_LAUNCH_CHECK("adamw");
+    if (bump_step) {
+        hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step_dev);
+        HV_LAUNCH_CHECK("adamw bump");
+    }
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, int64_t B, int L, float *embs_norm,
+                               float *p_unique, int64_t *scratch, void *stream) {
+    HV_REQUIRE(ids && p_unique && scratch && B >= 1 && L >= 1 && L <= HIDVAE_MAX_LEVELS, "id_stats: bad arguments");
+    HV_REQUIRE(embs_norm == nullptr || (emb_cat != nullptr && ld_cat >= (int64_t)L * 32 && ld_cat % 4 == 0), "id_stats: emb_cat/ld_cat");
+    const int64_t tsize = 4 * B - 1;  // scratch holds tsize slots + 1 counter
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n0 = tsize > B * L ? tsize : B * L;
+    hipLaunchKernelGGL(id_stats_init_kernel, dim3((unsigned)hv_cdiv(n0, 256)), dim3(256), 0, s, emb_cat, ld_cat, B, L, embs_norm, scratch, tsize);
+    HV_LAUNCH_CHECK("id_stats init");
+    hipLaunchKernelGGL(id_stats_insert_kernel, dim3((unsigned)hv_cdiv(B, 256)), dim3(256), 0, s, ids, B, L, scratch, tsize);
+    HV_LAUNCH_CHECK("id_stats insert");
+    hipLaunchKernelGGL(id_stats_final_kernel, dim3(1), dim3(1), 0, s, scratch, tsize, B, p_unique);
+    HV_LAUNCH_CHECK("id_stats final");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_l2norm_fwd(const float *x, int64_t M, int64_t N, int64_t ldx, float eps, float *out, int64_t ldo,
+                                 float *norms, void *stream) {
+    HV_REQUIRE(x && out && M >= 1 && N >= 1 && ldx >= N && ldo >= N, "l2norm_fwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, N, ldx, eps, out,
+                       ldo, norms);
+    HV_LAUNCH_CHECK("l2norm_fwd");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_l2norm_bwd(const float *g, int64_t ldg, const float *out, int64_t ldo, const float *norms, int64_t M,
+                                 int64_t N, float eps, float *gx, int64_t ldgx, int accumulate, void *stream) {
+    HV_REQUIRE(g && out && norms && gx && M >= 1 && N >= 1 && ldg >= N && ldo >= N && ldgx >= N, "l2norm_bwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, g, ldg, out, ldo, norms,
+                       M, N, eps, gx, ldgx, accumulate);
+    HV_LAUNCH_CHECK("l2norm_bwd");
+    return HIDVAE_OK;
+}

@@ -1,0 +1,302 @@
+// fp32 MFMA GEMM for gfx950 with fused epilogues: the Linear layers of the HiD-VAE tokenizer
+// (modules/encoder.py:23-36 encoder/decoder MLPs; h_rqvae.py:132-188,322-331 tag heads) and their
+// input / weight gradients.
+//
+// v_mfma_f32_32x32x2_f32: per lane ONE A value (row = lane&31, k = lane>>5) and ONE B value, 16 accumulator
+// registers; the result is a k-ordered fmaf chain, so with split_k == 1 an output element is bit-identical to
+// `for k: acc = fmaf(a[k], b[k], acc)` -- the order oracle/exact.c uses (ORDER-G).
+//
+// Workgroup tile (32*WM) x (32*WN), one 32x32 accumulator per wave, BK = 16.  Both operand tiles live in LDS
+// k-major (As[k][m], Bs[k][n]) so a fragment read is 32 consecutive floats per half-wave (conflict-free
+// ds_read_b32) whatever the global layout was; the transposition happens on the LDS store:
+//   k-contiguous source (A of NT/NN, B of NT): float4 along k -> four ds_write_b32 (LD = tile+4 keeps them 2-way)
+//   m-contiguous source (A of TN, B of NN/TN): float4 along m -> one ds_write_b128
+// Global loads for tile t+1 are issued before the MFMAs of tile t (register prefetch, two LDS buffers, one
+// barrier per k-tile).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+struct GemmArgs {
+    int64_t M, N, K;
+    const float *A;
+    int64_t lda;
+    const float *B;
+    int64_t ldb;
+    const float *bias;
+    float *C;
+    int64_t ldc;
+    int epilogue;
+    float *aux;
+    int64_t ldaux;
+    int accumulate;
+    int64_t k_per_split;  // multiple of BK
+    float *partial;       // split-K slabs [splits][M][N] (nullptr when split_k == 1)
+    int vecA, vecB;       // 16-byte loads legal for the operand
+};
+
+__device__ __forceinline__ float apply_epilogue(int epi, float v, const float *aux, int64_t off) {
+    switch (epi) {
+        case HIDVAE_EPI_SILU: return hv_silu(v);
+        case HIDVAE_EPI_RELU: return fmaxf(v, 0.0f);
+        case HIDVAE_EPI_GELU: return hv_gelu(v);
+        case HIDVAE_EPI_SIGMOID: return hv_sigmoid(v);
+        case HIDVAE_EPI_DSILU: return v * hv_dsilu(aux[off]);
+        case HIDVAE_EPI_DRELU: return aux[off] > 0.0f ? v : 0.0f;
+        case HIDVAE_EPI_DGELU: return v * hv_dgelu(aux[off]);
+        case HIDVAE_EPI_DSIGMOID: { const float s = aux[off]; return v * (s * (1.0f - s)); }
+        default: return v;
+    }
+}
+
+// Load a [ROWS x BK] operand tile (ROWS = 32*W along m or n) into registers.  KCONTIG: element (row, k) is at
+// P[row*ld + k]; otherwise at P[k*ld + row].  Out-of-range elements read as 0.
+template <int ROWS, int NT, bool KCONTIG>
+struct TileLoader {
+    static constexpr int NV = (ROWS * BK / 4 + NT - 1) / NT;  // float4 slots per thread
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float *P, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+                                         int64_t kend, bool vec, int tid) {
+#pragma unroll
+        for (int s = 0; s < NV; s++) {
+            const int idx = tid + s * NT;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < ROWS * BK / 4) {
+                if (KCONTIG) {
+                    const int r = idx / (BK / 4), k4 = idx % (BK / 4);
+                    const int64_t row = row0 + r, k = k0 + 4 * k4;
+                    if (row < nrows) {
+                        const float *p = P + row * ld + k;
+                        if (vec && k + 4 <= kend) {
+                            x = *reinterpret_cast<const float4 *>(p);
+                        } else {
+                            if (k + 0 < kend) x.x = p[0];
+                            if (k + 1 < kend) x.y = p[1];
+                            if (k + 2 < kend) x.z = p[2];
+                            if (k + 3 < kend) x.w = p[3];
+                        }
+                    }
+                } else {
+                    const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
+                    const int64_t kk = k0 + k, row = row0 + 4 * r4;
+                    if (kk < kend) {
+                        const float *p = P + kk * ld + row;
+                        if (vec && row + 4 <= nrows) {
+                            x = *reinterpret_cast<const float4 *>(p);
+                        } else {
+                            if (row + 0 < nrows) x.x = p[0];
+                            if (row + 1 < nrows) x.y = p[1];
+                            if (row + 2 < nrows) x.z = p[2];
+                            if (row + 3 < nrows) x.w = p[3];
+                        }
+                    }
+                }
+            }
+            v[s] = x;
+        }
+    }
+
+    // LDS image: T[k][ROWS + 4]
+    __device__ __forceinline__ void store(float *T, int tid) const {
+        constexpr int LD = ROWS + 4;
+#pragma unroll
+        for (int s = 0; s < NV; s++) {
+            const int idx = tid + s * NT;
+            if (idx < ROWS * BK / 4) {
+                if (KCONTIG) {
+                    const int r = idx / (BK / 4), k4 = idx % (BK / 4);
+                    T[(4 * k4 + 0) * LD + r] = v[s].x;
+                    T[(4 * k4 + 1) * LD + r] = v[s].y;
+                    T[(4 * k4 + 2) * LD + r] = v[s].z;
+                    T[(4 * k4 + 3) * LD + r] = v[s].w;
+                } else {
+                    const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
+                    *reinterpret_cast<float4 *>(T + k * LD + 4 * r4) = v[s];
+                }
+            }
+        }
+    }
+};
+
+template <int WM, int WN, int LAYOUT>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN;
+    constexpr bool A_KC = (LAYOUT != HIDVAE_GEMM_TN);  // A[M,K] row-major
+    constexpr bool B_KC = (LAYOUT == HIDVAE_GEMM_NT);  // B[N,K] row-major
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+    const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+
+    TileLoader<BM, NT, A_KC> la;
+    TileLoader<BN, NT, B_KC> lb;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+
+    la.load(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid);
+    lb.load(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid);
+    la.store(As[0], tid);
+    lb.store(Bs[0], tid);
+    __syncthreads();
+    int buf = 0;
+    const int i32 = lane & 31, h = lane >> 5;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) {
+            la.load(g.A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, tid);
+            lb.load(g.B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, tid);
+        }
+        const float *ap = As[buf] + wm * 32 + i32, *bp = Bs[buf] + wn * 32 + i32;
+#pragma unroll
+        for (int s = 0; s < BK / 2; s++) {
+            const float a = ap[(2 * s + h) * LDA];
+            const float b = bp[(2 * s + h) * LDB];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (more) {
+            la.store(As[buf ^ 1], tid);
+            lb.store(Bs[buf ^ 1], tid);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int64_t col = n0 + wn * 32 + i32;
+    if (col >= g.N) return;
+    const float bias = (g.bias != nullptr && g.partial == nullptr) ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        if (g.partial != nullptr) {
+            g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = acc[r];
+        } else {
+            float v = acc[r] + bias;
+            if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE)
+                g.aux[row * g.ldaux + col] = v;
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            float *dst = g.C + row * g.ldc + col;
+            *dst = g.accumulate ? *dst + v : v;
+        }
+    }
+}
+
+// fixed-order reduction of the split-K slabs + the same epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int splits) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= g.M * g.N) return;
+    const int64_t row = idx / g.N, col = idx - row * g.N;
+    float v = g.partial[idx];
+    for (int s = 1; s < splits; s++) v += g.partial[(int64_t)s * g.M * g.N + idx];
+    v += g.bias != nullptr ? g.bias[col] : 0.0f;
+    if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+    v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+    float *dst = g.C + row * g.ldc + col;
+    *dst = g.accumulate ? *dst + v : v;
+}
+
+// column sums (bias gradients) in two fixed-order passes: 64-row chunks, then the chunks in ascending order
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *X, int64_t M, int64_t N, int64_t ldx,
+                                                             float *partial) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    float s = 0.0f;
+    if (n < N) {
+#pragma unroll 4
+        for (int j = 0; j < 16; j++) {
+            const int64_t m = r0 + rl + 4 * j;
+            if (m < M) s += X[m * ldx + n];
+        }
+    }
+    red[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *partial, int64_t chunks, int64_t N, float *out,
+                                                           int accumulate) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.0f;
+    for (int64_t c = 0; c < chunks; c++) s += partial[c * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+template <int WM, int WN>
+void launch_tile(int layout, const GemmArgs &g, int splits, hipStream_t s) {
+    dim3 grid((unsigned)hv_cdiv(g.N, 32 * WN), (unsigned)hv_cdiv(g.M, 32 * WM), (unsigned)splits);
+    dim3 block(64 * WM * WN);
+    if (layout == HIDVAE_GEMM_NT) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, HIDVAE_GEMM_NT>), grid, block, 0, s, g);
+    else if (layout == HIDVAE_GEMM_NN) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, HIDVAE_GEMM_NN>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, HIDVAE_GEMM_TN>), grid, block, 0, s, g);
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
+                               const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int epilogue,
+                               float *aux, int64_t ldaux, int split_k, float *workspace, int accumulate,
+                               void *stream) {
+    HV_REQUIRE(layout >= 0 && layout <= 2, "gemm: layout %d", layout);
+    HV_REQUIRE(M >= 1 && N >= 1 && K >= 1, "gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+    HV_REQUIRE(A && B && C, "gemm: null operand");
+    const int64_t a_min = (layout == HIDVAE_GEMM_TN) ? M : K, b_min = (layout == HIDVAE_GEMM_NT) ? K : N;
+    HV_REQUIRE(lda >= a_min && ldb >= b_min && ldc >= N, "gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)",
+               (long long)lda, (long long)ldb, (long long)ldc);
+    HV_REQUIRE(epilogue < HIDVAE_EPI_DSILU || (aux != nullptr && ldaux >= N), "gemm: backward epilogue %d needs aux", epilogue);
+    HV_REQUIRE(split_k >= 1 && (split_k == 1 || workspace != nullptr), "gemm: split_k=%d needs a workspace", split_k);
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.epilogue = epilogue; g.aux = aux; g.ldaux = aux ? ldaux : 0; g.accumulate = accumulate;
+    g.vecA = (lda % 4 == 0) && aligned16(A);
+    g.vecB = (ldb % 4 == 0) && aligned16(B);
+    int splits = split_k;
+    int64_t kps = hv_cdiv(hv_cdiv(K, splits), BK) * BK;
+    splits = (int)hv_cdiv(K, kps);
+    g.k_per_split = kps;
+    g.partial = splits > 1 ? workspace : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    // tile choice: biggest tile that still gives the chip >= ~1 workgroup per CU
+    const int64_t t64 = hv_cdiv(M, 64) * hv_cdiv(N, 64) * splits;
+    const int64_t t32x64 = hv_cdiv(M, 32) * hv_cdiv(N, 64) * splits;
+    if (N <= 32 || M <= 32) {
+        if (N <= 32) launch_tile<2, 1>(layout, g, splits, s);
+        else launch_tile<1, 2>(layout, g, splits, s);
+    } else if (t64 >= 256) launch_tile<2, 2>(layout, g, splits, s);
+    else if (t32x64 >= 192) launch_tile<1, 2>(layout, g, splits, s);
+    else launch_tile<1, 1>(layout, g, splits, s);
+    HV_LAUNCH_CHECK("gemm_f32");
+    if (splits > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)hv_cdiv(M * N, 256)), dim3(256), 0, s, g, splits);
+        HV_LAUNCH_CHECK("splitk_reduce");
+    }
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate,
+                             float *workspace, void *stream) {
+    HV_REQUIRE(X && out && workspace && M >= 1 && N >= 1 && ldx >= N, "colsum: bad arguments");
+    const int64_t chunks = hv_cdiv(M, 64);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)hv_cdiv(N, 64), (unsigned)chunks), dim3(256), 0, s, X, M, N,
+                       ldx, workspace);
+    HV_LAUNCH_CHECK("colsum_partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)hv_cdiv(N, 256)), dim3(256), 0, s, workspace, chunks, N, out,
+                       accumulate);
+    HV_LAUNCH_CHECK("colsum_final");
+    return HIDVAE_OK;
+}

@@ -1,0 +1,563 @@
+// Fused L-level residual quantisation for gfx950 (CDNA4), embed_dim = 32.
+//
+// Replaces the per-level op sequence of the reference (modules/quantize.py:100-153 called from
+// modules/h_rqvae.py:515-552): distance GEMM -> argmin -> gather -> rotation trick / STE -> QuantizeLoss
+// -> residual subtract, for all L levels in ONE kernel, residual kept in registers, codebooks staged in LDS.
+//
+// Geometry (wave = 64 lanes): a wave owns 16 items; lane = (it = lane & 15, q = lane >> 4) holds the 8
+// contiguous components d in [8q, 8q+8) of item `it`.  That one layout is
+//   * the B operand of v_mfma_f32_16x16x4_f32 (B[k = lane>>4][col = lane&15]) with the codes as A rows, so the
+//     16x16 accumulator puts item `it` on the lane and 4 codes in its 4 registers: the argmin is in-lane over
+//     codes and needs only two cross-lane steps (xor 16, xor 32);
+//   * two float4 global loads/stores per lane per row (coalesced 128-B rows);
+//   * the partial-sum layout of every 32-wide reduction (four chains combined as (p0+p1)+(p2+p3)).
+// fp32 MFMA is a k-ordered fmaf chain, so distances are reproducible bit-for-bit by oracle/exact.c, which is
+// how the semantic ids are proven bit-exact.  Exact fp32 makes this kernel MFMA-bound, not HBM-bound
+// (2*K*32 FLOP per item-level at the vector rate) -- see DESIGN.md for the roofline.
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int D = HIDVAE_EMBED_DIM;
+constexpr int WG_THREADS = 256;
+constexpr int ITEMS_PER_WAVE = 16;
+constexpr int ITEMS_PER_WG = 64;
+constexpr int MAX_KC = 1024;  // codes staged in LDS at a time (32*(1024+2)+1024 floats = 135.3 KB)
+
+__device__ __forceinline__ float sumQ(float p) {
+    float s = p + __shfl_xor(p, 16);
+    return s + __shfl_xor(s, 32);
+}
+__device__ __forceinline__ float dotQ(const float (&a)[8], const float (&b)[8]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s = fmaf(a[j], b[j], s);
+    return sumQ(s);
+}
+__device__ __forceinline__ void load8(const float *p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4 *>(p);
+    const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(float *p, const float (&v)[8]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// o_i for one level (quantize.py:131-140,146-148).  r: level input, e: selected code, xx=|r|^2, cce=|e|^2.
+// Also returns the rotation frame (u, qv, w) for the backward.
+template <int MODE, bool TRAIN>
+__device__ __forceinline__ void level_output(const float (&r)[8], const float (&e)[8], float xx, float cce,
+                                             float (&o)[8], float (&u)[8], float (&qv)[8], float (&w)[8]) {
+    if (!TRAIN) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = e[j];
+    } else if (MODE == HIDVAE_MODE_STE) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = r[j] + (e[j] - r[j]);
+    } else {
+        const float nr = sqrtf(xx) + 1e-8f;
+        const float ne = sqrtf(cce) + 1e-8f;
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            u[j] = r[j] / nr;
+            qv[j] = e[j] / ne;
+            s[j] = u[j] + qv[j];
+        }
+        const float nw = fmaxf(sqrtf(dotQ(s, s)), 1e-6f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = s[j] / nw;
+        const float rw = dotQ(r, w), ru = dotQ(r, u);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (r[j] - 2.0f * (rw * w[j])) + 2.0f * (ru * qv[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// effective codebook: optional row normalisation + |c|^2, same lane geometry (16 rows per wave)
+// ------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const float *E[HIDVAE_MAX_LEVELS];
+    int normalize[HIDVAE_MAX_LEVELS];
+    int L;
+    int64_t K;
+    float *cb_eff;
+    float *cc;
+};
+
+__global__ __launch_bounds__(WG_THREADS) void codebook_prepare_kernel(PrepArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int it = lane & 15, q = lane >> 4;
+    const int64_t rows = (int64_t)a.L * a.K;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * ITEMS_PER_WAVE + it;
+    const int64_t src = row < rows ? row : rows - 1;
+    const int lvl = (int)(src / a.K);
+    const int64_t k = src - (int64_t)lvl * a.K;
+    float v[8];
+    load8(a.E[lvl] + k * D + 8 * q, v);
+    if (a.normalize[lvl]) {
+        const float den = fmaxf(sqrtf(dotQ(v, v)), 1e-12f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = v[j] / den;
+    }
+    const float cc = dotQ(v, v);
+    if (row < rows) {
+        store8(a.cb_eff + row * D + 8 * q, v);
+        if (q == 0) a.cc[row] = cc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float *y;
+    int64_t B;
+    int normalize_input;
+    const float *cb_eff;  // [L][K][32]
+    const float *cc;      // [L][K]
+    int L;
+    int64_t K;
+    int KC;       // codes per LDS chunk (multiple of 32)
+    int nchunks;  // ceil(K / KC)
+    float beta;
+    float *z;
+    int64_t *ids;
+    float *emb_cat;
+    int64_t ld_cat;
+    float *emb_sum;
+    float *res_cat;
+    float *qloss;
+};
+
+// stage codes [c0, c0+KC) of level `lvl` into LDS, d-major: Cs[d][KC+2], then |c|^2 (padding: 0 / +inf)
+__device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl, int c0) {
+    const int LDK = a.KC + 2;
+    float *ccs = Cs + 32 * LDK;
+    const float *src = a.cb_eff + (int64_t)lvl * a.K * D;
+    for (int idx = threadIdx.x; idx < a.KC * 8; idx += WG_THREADS) {
+        const int kl = idx >> 3, d4 = idx & 7;
+        const int64_t k = (int64_t)c0 + kl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < a.K) v = *reinterpret_cast<const float4 *>(src + k * D + 4 * d4);
+        Cs[(4 * d4 + 0) * LDK + kl] = v.x;
+        Cs[(4 * d4 + 1) * LDK + kl] = v.y;
+        Cs[(4 * d4 + 2) * LDK + kl] = v.z;
+        Cs[(4 * d4 + 3) * LDK + kl] = v.w;
+    }
+    for (int kl = threadIdx.x; kl < a.KC; kl += WG_THREADS) {
+        const int64_t k = (int64_t)c0 + kl;
+        ccs[kl] = k < a.K ? a.cc[(int64_t)lvl * a.K + k] : INFINITY;
+    }
+}
+
+template <int MODE, bool TRAIN, bool RESIDENT>
+__global__ __launch_bounds__(WG_THREADS) void rq_forward_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int it = lane & 15, q = lane >> 4;
+    const int LDK = a.KC + 2;
+    const int lvl_floats = 32 * LDK + a.KC;
+
+    if (RESIDENT) {
+        for (int i = 0; i < a.L; i++) stage_codes(lds + i * lvl_floats, a, i, 0);
+        __syncthreads();
+    }
+    const int64_t ntiles = (a.B + ITEMS_PER_WG - 1) / ITEMS_PER_WG;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t item = tile * ITEMS_PER_WG + wave * ITEMS_PER_WAVE + it;
+        const bool valid = item < a.B;
+        const int64_t src = valid ? item : a.B - 1;
+        float r[8];
+        load8(a.y + src * D + 8 * q, r);
+        if (a.normalize_input) {  // F.normalize(eps=1e-12), modules/encoder.py:32
+            const float den = fmaxf(sqrtf(dotQ(r, r)), 1e-12f);
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = r[j] / den;
+        }
+        if (a.z != nullptr && valid) store8(a.z + item * D + 8 * q, r);
+        float loss = 0.0f;
+        float esum[8];
+        for (int i = 0; i < a.L; i++) {
+            if (a.res_cat != nullptr && valid) store8(a.res_cat + item * (a.L * D) + i * D + 8 * q, r);
+            const float xx = dotQ(r, r);
+            float best = INFINITY;
+            int bidx = 0;
+            for (int c = 0; c < a.nchunks; c++) {
+                const float *Cs;
+                if (RESIDENT) {
+                    Cs = lds + i * lvl_floats;
+                } else {
+                    __syncthreads();  // previous chunk fully consumed
+                    stage_codes(lds, a, i, c * a.KC);
+                    __syncthreads();
+                    Cs = lds;
+                }
+                const float *ccs = Cs + 32 * LDK;
+                const float *arow = Cs + (8 * q) * LDK + it;
+                const int cbase = c * a.KC + 4 * q;
+                // two 16-code tiles per iteration: two independent accumulator chains keep the MFMA pipe full
+                for (int t = 0; t < a.KC; t += 32) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float a0 = arow[j * LDK + t];
+                        const float a1 = arow[j * LDK + t + 16];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, r[j], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, r[j], acc1, 0, 0, 0);
+                    }
+                    const float4 c0 = *reinterpret_cast<const float4 *>(ccs + t + 4 * q);
+                    const float4 c1 = *reinterpret_cast<const float4 *>(ccs + t + 16 + 4 * q);
+                    const float cc0[4] = {c0.x, c0.y, c0.z, c0.w};
+                    const float cc1[4] = {c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {  // ascending code index inside the lane: strict < keeps the first min
+                        const float d0 = fmaf(-2.0f, acc0[g], xx + cc0[g]);
+                        if (d0 < best) { best = d0; bidx = cbase + t + g; }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const float d1 = fmaf(-2.0f, acc1[g], xx + cc1[g]);
+                        if (d1 < best) { best = d1; bidx = cbase + t + 16 + g; }
+                    }
+                }
+            }
+            // combine the 4 quarter-lanes of the item; equal distances resolve to the lowest code index
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ob = __shfl_xor(best, o);
+                const int oi = __shfl_xor(bidx, o);
+                if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            }
+            float e[8];
+            load8(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 8 * q, e);
+            const float cce = a.cc[(int64_t)i * a.K + bidx];
+            float o[8], u[8], qv[8], w[8];
+            level_output<MODE, TRAIN>(r, e, xx, cce, o, u, qv, w);
+            float df[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) df[j] = r[j] - e[j];
+            const float l1 = dotQ(df, df);  // loss.py:41-44: both terms are numerically |r-e|^2
+            loss = loss + (l1 + a.beta * l1);
+            if (valid) {
+                if (q == 0) a.ids[item * a.L + i] = (int64_t)bidx;
+                if (a.emb_cat != nullptr) store8(a.emb_cat + item * a.ld_cat + i * D + 8 * q, o);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                esum[j] = (i == 0) ? o[j] : esum[j] + o[j];
+                r[j] = r[j] - o[j];
+            }
+        }
+        if (valid) {
+            if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
+            if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: recompute the residual chain from z and ids, then walk the levels in reverse
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    const float *y;
+    const float *z;
+    int64_t B;
+    int normalize_input;
+    const float *cb_eff;
+    const float *cc;
+    int64_t K;
+    float beta;
+    const int64_t *ids;
+    const float *g_cat;
+    int64_t ld_gcat;
+    const float *g_sum;
+    const float *g_z_in;
+    float gq;
+    const float *gq_items;  // per-item d(loss)/d(qloss[b]) (overrides gq when not null)
+    float *g_y;
+    float *dE_rows;
+};
+
+template <int MODE, int L>
+__global__ __launch_bounds__(WG_THREADS) void rq_backward_kernel(BwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int it = lane & 15, q = lane >> 4;
+    const int64_t item = ((int64_t)blockIdx.x * 4 + wave) * ITEMS_PER_WAVE + it;
+    const bool valid = item < a.B;
+    const int64_t src = valid ? item : a.B - 1;
+    float rs[L][8];
+    int64_t code[L];
+    float zr[8];
+    load8(a.z + src * D + 8 * q, zr);
+    {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = zr[j];
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) rs[i][j] = r[j];
+            code[i] = a.ids[src * L + i];
+            if (i + 1 < L) {
+                float e[8], o[8], u[8], qv[8], w[8];
+                load8(a.cb_eff + ((int64_t)i * a.K + code[i]) * D + 8 * q, e);
+                const float xx = dotQ(r, r);
+                level_output<MODE, true>(r, e, xx, a.cc[(int64_t)i * a.K + code[i]], o, u, qv, w);
+#pragma unroll
+                for (int j = 0; j < 8; j++) r[j] = r[j] - o[j];
+            }
+        }
+    }
+    float gs[8];
+    if (a.g_sum != nullptr) load8(a.g_sum + src * D + 8 * q, gs);
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) gs[j] = 0.0f;
+    }
+    float R[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) R[j] = 0.0f;
+#pragma unroll
+    for (int i = L - 1; i >= 0; i--) {
+        float e[8];
+        load8(a.cb_eff + ((int64_t)i * a.K + code[i]) * D + 8 * q, e);
+        float go[8];
+        if (a.g_cat != nullptr) load8(a.g_cat + src * a.ld_gcat + i * D + 8 * q, go);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) go[j] = 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) go[j] = (go[j] + gs[j]) - R[j];  // o_i feeds sum, concat and -r_{i+1}
+        float jt[8];
+        if (MODE == HIDVAE_MODE_STE) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) jt[j] = go[j];
+        } else {  // d o / d r = I - 2 w w^T + 2 q u^T with (u,q,w) constants  =>  J^T g = g - 2 w (w.g) + 2 u (q.g)
+            float o[8], u[8], qv[8], w[8];
+            const float xx = dotQ(rs[i], rs[i]);
+            level_output<MODE, true>(rs[i], e, xx, a.cc[(int64_t)i * a.K + code[i]], o, u, qv, w);
+            const float wg = dotQ(w, go), qg = dotQ(qv, go);
+#pragma unroll
+            for (int j = 0; j < 8; j++) jt[j] = (go[j] - 2.0f * (wg * w[j])) + 2.0f * (qg * u[j]);
+        }
+        float de[8];
+        const float gqb = a.gq_items != nullptr ? a.gq_items[src] : a.gq;
+        const float cq = 2.0f * gqb, cr = 2.0f * a.beta * gqb;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float df = rs[i][j] - e[j];
+            R[j] = (R[j] + jt[j]) + cr * df;  // commitment term: beta |r - sg(e)|^2
+            de[j] = -(cq * df);               // codebook term:   |sg(r) - e|^2
+        }
+        if (valid && a.dE_rows != nullptr) store8(a.dE_rows + item * (L * D) + i * D + 8 * q, de);
+    }
+    if (a.g_z_in != nullptr) {
+        float gz[8];
+        load8(a.g_z_in + src * D + 8 * q, gz);
+#pragma unroll
+        for (int j = 0; j < 8; j++) R[j] = R[j] + gz[j];
+    }
+    if (a.normalize_input) {  // z = y / max(|y|, eps)  =>  g_y = (g_z - z (z.g_z)) / max(|y|, eps)
+        float yv[8];
+        load8(a.y + src * D + 8 * q, yv);
+        const float den = fmaxf(sqrtf(dotQ(yv, yv)), 1e-12f);
+        const float zg = dotQ(zr, R);
+#pragma unroll
+        for (int j = 0; j < 8; j++) R[j] = (R[j] - zr[j] * zg) / den;
+    }
+    if (valid) store8(a.g_y + item * D + 8 * q, R);
+}
+
+// ------------------------------------------------------------------------------------------------
+// codebook gradient: one wave per (level, code); items scanned in ascending order => bit-reproducible
+// ------------------------------------------------------------------------------------------------
+struct CbGradArgs {
+    const int64_t *ids;
+    const float *dE_rows;
+    int64_t B;
+    int L;
+    int64_t K;
+    const float *E[HIDVAE_MAX_LEVELS];
+    const float *cb_eff;
+    int normalize[HIDVAE_MAX_LEVELS];
+    float *gE[HIDVAE_MAX_LEVELS];
+    int accumulate;
+};
+
+__global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= (int64_t)a.L * a.K) return;
+    const int lvl = (int)(row / a.K);
+    const int64_t k = row - (int64_t)lvl * a.K;
+    const int d = lane & 31;
+    float acc = 0.0f;
+    for (int64_t b0 = 0; b0 < a.B; b0 += 64) {
+        const int64_t b = b0 + lane;
+        const bool hit = b < a.B && a.ids[b * a.L + lvl] == k;
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            acc += a.dE_rows[(b0 + j) * ((int64_t)a.L * D) + lvl * D + d];
+        }
+    }
+    if (a.normalize[lvl]) {  // c = E / max(|E|, eps)  =>  gE = (g - c (c.g)) / max(|E|, eps)
+        const float ev = a.E[lvl][k * D + d];
+        const float cv = a.cb_eff[row * D + d];
+        float n2 = ev * ev, cg = cv * acc;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            n2 += __shfl_xor(n2, o);
+            cg += __shfl_xor(cg, o);
+        }
+        acc = (acc - cv * cg) / fmaxf(sqrtf(n2), 1e-12f);
+    }
+    if (lane < 32) {
+        float *dst = a.gE[lvl] + k * D + d;
+        *dst = a.accumulate ? *dst + acc : acc;
+    }
+}
+
+// rows of 32 L2-normalised with the same partial-sum order as the RQ prologue, so HRqVae.encode() and the
+// fused forward produce the same z bit for bit (modules/normalize.py:7-8)
+__global__ __launch_bounds__(WG_THREADS) void l2norm32_kernel(const float *x, int64_t M, int64_t ldx, float eps, float *out,
+                                                              int64_t ldo, float *norms) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int it = lane & 15, q = lane >> 4;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * ITEMS_PER_WAVE + it;
+    const int64_t src = row < M ? row : M - 1;
+    float v[8];
+    load8(x + src * ldx + 8 * q, v);
+    const float nrm = sqrtf(dotQ(v, v));
+    const float den = fmaxf(nrm, eps);
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = v[j] / den;
+    if (row < M) {
+        store8(out + row * ldo + 8 * q, v);
+        if (norms != nullptr && q == 0) norms[row] = nrm;
+    }
+}
+
+size_t level_lds_bytes(int KC) { return (size_t)(32 * (KC + 2) + KC) * sizeof(float); }
+
+template <int MODE, bool TRAIN>
+int launch_fwd(const FwdArgs &a, bool resident, int grid, size_t lds, hipStream_t s) {
+    if (resident) {
+        auto kern = rq_forward_kernel<MODE, TRAIN, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, a);
+    } else {
+        auto kern = rq_forward_kernel<MODE, TRAIN, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, a);
+    }
+    HV_LAUNCH_CHECK("rq_forward");
+    return HIDVAE_OK;
+}
+
+template <int MODE>
+int launch_bwd(const BwdArgs &a, int L, int grid, hipStream_t s) {
+    switch (L) {
+#define HV_CASE(n) \
+    case n: hipLaunchKernelGGL((rq_backward_kernel<MODE, n>), dim3(grid), dim3(WG_THREADS), 0, s, a); break;
+        HV_CASE(1) HV_CASE(2) HV_CASE(3) HV_CASE(4) HV_CASE(5) HV_CASE(6) HV_CASE(7) HV_CASE(8)
+#undef HV_CASE
+        default: return hv_fail(HIDVAE_EINVAL, "rq_backward: L=%d out of range", L);
+    }
+    HV_LAUNCH_CHECK("rq_backward");
+    return HIDVAE_OK;
+}
+
+}  // namespace
+
+extern "C" int hidvae_codebook_prepare(const float *const *E_host, const int32_t *normalize_host, int L, int64_t K,
+                                       float *cb_eff, float *cc, void *stream) {
+    HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "codebook_prepare: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
+    HV_REQUIRE(K >= 1 && E_host && cb_eff && cc, "codebook_prepare: bad arguments");
+    PrepArgs a{};
+    for (int i = 0; i < L; i++) {
+        a.E[i] = E_host[i];
+        a.normalize[i] = normalize_host ? normalize_host[i] : 0;
+    }
+    a.L = L; a.K = K; a.cb_eff = cb_eff; a.cc = cc;
+    const int grid = (int)hv_cdiv((int64_t)L * K, ITEMS_PER_WG);
+    hipLaunchKernelGGL(codebook_prepare_kernel, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("codebook_prepare");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input, const float *cb_eff, const float *cc,
+                                 int L, int64_t K, int mode, int training, float beta, float *z, int64_t *ids,
+                                 float *emb_cat, int64_t ld_cat, float *emb_sum, float *res_cat, float *qloss,
+                                 void *stream) {
+    HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "rq_forward: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
+    HV_REQUIRE(B >= 1 && K >= 1, "rq_forward: empty batch or codebook (B=%lld K=%lld)", (long long)B, (long long)K);
+    HV_REQUIRE(y && cb_eff && cc && ids, "rq_forward: null pointer");
+    HV_REQUIRE(mode == HIDVAE_MODE_STE || mode == HIDVAE_MODE_ROTATION || !training,
+               "rq_forward: mode %d is not fused (GUMBEL_SOFTMAX is composed from GEMM + softmax)", mode);
+    HV_REQUIRE(emb_cat == nullptr || (ld_cat >= (int64_t)L * D && ld_cat % 4 == 0), "rq_forward: ld_cat=%lld", (long long)ld_cat);
+    FwdArgs a{};
+    a.y = y; a.B = B; a.normalize_input = normalize_input; a.cb_eff = cb_eff; a.cc = cc; a.L = L; a.K = K;
+    const int64_t Kp = hv_cdiv(K, 32) * 32;
+    a.KC = (int)(Kp < MAX_KC ? Kp : MAX_KC);
+    a.nchunks = (int)hv_cdiv(K, a.KC);
+    a.beta = beta; a.z = z; a.ids = ids; a.emb_cat = emb_cat; a.ld_cat = ld_cat; a.emb_sum = emb_sum;
+    a.res_cat = res_cat; a.qloss = qloss;
+    const size_t per_level = level_lds_bytes(a.KC);
+    const bool resident = a.nchunks == 1 && per_level * (size_t)L <= 152 * 1024;
+    const size_t lds = resident ? per_level * (size_t)L : per_level;
+    const int64_t ntiles = hv_cdiv(B, ITEMS_PER_WG);
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU (LDS-limited), grid-stride over tiles
+    hipStream_t s = (hipStream_t)stream;
+    if (!training) return launch_fwd<HIDVAE_MODE_STE, false>(a, resident, grid, lds, s);
+    if (mode == HIDVAE_MODE_STE) return launch_fwd<HIDVAE_MODE_STE, true>(a, resident, grid, lds, s);
+    return launch_fwd<HIDVAE_MODE_ROTATION, true>(a, resident, grid, lds, s);
+}
+
+extern "C" int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_input, const float *cb_eff,
+                                  const float *cc, int L, int64_t K, int mode, float beta, const int64_t *ids,
+                                  const float *g_cat, int64_t ld_gcat, const float *g_sum, const float *g_z_in,
+                                  float gq, const float *gq_items, float *g_y, float *dE_rows, void *stream) {
+    HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "rq_backward: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
+    HV_REQUIRE(B >= 1 && K >= 1 && z && cb_eff && cc && ids && g_y, "rq_backward: bad arguments");
+    HV_REQUIRE(!normalize_input || y, "rq_backward: normalize_input needs y");
+    HV_REQUIRE(mode == HIDVAE_MODE_STE || mode == HIDVAE_MODE_ROTATION, "rq_backward: mode %d is not fused", mode);
+    HV_REQUIRE(g_cat == nullptr || (ld_gcat >= (int64_t)L * D && ld_gcat % 4 == 0), "rq_backward: ld_gcat=%lld", (long long)ld_gcat);
+    BwdArgs a{y, z, B, normalize_input, cb_eff, cc, K, beta, ids, g_cat, ld_gcat, g_sum, g_z_in, gq, gq_items, g_y, dE_rows};
+    const int grid = (int)hv_cdiv(B, ITEMS_PER_WG);
+    if (mode == HIDVAE_MODE_STE) return launch_bwd<HIDVAE_MODE_STE>(a, L, grid, (hipStream_t)stream);
+    return launch_bwd<HIDVAE_MODE_ROTATION>(a, L, grid, (hipStream_t)stream);
+}
+
+extern "C" int hidvae_codebook_grad(const int64_t *ids, const float *dE_rows, int64_t B, int L, int64_t K,
+                                    const float *const *E_host, const float *cb_eff, const int32_t *normalize_host,
+                                    float *const *gE_host, int accumulate, void *stream) {
+    HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS && B >= 1 && K >= 1, "codebook_grad: bad sizes");
+    HV_REQUIRE(ids && dE_rows && E_host && cb_eff && gE_host, "codebook_grad: null pointer");
+    CbGradArgs a{};
+    a.ids = ids; a.dE_rows = dE_rows; a.B = B; a.L = L; a.K = K; a.cb_eff = cb_eff; a.accumulate = accumulate;
+    for (int i = 0; i < L; i++) {
+        a.E[i] = E_host[i];
+        a.normalize[i] = normalize_host ? normalize_host[i] : 0;
+        a.gE[i] = gE_host[i];
+    }
+    const int grid = (int)hv_cdiv((int64_t)L * K, 4);
+    hipLaunchKernelGGL(codebook_grad_kernel, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("codebook_grad");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_l2norm32_fwd(const float *x, int64_t M, int64_t ldx, float eps, float *out, int64_t ldo, float *norms,
+                                   void *stream) {
+    HV_REQUIRE(x && out && M >= 1 && ldx >= 32 && ldo >= 32 && ldx % 4 == 0 && ldo % 4 == 0, "l2norm32: bad arguments");
+    hipLaunchKernelGGL(l2norm32_kernel, dim3((unsigned)hv_cdiv(M, ITEMS_PER_WG)), dim3(WG_THREADS), 0, (hipStream_t)stream, x, M,
+                       ldx, eps, out, ldo, norms);
+    HV_LAUNCH_CHECK("l2norm32");
+    return HIDVAE_OK;
+}

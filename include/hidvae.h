@@ -1,0 +1,154 @@
+/* hidvae.h -- C ABI of the MI355X-native (gfx950) HiD-VAE tokenizer hot path.
+ *
+ * The reference (FDzhaozi/HiD-VAE) has NO native/FFI layer: its "operator interface" for this path
+ * is the Python API of modules/h_rqvae.py, modules/encoder.py, modules/quantize.py, modules/loss.py
+ * and init/kmeans.py.  Each entry point below names the reference function (file:line, relative to
+ * the reference root) whose arithmetic it replaces; the Python mirror in hid-vae_amd/ binds them
+ * with ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; row-major, fp32, ids int64;
+ *   - `ld*` arguments are row strides in ELEMENTS (so column slices / concatenated views need no copy);
+ *   - the caller allocates every input, output and workspace; the library never allocates or
+ *     retains device memory, never synchronises, and launches on `stream` (a hipStream_t);
+ *   - return 0 on success, a negative HIDVAE_E* code otherwise; hidvae_last_error() gives the
+ *     message of the calling thread's last failure.  Nothing throws across this boundary.
+ *   - re-entrant: no mutable global state besides one-time kernel attribute setup.
+ */
+#ifndef HIDVAE_H
+#define HIDVAE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIDVAE_OK 0
+#define HIDVAE_EINVAL (-1)   /* bad shape / argument (mirrors the reference's asserts)            */
+#define HIDVAE_EUNSUPPORTED (-2)
+#define HIDVAE_ELAUNCH (-3)  /* hip runtime error at launch                                       */
+
+#define HIDVAE_MAX_LEVELS 8
+#define HIDVAE_EMBED_DIM 32  /* the fused RQ kernels are specialised for embed_dim = 32 (both gin configs) */
+
+/* quantize.py:17-20 QuantizeForwardMode */
+#define HIDVAE_MODE_GUMBEL 1
+#define HIDVAE_MODE_STE 2
+#define HIDVAE_MODE_ROTATION 3
+
+/* GEMM operand layouts: C[M,N] = opA(A) . opB(B) */
+#define HIDVAE_GEMM_NT 0 /* A[M,K] B[N,K]  : Linear forward   x W^T        (encoder.py:27) */
+#define HIDVAE_GEMM_NN 1 /* A[M,K] B[K,N]  : input gradient   dY W                          */
+#define HIDVAE_GEMM_TN 2 /* A[K,M] B[K,N]  : weight gradient  dY^T X                        */
+
+/* GEMM epilogues */
+#define HIDVAE_EPI_NONE 0
+#define HIDVAE_EPI_SILU 1      /* C = silu(acc+bias); if aux != NULL also aux = acc+bias (pre-activation)   */
+#define HIDVAE_EPI_RELU 2
+#define HIDVAE_EPI_GELU 3      /* exact erf GELU (nn.GELU default, h_rqvae.py:136)                          */
+#define HIDVAE_EPI_SIGMOID 4
+#define HIDVAE_EPI_DSILU 16    /* C = acc * silu'(aux)      (backward through the activation)              */
+#define HIDVAE_EPI_DRELU 17    /* C = acc * (aux > 0)        aux = forward OUTPUT or pre-activation         */
+#define HIDVAE_EPI_DGELU 18    /* C = acc * gelu'(aux)       aux = pre-activation                           */
+#define HIDVAE_EPI_DSIGMOID 19 /* C = acc * s(1-s), s = aux  aux = forward OUTPUT                           */
+
+const char *hidvae_version(void);
+const char *hidvae_last_error(void);
+
+/* ---- a2/a3/a9/a10: Linear layers (modules/encoder.py:23-36, h_rqvae.py:132-188,322-331) ------------
+ * C[M,N] (ldc) = epilogue( opA(A) opB(B) + bias[N] ).  fp32 in, fp32 MFMA (exact fmaf chain, k ascending,
+ * when split_k == 1).  split_k > 1 needs `workspace` of split_k*M*N floats and is reduced in fixed order
+ * (bit-reproducible); accumulate != 0 adds into C instead of overwriting (gradient accumulation). */
+int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K,
+                    const float *A, int64_t lda, const float *B, int64_t ldb,
+                    const float *bias, float *C, int64_t ldc,
+                    int epilogue, float *aux, int64_t ldaux,
+                    int split_k, float *workspace, int accumulate, void *stream);
+
+/* out[n] (+)= sum_m X[m,n]   (bias gradients; fixed-order two-pass, bit-reproducible).
+ * workspace: >= ceil(M/64)*N floats. */
+int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate,
+                  float *workspace, void *stream);
+
+/* ---- a4: effective codebooks (modules/quantize.py:106; h_rqvae.py:295) -----------------------------
+ * For each level i: cb_eff[i] = rows of E[i] L2-normalised iff normalize[i], cc[i][k] = |cb_eff[i][k]|^2.
+ * E_host / normalize_host are HOST arrays of L entries (device pointers / flags).
+ * cb_eff: [L][K][32], cc: [L][K] device workspaces. */
+int hidvae_codebook_prepare(const float *const *E_host, const int32_t *normalize_host, int L, int64_t K,
+                            float *cb_eff, float *cc, void *stream);
+
+/* ---- a4-a7: fused L-level residual quantisation, forward ------------------------------------------
+ * Replaces the level loop of HRqVae.get_semantic_ids (h_rqvae.py:515-552) and Quantize.forward
+ * (quantize.py:100-153) incl. the rotation trick (quantize.py:34-45) and QuantizeLoss (loss.py:41-44),
+ * plus the encoder's trailing L2 normalisation (encoder.py:32) when normalize_input != 0.
+ *   y        [B,32] encoder output (before normalisation iff normalize_input)
+ *   cb_eff   [L][K][32], cc [L][K] from hidvae_codebook_prepare
+ *   mode     HIDVAE_MODE_STE | HIDVAE_MODE_ROTATION (GUMBEL is composed from GEMM + softmax entry points)
+ *   training 0: o = e (eval branch, quantize.py:146-148)
+ * outputs (any may be NULL except ids):
+ *   z [B,32] level-0 input; ids [B,L] int64; emb_cat [B, ld_cat>=L*32] per-level o_i side by side
+ *   (level-i concat_emb of h_rqvae.py:526 is the first (i+1)*32 columns); emb_sum [B,32] = sum_i o_i
+ *   (decoder input, h_rqvae.py:607); res_cat [B, L*32] level inputs r_i; qloss [B] = sum_i loss_i. */
+int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
+                      const float *cb_eff, const float *cc, int L, int64_t K,
+                      int mode, int training, float beta,
+                      float *z, int64_t *ids, float *emb_cat, int64_t ld_cat,
+                      float *emb_sum, float *res_cat, float *qloss, void *stream);
+
+/* ---- fused RQ backward (autograd of the above) --------------------------------
+ *   g_cat [B, ld_gcat] grad wrt each o_i (NULL = 0); g_sum [B,32] grad wrt sum_i o_i (NULL = 0);
+ *   g_z_in [B,32] extra grad wrt z (uniqueness loss; NULL = 0); gq: d(loss)/d(qloss[b]) (same for all b),
+ *   or gq_items [B] per-item values (overrides gq when not NULL).
+ * outputs: g_y [B,32] grad wrt the encoder output; dE_rows [B, L*32]: per-item codebook-row gradient
+ * contributions gq*2*(e_i - r_i), summed per code by hidvae_codebook_grad in ascending item order. */
+int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_input,
+                       const float *cb_eff, const float *cc, int L, int64_t K,
+                       int mode, float beta, const int64_t *ids,
+                       const float *g_cat, int64_t ld_gcat, const float *g_sum, const float *g_z_in, float gq,
+                       const float *gq_items, float *g_y, float *dE_rows, void *stream);
+
+/* gE[i][k][:] (+)= sum_{b: ids[b,i]==k} dE_rows[b, i*32:(i+1)*32], pushed through the row-normalise
+ * Jacobian for levels with normalize[i] (E_host: raw tables, needed for |E_k|).  gE_host: L device ptrs. */
+int hidvae_codebook_grad(const int64_t *ids, const float *dE_rows, int64_t B, int L, int64_t K,
+                         const float *const *E_host, const float *cb_eff, const int32_t *normalize_host,
+                         float *const *gE_host, int accumulate, void *stream);
+
+/* ---- a3/a14: decoder tail.  x_hat = y / max(|y|,1e-12) (encoder.py:32), recon[b] = sum (x_hat-x)^2
+ * (loss.py:11-12) and, if g_y != NULL, g_y = d(sum_b gscale_b * recon[b]) / dy with gscale_b = gscale_items[b]
+ * (or the scalar gscale when gscale_items == NULL; 1/B for .mean()). */
+int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, int64_t N, float gscale,
+                         const float *gscale_items, float *x_hat, float *recon, float *g_y, void *stream);
+
+/* rows L2-normalise forward / backward (modules/normalize.py:7-8; F.normalize in h_rqvae.py:212, loss.py:66).
+ * out = x / max(|x|, eps); norms[m] = |x_m| saved for the backward.  The N == 32 form uses the RQ kernel's
+ * summation order so that HRqVae.encode() reproduces the fused forward's z bit for bit. */
+int hidvae_l2norm_fwd(const float *x, int64_t M, int64_t N, int64_t ldx, float eps, float *out, int64_t ldo,
+                      float *norms, void *stream);
+int hidvae_l2norm32_fwd(const float *x, int64_t M, int64_t ldx, float eps, float *out, int64_t ldo, float *norms,
+                        void *stream);
+int hidvae_l2norm_bwd(const float *g, int64_t ldg, const float *out, int64_t ldo, const float *norms,
+                      int64_t M, int64_t N, float eps, float *gx, int64_t ldgx, int accumulate, void *stream);
+
+/* ---- a13: debug statistics (h_rqvae.py:643-648) ----------------------------------------------------
+ * embs_norm[b,i] = |emb_cat[b, i*32:(i+1)*32]|; *p_unique = (#distinct id tuples)/B computed by a
+ * sort-free hash census (== the reference's O(B^2 L) triu expression).  scratch: >= 4*B int64. */
+int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, int64_t B, int L,
+                    float *embs_norm, float *p_unique, int64_t *scratch, void *stream);
+
+/* ---- a16: AdamW (torch.optim.AdamW defaults; train_hidvae.py:533-563,762-766) with the cosine schedule
+ * evaluated ON DEVICE from a device step counter, so the whole step is graph-capturable.
+ * One launch updates n_tensors tensors described by device arrays (desc_* built once by the host):
+ *   p/g/m/v: arrays of device pointers; numel; base_lr; weight_decay per tensor.
+ *   step_dev: int64 device scalar = number of optimizer steps already taken (incremented by the call
+ *   when bump_step != 0).  lr_t = eta_min + (base_lr-eta_min)(1+cos(pi*t/T_max))/2 if T_max > 0 else base_lr.
+ *   grad_scale multiplies g first (1/world_size after an all-reduce SUM). */
+int hidvae_adamw_step(float *const *p_dev, const float *const *g_dev, float *const *m_dev, float *const *v_dev,
+                      const int64_t *numel_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
+                      int64_t max_numel, int64_t *step_dev, int bump_step,
+                      float beta1, float beta2, float eps, float eta_min, int64_t T_max, float grad_scale,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIDVAE_H */

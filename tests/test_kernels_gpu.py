@@ -1,0 +1,197 @@
+"""GPU: every C-ABI kernel of the core path against the oracle (bit-exact where the order is specified)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import exact, fill, torch_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def C():
+    import hidvae_amd
+    from hidvae_amd import _C
+    _C.lib()
+    return _C
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (1024, 512, 768), (128, 32, 128), (100, 38, 115), (33, 230, 691),
+                                   (7, 5, 3), (256, 768, 512)])
+def test_gemm_nt_is_the_sequential_fmaf_chain(C, M, N, K):
+    x = fill.uniform((M, K), 1, -1, 1)
+    w = fill.uniform((N, K), 2, -1, 1)
+    want = exact.linear(x, w)
+    got = C.gemm(C.GEMM_NT, dev(x), dev(w)).cpu().numpy()
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+def test_gemm_silu_epilogue_bit_exact(C):
+    x = fill.uniform((200, 96), 3, -2, 2)
+    w = fill.uniform((72, 96), 4, -1, 1)
+    want = exact.linear(x, w, silu=True)
+    aux = torch.empty((200, 72), device="cuda")
+    got = C.gemm(C.GEMM_NT, dev(x), dev(w), epilogue=C.EPI_SILU, aux=aux).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(aux.cpu().numpy(), exact.linear(x, w))
+
+
+@pytest.mark.parametrize("layout", ["NN", "TN"])
+@pytest.mark.parametrize("M,N,K,split", [(96, 80, 72, 1), (130, 67, 45, 1), (512, 768, 1024, 4), (32, 128, 1000, 3)])
+def test_gemm_other_layouts(C, layout, M, N, K, split):
+    a = fill.uniform((M, K), 5, -1, 1)
+    b = fill.uniform((K, N), 6, -1, 1)
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    if layout == "NN":
+        got = C.gemm(C.GEMM_NN, dev(a), dev(b), split_k=split)
+    else:
+        got = C.gemm(C.GEMM_TN, dev(np.ascontiguousarray(a.T)), dev(b), split_k=split)
+    assert H.rel_err(got.cpu().numpy(), want) < 2e-6
+
+
+def test_gemm_views_bias_accumulate_and_backward_epilogue(C):
+    big = dev(fill.uniform((50, 96), 7, -1, 1))
+    a = big[:, :64]  # column-slice view, lda = 96
+    w = dev(fill.uniform((40, 64), 8, -1, 1))
+    bias = dev(fill.uniform((40,), 9, -1, 1))
+    out = torch.ones((50, 40), device="cuda")
+    C.gemm(C.GEMM_NT, a, w, out=out, bias=bias, accumulate=True)
+    want = 1.0 + a.double() @ w.double().T + bias.double()
+    assert H.rel_err(out.cpu().numpy(), want.cpu().numpy()) < 2e-6
+    pre = dev(fill.uniform((50, 40), 10, -3, 3))
+    g = C.gemm(C.GEMM_NT, a, w, epilogue=C.EPI_DSILU, aux=pre)
+    s = torch.sigmoid(pre.double())
+    want = (a.double() @ w.double().T) * (s * (1 + pre.double() * (1 - s)))
+    assert H.rel_err(g.cpu().numpy(), want.cpu().numpy()) < 2e-6
+
+
+def test_colsum(C):
+    x = dev(fill.uniform((1000, 230), 11, -1, 1))
+    assert H.rel_err(C.colsum(x).cpu().numpy(), x.double().sum(0).cpu().numpy()) < 2e-6
+
+
+def _rq_inputs(B, L, K, seed, scale=1.0):
+    y = fill.gauss((B, 32), seed) * np.float32(scale)
+    tables = [fill.uniform((K, 32), seed + 1 + i, -1, 1) * np.float32(1.0 if i == 0 else 0.35 * 0.5 ** i) for i in range(L)]
+    return y, tables
+
+
+@pytest.mark.parametrize("B,L,K", [(1, 1, 1), (16, 3, 256), (1000, 3, 256), (77, 4, 1024), (130, 2, 40), (64, 8, 16),
+                                   (300, 1, 2048), (4096, 3, 256)])
+@pytest.mark.parametrize("mode,training", [(3, True), (2, True), (3, False)])
+def test_rq_forward_bit_exact_vs_c_oracle(C, B, L, K, mode, training):
+    y, tables = _rq_inputs(B, L, K, 20 + B % 7)
+    want = exact.rq_forward(y, tables, True, True, mode, training, 0.4)
+    cb, cc = C.codebook_prepare([dev(t) for t in tables], [i == 0 for i in range(L)])
+    assert np.array_equal(cb.cpu().numpy(), np.stack(want["cbs"]))
+    assert np.array_equal(cc.cpu().numpy(), np.stack(want["ccs"]))
+    z, ids, emb_cat, emb_sum, res, qloss = C.rq_forward(dev(y), cb, cc, True, mode, training, 0.4, want_res=True)
+    assert np.array_equal(ids.cpu().numpy(), want["ids"]), "semantic ids differ"
+    for got, key in ((z, "z"), (emb_cat, "emb_cat"), (emb_sum, "emb_sum"), (res, "res_cat"), (qloss, "loss")):
+        assert np.array_equal(got.cpu().numpy(), want[key]), key
+
+
+def test_rq_exact_ties_pick_lowest_index(C):
+    y = np.zeros((70, 32), np.float32)
+    y[:, 0] = 1.0
+    E = np.zeros((48, 32), np.float32)
+    E[:, 1] = 1.0
+    cb, cc = C.codebook_prepare([dev(E), dev(E.copy())], [False, False])
+    _, ids, *_ = C.rq_forward(dev(y), cb, cc, False, 2, True, 0.25)
+    assert int(ids.abs().sum()) == 0
+    E2 = E.copy()
+    E2[37] = y[0]  # a single exact match must win wherever it sits
+    cb, cc = C.codebook_prepare([dev(E2)], [False])
+    _, ids, *_ = C.rq_forward(dev(y), cb, cc, False, 2, True, 0.25)
+    assert (ids.cpu().numpy() == 37).all()
+
+
+@pytest.mark.parametrize("name", [n for n in H.case_names("case") if "gumbel" not in n and "simvq" not in n])
+def test_rq_forward_on_reference_goldens(C, name):
+    """Reference z (from the fixture) -> HIP RQ -> the reference's own ids / embeddings / losses."""
+    fx, desc = H.load(name)
+    if "z" not in fx:
+        pytest.skip("fixture stores no z")
+    cfg, P, *_ = H.inputs_of(desc)
+    tables = [P[f"layers.{i}.embedding.weight"].cuda() for i in range(cfg.n_layers)]
+    cb, cc = C.codebook_prepare(tables, [cfg.codebook_normalize and i == 0 for i in range(cfg.n_layers)])
+    z, ids, emb_cat, emb_sum, res, qloss = C.rq_forward(dev(fx["z"]), cb, cc, False, cfg.codebook_mode, desc["training"],
+                                                        cfg.commitment_weight, want_res=True)
+    assert (fx["margins"] > 1e-6).all()
+    assert np.array_equal(ids.cpu().numpy(), fx["sem_ids"].astype(np.int64))
+    L = cfg.n_layers
+    assert H.rel_err(emb_cat.cpu().numpy().reshape(-1, L, 32).transpose(0, 2, 1), fx["embeddings"]) <= 1e-5
+    assert H.rel_err(res.cpu().numpy().reshape(-1, L, 32).transpose(0, 2, 1), fx["residuals"]) <= 1e-5
+    assert H.rel_err(qloss.cpu().numpy(), fx["rqvae_loss"]) <= 1e-5
+
+
+@pytest.mark.parametrize("mode", [3, 2])
+@pytest.mark.parametrize("B,L,K,norm", [(50, 3, 256, True), (200, 4, 64, False), (17, 1, 16, True)])
+def test_rq_backward_vs_autograd(C, mode, B, L, K, norm):
+    y, tables = _rq_inputs(B, L, K, 31)
+    g_cat = fill.uniform((B, L * 32), 32, -1, 1)
+    g_sum = fill.uniform((B, 32), 33, -1, 1)
+    g_z = fill.uniform((B, 32), 34, -1, 1)
+    gq = fill.uniform((B,), 35, 0.1, 1)
+    # autograd reference (oracle) for sum(g_cat*emb) + sum(g_sum*emb.sum) + sum(g_z*z) + sum(gq*loss)
+    yt = torch.from_numpy(y).requires_grad_(True)
+    Et = [torch.from_numpy(t).requires_grad_(True) for t in tables]
+    zt = torch.nn.functional.normalize(yt, dim=-1, eps=1e-12) if norm else yt
+    res, embs, loss = zt, [], 0
+    for i in range(L):
+        cbt = torch.nn.functional.normalize(Et[i], dim=-1, eps=1e-12) if (norm and i == 0) else Et[i]
+        o, ids_i, l, _ = O.quantize_level(res, cbt, mode, 0.4, True, 0.2, None)
+        embs.append(o)
+        loss = loss + l
+        res = res - o
+    emb_cat = torch.cat(embs, -1)
+    obj = (emb_cat * torch.from_numpy(g_cat)).sum() + (sum(embs) * torch.from_numpy(g_sum)).sum() \
+        + (zt * torch.from_numpy(g_z)).sum() + (loss * torch.from_numpy(gq)).sum()
+    obj.backward()
+    cb, cc = C.codebook_prepare([dev(t) for t in tables], [norm and i == 0 for i in range(L)])
+    z, ids, *_ = C.rq_forward(dev(y), cb, cc, norm, mode, True, 0.4)
+    g_y, dE = C.rq_backward(dev(y), z, cb, cc, norm, mode, 0.4, ids, dev(g_cat), dev(g_sum), dev(g_z), 0.0, dev(gq))
+    assert H.close(g_y.cpu().numpy(), yt.grad.numpy(), 2e-5, 1e-7)
+    gE = C.codebook_grad(ids, dE, [dev(t) for t in tables], cb, [norm and i == 0 for i in range(L)])
+    for i in range(L):
+        assert H.close(gE[i].cpu().numpy(), Et[i].grad.numpy(), 2e-5, 1e-7), i
+
+
+def test_recon_and_l2norm(C):
+    y = dev(fill.gauss((300, 768), 40))
+    x = dev(fill.unit_rows((300, 768), 41))
+    gs = dev(fill.uniform((300,), 42, 0.1, 1.0))
+    yt = y.cpu().clone().requires_grad_(True)
+    xh = torch.nn.functional.normalize(yt, dim=-1, eps=1e-12)
+    rec = ((xh - x.cpu()) ** 2).sum(-1)
+    (rec * gs.cpu()).sum().backward()
+    recon, x_hat, g_y = C.recon_fwd_bwd(y, x, gscale_items=gs, want_xhat=True, want_grad=True)
+    assert H.rel_err(recon.cpu().numpy(), rec.detach().numpy()) < 1e-5
+    assert H.rel_err(x_hat.cpu().numpy(), xh.detach().numpy()) < 1e-5
+    assert H.close(g_y.cpu().numpy(), yt.grad.numpy(), 2e-5, 1e-8)
+    for n in (32, 96, 230):
+        v = dev(fill.gauss((70, n), 43))
+        out, norms = C.l2norm_fwd(v)
+        vt = v.cpu().clone().requires_grad_(True)
+        ot = torch.nn.functional.normalize(vt, dim=-1)
+        g = dev(fill.gauss((70, n), 44))
+        (ot * g.cpu()).sum().backward()
+        assert H.rel_err(out.cpu().numpy(), ot.detach().numpy()) < 1e-6
+        assert H.close(C.l2norm_bwd(g, out, norms).cpu().numpy(), vt.grad.numpy(), 1e-5, 1e-8)
+    z = dev(fill.gauss((40, 32), 45))
+    assert np.array_equal(C.l2norm_fwd(z)[0].cpu().numpy(),
+                          exact.rq_forward(z.cpu().numpy(), [np.ones((1, 32), np.float32)], True, False, 2, False, 0.0)["z"])
+
+
+def test_id_stats(C):
+    ids = torch.from_numpy(fill.ints((5000, 3), 50, 12)).cuda()
+    emb = dev(fill.gauss((5000, 96), 51))
+    norms, pu = C.id_stats(emb, ids)
+    assert abs(float(pu) - float(O.p_unique_fast(ids.cpu()))) < 1e-7
+    assert abs(float(O.p_unique(ids.cpu()[:600])) - float(C.id_stats(emb[:600], ids[:600])[1])) < 1e-7
+    assert H.rel_err(norms.cpu().numpy(), emb.cpu().reshape(5000, 3, 32).norm(dim=-1).numpy()) < 1e-6
