@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py -- items/s of one HiD-VAE tokenizer TRAIN step (forward + backward + grad all-reduce + AdamW) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL; per-rank batch fixed => weak scaling)
+
+Workload at N=1 = BASELINE.json configs[1]: Amazon-Beauty-shaped synthetic items, 768-d unit-norm inputs,
+hidden [512,256,128], D=32, 3 x 256 codebooks, ROTATION_TRICK, batch 1024 per GPU, amazon-gin hyper-parameters.
+Inputs are resident in HBM before the timed region (a pool of pre-generated batches, one D2D copy per step).
+One JSON line on rank 0 carrying `roofline` (dominant kernel, timed live with HIP events) and `cpu_baseline`
+(the oracle's torch-CPU restatement of the same step, timed on this host for a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+AMAZON = dict(commitment_weight=0.4, tag_alignment_weight=0.15, tag_prediction_weight=0.55, tag_class_counts=[38, 168, 348],
+              use_focal_loss=True, focal_loss_params={"gamma_0": 2.7, "alpha_0": 0.24, "gamma_1": 2.7, "alpha_1": 0.24,
+                                                      "gamma_2": 2.7, "alpha_2": 0.24},
+              dropout_rate=0.4, alignment_temperature=0.1, sem_id_uniqueness_weight=1.5, sem_id_uniqueness_margin=0.0)
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA = vector rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="items per GPU per step")
+    ap.add_argument("--levels", type=int, default=3)
+    ap.add_argument("--codes", type=int, default=256)
+    ap.add_argument("--tagged", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--pool", type=int, default=8, help="resident synthetic batches cycled through")
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    import hidvae_amd  # noqa: F401
+    from hidvae_amd.modules.h_rqvae import HRqVae
+    from hidvae_amd.modules.quantize import QuantizeForwardMode
+    torch.manual_seed(0)
+    m = HRqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=args.codes, codebook_kmeans_init=False,
+               codebook_normalize=True, codebook_mode=QuantizeForwardMode.ROTATION_TRICK, n_layers=args.levels, n_cat_features=0,
+               tag_embed_dim=768, **{**AMAZON, "tag_class_counts": (AMAZON["tag_class_counts"] + [500] * 8)[: args.levels]})
+    # codebooks as k-means would leave them: residual-sized, spread (k-means itself is start-up work, not part of a step)
+    with torch.no_grad():
+        for i, layer in enumerate(m.layers):
+            layer.embedding.weight.copy_((torch.rand_like(layer.embedding.weight) * 2 - 1) * (1.0 if i == 0 else 0.35 * 0.5 ** i))
+    return m.to(device).train()
+
+
+def param_groups(m, lr=2.8e-4, wd=0.015, pwd=0.015, tagged=False):
+    """train_hidvae.py:537-561 of the reference"""
+    groups = [{"params": list(m.encoder.parameters()) + list(m.decoder.parameters()), "lr": lr, "weight_decay": wd},
+              {"params": [p for layer in m.layers for p in layer.parameters()], "lr": lr, "weight_decay": wd}]
+    if tagged:
+        for i in range(m.n_layers):
+            plr, pw = lr * (1 + 0.1 * i), pwd / (1 + 0.2 * i)
+            groups.append({"params": list(m.tag_predictors[i].parameters()), "lr": plr, "weight_decay": pw})
+            groups.append({"params": list(m.tag_projectors[i].parameters()), "lr": plr, "weight_decay": pw})
+    return groups
+
+
+def synth_pool(args, device, rank):
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.nn.functional.normalize(torch.randn(args.pool, args.batch, 768, generator=g), dim=-1).to(device)
+    te = ti = None
+    if args.tagged:
+        te = torch.randn(args.pool, args.batch, args.levels, 768, generator=g).to(device)
+        classes = (AMAZON["tag_class_counts"] + [500] * 8)[: args.levels]
+        cols = [torch.randint(0, c, (args.pool, args.batch), generator=g) for c in classes]
+        ti = torch.stack(cols, dim=-1)
+        ti[torch.rand(ti.shape, generator=g) < 0.05] = -1
+        ti = ti.to(device)
+    return x, te, ti
+
+
+def time_kernel(fn, iters=50):
+    """average duration (us) of `fn` launched back to back on torch's current stream, by HIP events on that stream"""
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def kernel_rooflines(args, m, device):
+    """Live per-kernel timings on the bench shapes: the fused RQ forward (HBM roofline, algorithmic bytes per item from
+    SURVEY.md 8d) and the largest GEMMs of the step (fp32 MFMA roofline)."""
+    from hidvae_amd import _C
+    B, L, K = args.batch, args.levels, args.codes
+    out = []
+    y = torch.randn(B, 32, device=device)
+    tables = [layer.embedding.weight.detach() for layer in m.layers]
+    flags = [i == 0 for i in range(L)]
+    cb, cc = _C.codebook_prepare(tables, flags)
+    t = time_kernel(lambda: _C.rq_forward(y, cb, cc, True, 3, True, 0.4))
+    bytes_item = 128 + 8 * L + 4 * 32 * L + 128 + 4  # read y, write ids, emb_cat, emb_sum(+z), loss   (tagged layout)
+    alg = bytes_item * B + 4 * L * K * 32
+    out.append(dict(kernel="rq_forward_kernel", bound="hbm", achieved=alg / t * 1e-3, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=alg / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t, algorithmic_bytes=alg,
+                    mfma_f32_frac=2.0 * B * L * K * 32 / t * 1e-6 / MFMA_F32_PEAK_TF))
+    x = torch.randn(B, 768, device=device)
+    w0 = m.encoder.mlp[0].weight.detach()
+    t = time_kernel(lambda: _C.gemm(_C.GEMM_NT, x, w0, epilogue=_C.EPI_SILU))
+    fl = 2.0 * B * 768 * 512
+    out.append(dict(kernel="gemm_f32_kernel<NT> enc0 [B,768]x[768,512]", bound="mfma", achieved=fl / t * 1e-6, peak=MFMA_F32_PEAK_TF,
+                    unit="TFLOP/s", frac=fl / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None, us=t))
+    g = torch.randn(B, 512, device=device)
+    t = time_kernel(lambda: _C.gemm(_C.GEMM_TN, g, x, split_k=3))
+    out.append(dict(kernel="gemm_f32_kernel<TN> dW enc0 [512,B]x[B,768] split-K", bound="mfma", achieved=fl / t * 1e-6,
+                    peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None, us=t))
+    return out
+
+
+def cpu_baseline(args, budget_s):
+    """The oracle's torch-CPU restatement of the SAME step (fwd + bwd + torch AdamW, reference op sequence incl. the
+    O(B^2) p_unique_ids), timed on this host.  This is the checker being timed as a baseline, never the product."""
+    from oracle import torch_oracle as O
+    cfg = O.Cfg(n_layers=args.levels, codebook_size=args.codes, codebook_mode=O.ROTATION,
+                **{**AMAZON, "tag_class_counts": (AMAZON["tag_class_counts"] + [500] * 8)[: args.levels]})
+    P = O.formula_params(cfg, seed=100, with_tags=bool(args.tagged))
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    opt = torch.optim.AdamW(list(Pg.values()), lr=2.8e-4, weight_decay=0.015)
+    x, te, ti = O.formula_batch(cfg, args.batch, seed=7, tagged=bool(args.tagged))
+    bn = None
+    if args.tagged:
+        bn = {f"tag_projectors.{i}.1.running_{s}": (torch.zeros(512) if s == "mean" else torch.ones(512))
+              for i in range(args.levels) for s in ("mean", "var")}
+    rand = O.TorchRand(cfg.mixup_alpha)
+    n, t0, first = 0, time.perf_counter(), None
+    while True:
+        opt.zero_grad()
+        out = O.forward(Pg, cfg, x, te, ti, gumbel_t=0.2, training=True, rand=rand, bn_buffers=bn)
+        out["loss"].backward()
+        opt.step()
+        n += 1
+        if n == 2:
+            first = time.perf_counter()  # two warm-up steps
+        if first is not None and (time.perf_counter() - first > budget_s or n >= 2 + 200):
+            break
+    dt = time.perf_counter() - first
+    steps = n - 2
+    return dict(value=args.batch * steps / dt, unit="items/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} full train steps (fwd+bwd+AdamW) of the oracle's torch-CPU restatement at B={args.batch}, "
+                       f"{'tagged' if args.tagged else 'untagged'}, after 2 warm-up steps; {dt:.1f} s")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    from hidvae_amd.optim import HidvaeAdamW
+    m = build_model(args, device)
+    if world > 1:  # replicas start identical (DDP semantics: rank 0's parameters are broadcast)
+        for p in m.parameters():
+            dist.broadcast(p.data, 0)
+    opt = HidvaeAdamW(param_groups(m, tagged=bool(args.tagged)), cosine=(400000, 7e-8), flat_grads=world > 1).prepare()
+    pool_x, pool_te, pool_ti = synth_pool(args, device, rank)
+    batch = types.SimpleNamespace(x=torch.empty_like(pool_x[0]))
+    if args.tagged:
+        batch.tags_emb, batch.tags_indices = torch.empty_like(pool_te[0]), torch.empty_like(pool_ti[0])
+
+    def load(i):  # "next_batch": one resident batch -> the static step inputs
+        batch.x.copy_(pool_x[i % args.pool])
+        if args.tagged:
+            batch.tags_emb.copy_(pool_te[i % args.pool])
+            batch.tags_indices.copy_(pool_ti[i % args.pool])
+
+    last = {}
+
+    def fwd_bwd():
+        opt.zero_grad()
+        out = m(batch, gumbel_t=0.2)
+        out.loss.backward()
+        last["loss"] = out.loss.detach()
+
+    def step_eager():
+        fwd_bwd()
+        if world > 1:
+            dist.all_reduce(opt.flat_grad)  # ONE RCCL all-reduce of the flat gradient buffer; 1/world folded into AdamW
+            opt.grad_scale = 1.0 / world
+        opt.step()
+
+    use_graph = bool(args.graph)
+    graphs = None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(3):  # allocator / kernel-attribute warm-up outside any capture
+            load(i)
+            step_eager()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            if world > 1:  # collectives stay outside the graphs: [fwd+bwd] -> all-reduce -> [AdamW]
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    fwd_bwd()
+                opt.grad_scale = 1.0 / world
+                with torch.cuda.graph(g2):
+                    opt.step()
+                graphs = (g1, g2)
+            else:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    step_eager()
+                graphs = (g1,)
+        except Exception as e:  # noqa: BLE001  report and run eagerly rather than die
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graphs, use_graph = None, False
+            torch.cuda.synchronize()
+
+    def step(i):
+        load(i)
+        if graphs is None:
+            step_eager()
+        elif len(graphs) == 1:
+            graphs[0].replay()
+        else:
+            graphs[0].replay()
+            dist.all_reduce(opt.flat_grad)
+            graphs[1].replay()
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(last["loss"]) if "loss" in last else float("nan")
+
+    if rank == 0:
+        ks = kernel_rooflines(args, m, device)
+        # dominant kernel of the step = the one with the most time per step among the timed classes
+        roof = max(ks, key=lambda k: k["us"])
+        line = {
+            "metric": "item-embeddings/sec HiD-VAE train step, 768-d in, 3x256 codebooks",
+            "value": args.batch * world * args.steps / dt, "unit": "items/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Amazon-Beauty-shaped synthetic 768-d, {args.levels}x{args.codes} codebooks, batch {args.batch}/GPU, "
+                                   f"ROTATION_TRICK, {'tagged (projector+InfoNCE+predictor+focal/mixup)' if args.tagged else 'untagged core'}"
+                                   f" train step = fwd+bwd+{'RCCL all-reduce+' if world > 1 else ''}AdamW(cosine)",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(use_graph)},
+            "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"], "us_per_launch": roof["us"]},
+            "kernels": ks, "final_loss": final_loss,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,9 +26,12 @@ _SIGNATURES = {
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
-    "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp],
+    "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _vp],
+    "hidvae_uniq_loss": [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
+    "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
+    "hidvae_total_loss_bwd": [_vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp],
     "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp],
-    "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _i64, _vp, _vp, _vp, _vp],
     "hidvae_l2norm_fwd": [_vp, _i64, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm32_fwd": [_vp, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _f, _vp, _i64, _i, _vp],
@@ -91,12 +94,20 @@ def _row_stride(t, name):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+def _vec_stride(t):
+    """element stride of a per-item vector (0 for an expanded scalar, or for a 0-d tensor)."""
+    if t is None or t.dim() == 0:
+        return 0
+    return t.stride(0)
+
+
 def _host_ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
 # ------------------------------------------------------------------------------------------------
-def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k=1, accumulate=False):
+def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k=1, accumulate=False, mask=None,
+         mask_scale=1.0):
     """C = epilogue(op(A) op(B) + bias).  NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
     _f32(A, "A"), _f32(B, "B")
     lda, ldb = _row_stride(A, "A"), _row_stride(B, "B")
@@ -175,7 +186,8 @@ def rq_backward(y, z, cb_eff, cc, normalize_input, mode, beta, ids, g_cat, g_sum
     dE = torch.empty((B, L * EMBED_DIM), device=z.device, dtype=torch.float32)
     ldg = _row_stride(g_cat, "g_cat") if g_cat is not None else 0
     _check(lib().hidvae_rq_backward(_p(y), _p(z), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, int(mode), float(beta),
-                                    _p(ids), _p(g_cat), ldg, _p(g_sum), _p(g_z_in), float(gq), _p(gq_items), _p(g_y), _p(dE),
+                                    _p(ids), _p(g_cat), ldg, _p(g_sum), _p(g_z_in),
+                                    int(g_z_in.shape[0]) if g_z_in is not None else 0, float(gq), _p(gq_items), _vec_stride(gq_items), _p(g_y), _p(dE),
                                     _stream()), "hidvae_rq_backward")
     return g_y, dE
 
@@ -191,7 +203,7 @@ def codebook_grad(ids, dE_rows, tables, cb_eff, normalize_flags, grads=None, acc
     return grads
 
 
-def recon_fwd_bwd(y, x, gscale=0.0, gscale_items=None, want_xhat=False, want_grad=False):
+def recon_fwd_bwd(y, x, gscale=1.0, gscale_items=None, want_xhat=False, want_grad=False):
     _f32(y, "y"), _f32(x, "x")
     if y.shape != x.shape or not y.is_contiguous() or not x.is_contiguous():
         raise RuntimeError(f"recon: shapes differ or not contiguous ({tuple(y.shape)} vs {tuple(x.shape)})")
@@ -199,7 +211,8 @@ def recon_fwd_bwd(y, x, gscale=0.0, gscale_items=None, want_xhat=False, want_gra
     x_hat = torch.empty_like(y) if want_xhat else None
     recon = torch.empty((B,), device=y.device, dtype=torch.float32)
     g_y = torch.empty_like(y) if want_grad else None
-    _check(lib().hidvae_recon_fwd_bwd(_p(y), _p(x), B, N, float(gscale), _p(gscale_items), _p(x_hat), _p(recon), _p(g_y), _stream()),
+    _check(lib().hidvae_recon_fwd_bwd(_p(y), _p(x), B, N, float(gscale), _p(gscale_items), _vec_stride(gscale_items), _p(x_hat), _p(recon),
+                                      _p(g_y), _stream()),
            "hidvae_recon_fwd_bwd")
     return recon, x_hat, g_y
 
@@ -240,6 +253,35 @@ def id_stats(emb_cat, ids, want_norms=True):
 
 def adamw_step(desc, step_dev, bump_step, beta1, beta2, eps, eta_min, T_max, grad_scale):
     """desc: dict of device arrays built by optim.HidvaeAdamW (p/g/m/v pointer tables, numel, lr, wd)."""
-    _check(lib().hidvae_adamw_step(_p(desc["p"]), _p(desc["g"]), _p(desc["m"]), _p(desc["v"]), _p(desc["numel"]), _p(desc["lr"]),
+    _check(lib().hidvae_adamw_step(_p(desc["p"]), desc["g_host"], _p(desc["m"]), _p(desc["v"]), _p(desc["numel"]), _p(desc["lr"]),
                                    _p(desc["wd"]), int(desc["n"]), int(desc["max_numel"]), _p(step_dev), int(bump_step), float(beta1),
                                    float(beta2), float(eps), float(eta_min), int(T_max), float(grad_scale), _stream()), "hidvae_adamw_step")
+
+
+def uniq_loss(ids, z, weight, margin, want_grad=False):
+    B, L = ids.shape
+    loss = torch.empty((), device=ids.device, dtype=torch.float32)
+    g_rows = torch.empty((L, EMBED_DIM), device=ids.device, dtype=torch.float32) if want_grad else None
+    _check(lib().hidvae_uniq_loss(_p(ids), _p(z), B, L, float(weight), float(margin), _p(loss), _p(g_rows), _stream()), "hidvae_uniq_loss")
+    return loss, g_rows
+
+
+def total_loss(recon, qloss, align, pred, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want_grad):
+    """-> (loss, uniq, g_rows).  ids/z None skips the uniqueness term."""
+    dev = recon.device
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    uniq = torch.empty((), device=dev, dtype=torch.float32)
+    L = ids.shape[1] if ids is not None else 0
+    g_rows = torch.empty((L, EMBED_DIM), device=dev, dtype=torch.float32) if (want_grad and ids is not None) else None
+    _check(lib().hidvae_total_loss(_p(recon), _p(qloss), recon.shape[0], _p(align), _p(pred), _p(ids), _p(z), L, float(uniq_weight),
+                                   float(uniq_margin), float(w_a), float(w_p), float(w_u), _p(loss), _p(uniq), _p(g_rows), _stream()),
+           "hidvae_total_loss")
+    return loss, uniq, g_rows
+
+
+def total_loss_bwd(g_loss, B, L, w_a, w_p, w_u, g_rows, want_gz):
+    scal = torch.empty((3,), device=g_loss.device, dtype=torch.float32)
+    g_z = torch.empty((B, EMBED_DIM), device=g_loss.device, dtype=torch.float32) if want_gz else None
+    _check(lib().hidvae_total_loss_bwd(_p(g_loss), B, L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(scal), _p(g_z), _stream()),
+           "hidvae_total_loss_bwd")
+    return scal, g_z

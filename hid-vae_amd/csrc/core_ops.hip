@@ -14,12 +14,12 @@ constexpr int MAXV = 4;  // N <= 64 lanes * 4 floats * MAXV = 1024 on the vector
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void recon_kernel(const float *y, const float *x, int64_t B, int64_t N, float gscale_all,
-                                                    const float *gscale_items, float *x_hat, float *recon, float *g_y) {
+                                                    const float *gscale_items, int64_t gs_stride, float *x_hat, float *recon, float *g_y) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
     const float *yr = y + row * N, *xr = x + row * N;
-    const float gscale = gscale_items != nullptr ? gscale_items[row] : gscale_all;
+    const float gscale = gscale_items != nullptr ? gscale_all * gscale_items[row * gs_stride] : gscale_all;
     if (VEC) {
         const int nv = (int)(N / 4);
         float4 yv[MAXV], xv[MAXV];
@@ -126,9 +126,12 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *g, int64_t
 // ---------------------------------------------------------------------------------------------------
 // AdamW.  blockIdx.y = tensor, blockIdx.x strides over its elements.
 // ---------------------------------------------------------------------------------------------------
+constexpr int ADAM_CHUNK = 128;  // gradient pointers travel BY VALUE in the kernel arguments (they change every step
+                                  // under autograd; parameters / moments / hyper-parameters are fixed device tables)
 struct AdamArgs {
     float *const *p;
-    const float *const *g;
+    const float *g[ADAM_CHUNK];
+    int first;  // index of g[0] in the device tables
     float *const *m;
     float *const *v;
     const int64_t *numel;
@@ -140,7 +143,7 @@ struct AdamArgs {
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
-    const int t = blockIdx.y;
+    const int t = a.first + blockIdx.y;
     const int64_t n = a.numel[t];
     const int64_t step = *a.step + 1;  // torch counts the step being taken from 1
     double lr = (double)a.base_lr[t];
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     const float step_size = (float)(lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     float *p = a.p[t], *m = a.m[t], *v = a.v[t];
-    const float *g = a.g[t];
+    const float *g = a.g[blockIdx.y];
     const float w1 = 1.0f - a.beta1, w2 = 1.0f - a.beta2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i] * a.grad_scale;
@@ -223,29 +226,40 @@ __global__ void id_stats_final_kernel(const int64_t *table, int64_t tsize, int64
 }  // namespace
 
 extern "C" int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, int64_t N, float gscale,
-                                    const float *gscale_items, float *x_hat, float *recon, float *g_y, void *stream) {
+                                    const float *gscale_items, int64_t gs_stride, float *x_hat, float *recon, float *g_y,
+                                    void *stream) {
     HV_REQUIRE(y && x && B >= 1 && N >= 1, "recon: bad arguments");
     const unsigned grid = (unsigned)hv_cdiv(B, 4);
     const bool vec = (N % 4 == 0) && N <= 256 * MAXV && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x) |
                                                           reinterpret_cast<uintptr_t>(x_hat) | reinterpret_cast<uintptr_t>(g_y)) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(recon_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, gscale, gscale_items, x_hat, recon, g_y);
-    else hipLaunchKernelGGL(recon_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, gscale, gscale_items, x_hat, recon, g_y);
+    if (vec) hipLaunchKernelGGL(recon_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, gscale, gscale_items, gs_stride, x_hat, recon, g_y);
+    else hipLaunchKernelGGL(recon_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, gscale, gscale_items, gs_stride, x_hat, recon, g_y);
     HV_LAUNCH_CHECK("recon_fwd_bwd");
     return HIDVAE_OK;
 }
 
-extern "C" int hidvae_adamw_step(float *const *p_dev, const float *const *g_dev, float *const *m_dev, float *const *v_dev,
+extern "C" int hidvae_adamw_step(float *const *p_dev, const float *const *g_host, float *const *m_dev, float *const *v_dev,
                                  const int64_t *numel_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
                                  int64_t max_numel, int64_t *step_dev, int bump_step, float beta1, float beta2, float eps,
                                  float eta_min, int64_t T_max, float grad_scale, void *stream) {
-    HV_REQUIRE(p_dev && g_dev && m_dev && v_dev && numel_dev && base_lr_dev && wd_dev && step_dev, "adamw: null pointer");
-    HV_REQUIRE(n_tensors >= 1 && n_tensors <= 65535 && max_numel >= 1, "adamw: bad tensor count / size");
-    AdamArgs a{p_dev, g_dev, m_dev, v_dev, numel_dev, base_lr_dev, wd_dev, step_dev, beta1, beta2, eps, eta_min, grad_scale, T_max};
+    HV_REQUIRE(p_dev && g_host && m_dev && v_dev && numel_dev && base_lr_dev && wd_dev && step_dev, "adamw: null pointer");
+    HV_REQUIRE(n_tensors >= 1 && max_numel >= 1, "adamw: bad tensor count / size");
     int64_t gx = hv_cdiv(max_numel, 256 * 4);
     if (gx > 256) gx = 256;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)gx, (unsigned)n_tensors), dim3(256), 0, s, a);
-    HV_LAUNCH_CHECK("adamw");
+    for (int first = 0; first < n_tensors; first += ADAM_CHUNK) {
+        const int cnt = n_tensors - first < ADAM_CHUNK ? n_tensors - first : ADAM_CHUNK;
+        AdamArgs a{};
+        a.p = p_dev; a.m = m_dev; a.v = v_dev; a.numel = numel_dev; a.base_lr = base_lr_dev; a.wd = wd_dev; a.step = step_dev;
+        a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.eta_min = eta_min; a.grad_scale = grad_scale; a.T_max = T_max;
+        a.first = first;
+        for (int i = 0; i < cnt; i++) {
+            HV_REQUIRE(g_host[first + i] != nullptr, "adamw: gradient %d is null", first + i);
+            a.g[i] = g_host[first + i];
+        }
+        hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, s, a);
+        HV_LAUNCH_CHECK("adamw");
+    }
     if (bump_step) {
         hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step_dev);
         HV_LAUNCH_CHECK("adamw bump");
@@ -284,5 +298,143 @@ extern "C" int hidvae_l2norm_bwd(const float *g, int64_t ldg, const float *out, 
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, g, ldg, out, ldo, norms,
                        M, N, eps, gx, ldgx, accumulate);
     HV_LAUNCH_CHECK("l2norm_bwd");
+    return HIDVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// uniqueness loss exactly as HRqVae.forward calls it (h_rqvae.py:630-631 passes ids transposed to [L,B], so the
+// LEVELS play the batch role of SemanticIdUniquenessLoss.forward, h_rqvae.py:41-105 -- SURVEY Q3), fused with the
+// total loss (h_rqvae.py:634-640).  Tiny: one workgroup; wave 0 evaluates the uniqueness term.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+// executed by ONE full wave; returns the loss on every lane; g_rows [L,32] (optional) = d loss / d z[0:L]
+__device__ float uniq_loss_wave(const int64_t *ids, const float *z, int64_t B, int L, float weight, float margin,
+                                float *g_rows) {
+    const int lane = threadIdx.x & 63;
+    const int d = lane & 31;
+    if (g_rows != nullptr)
+        for (int i = lane; i < L * 32; i += 64) g_rows[i] = 0.0f;
+    float total = 0.0f;
+    int count = 0;
+    unsigned long long flagged = 0ull;  // bit (a*8+b): levels a<b carry identical id vectors over the whole batch
+    for (int a = 0; a < L; a++)
+        for (int b = a + 1; b < L; b++) {
+            bool eq = true;
+            for (int64_t i = lane; i < B; i += 64) eq = eq && (ids[i * L + a] == ids[i * L + b]);
+            if (__all(eq)) { flagged |= 1ull << (a * 8 + b); count++; }
+        }
+    if (count > 0) {
+        for (int a = 0; a < L; a++)
+            for (int b = a + 1; b < L; b++) {
+                if (!((flagged >> (a * 8 + b)) & 1ull) || b >= B) continue;  // (b >= B: the reference would raise IndexError)
+                const float za = z[(int64_t)a * 32 + d], zb = z[(int64_t)b * 32 + d];
+                float na = za * za, nb = zb * zb;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { na += __shfl_xor(na, o); nb += __shfl_xor(nb, o); }
+                const float da = fmaxf(sqrtf(na), 1e-12f), db = fmaxf(sqrtf(nb), 1e-12f);
+                const float ha = za / da, hb = zb / db;
+                float ab = ha * hb;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) ab += __shfl_xor(ab, o);
+                const float v = ab - margin;
+                if (v > 0.0f) {
+                    total += v;
+                    if (g_rows != nullptr && lane < 32) {  // d cos / d za = (hb - ha cos) / |za|
+                        const float c = weight / (float)count;
+                        g_rows[a * 32 + d] += c * (hb - ha * ab) / da;
+                        g_rows[b * 32 + d] += c * (ha - hb * ab) / db;
+                    }
+                }
+            }
+    }
+    return count > 0 ? weight * (total / (float)count) : 0.0f;
+}
+
+__global__ __launch_bounds__(64) void uniq_loss_kernel(const int64_t *ids, const float *z, int64_t B, int L, float weight,
+                                                       float margin, float *loss, float *g_rows) {
+    const float v = uniq_loss_wave(ids, z, B, L, weight, margin, g_rows);
+    if (threadIdx.x == 0) *loss = v;
+}
+
+struct TotalArgs {
+    const float *recon, *qloss;
+    int64_t B;
+    const float *align, *pred;
+    const int64_t *ids;  // uniqueness term (nullptr = skip)
+    const float *z;
+    int L;
+    float uniq_weight, uniq_margin;
+    float w_a, w_p, w_u;
+    float *loss, *uniq, *g_rows;
+};
+
+__global__ __launch_bounds__(256) void total_loss_kernel(TotalArgs a) {
+    __shared__ float red[2][4];
+    __shared__ float uq;
+    float r = 0.0f, q = 0.0f;
+    for (int64_t i = threadIdx.x; i < a.B; i += 256) { r += a.recon[i]; q += a.qloss[i]; }
+    r = hv_wave_sum(r);
+    q = hv_wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = r; red[1][threadIdx.x >> 6] = q; }
+    if (threadIdx.x < 64) {
+        const float v = a.ids != nullptr ? uniq_loss_wave(a.ids, a.z, a.B, a.L, a.uniq_weight, a.uniq_margin, a.g_rows) : 0.0f;
+        if (threadIdx.x == 0) uq = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float rm = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)a.B;
+        const float qm = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)a.B;
+        float t = rm + qm;
+        t = t + a.w_a * (a.align != nullptr ? *a.align : 0.0f);
+        t = t + a.w_p * (a.pred != nullptr ? *a.pred : 0.0f);
+        t = t + a.w_u * uq;
+        *a.loss = t;
+        if (a.uniq != nullptr) *a.uniq = uq;
+    }
+}
+
+// scal[0] = g/B, scal[1] = g*w_a, scal[2] = g*w_p ; g_z [B,32] = g*w_u*g_rows on the first L rows, 0 elsewhere
+__global__ __launch_bounds__(256) void total_loss_bwd_kernel(const float *g_loss, int64_t B, int L, float w_a, float w_p, float w_u,
+                                                             const float *g_rows, float *scal, float *g_z) {
+    const float g = *g_loss;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx == 0) {
+        scal[0] = g / (float)B;
+        scal[1] = g * w_a;
+        scal[2] = g * w_p;
+    }
+    if (g_z != nullptr && idx < B * 32) g_z[idx] = (g_rows != nullptr && idx < (int64_t)L * 32) ? (g * w_u) * g_rows[idx] : 0.0f;
+}
+
+}  // namespace
+
+extern "C" int hidvae_uniq_loss(const int64_t *ids, const float *z, int64_t B, int L, float weight, float margin, float *loss,
+                                float *g_rows, void *stream) {
+    HV_REQUIRE(ids && z && loss && B >= 1 && L >= 1 && L <= HIDVAE_MAX_LEVELS, "uniq_loss: bad arguments");
+    hipLaunchKernelGGL(uniq_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ids, z, B, L, weight, margin, loss, g_rows);
+    HV_LAUNCH_CHECK("uniq_loss");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_total_loss(const float *recon, const float *qloss, int64_t B, const float *align, const float *pred,
+                                 const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
+                                 float w_p, float w_u, float *loss, float *uniq, float *g_rows, void *stream) {
+    HV_REQUIRE(recon && qloss && loss && B >= 1, "total_loss: bad arguments");
+    HV_REQUIRE(ids == nullptr || (z != nullptr && L >= 1 && L <= HIDVAE_MAX_LEVELS),
+               "total_loss: uniqueness term needs z and 1 <= n_layers <= %d (L=%d)", HIDVAE_MAX_LEVELS, L);
+    TotalArgs a{recon, qloss, B, align, pred, ids, z, L, uniq_weight, uniq_margin, w_a, w_p, w_u, loss, uniq, g_rows};
+    hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("total_loss");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_total_loss_bwd(const float *g_loss, int64_t B, int L, float w_a, float w_p, float w_u, const float *g_rows,
+                                     float *scal, float *g_z, void *stream) {
+    HV_REQUIRE(g_loss && scal && B >= 1, "total_loss_bwd: bad arguments");
+    const int64_t n = g_z != nullptr ? B * 32 : 1;
+    hipLaunchKernelGGL(total_loss_bwd_kernel, dim3((unsigned)hv_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g_loss, B, L, w_a,
+                       w_p, w_u, g_rows, scal, g_z);
+    HV_LAUNCH_CHECK("total_loss_bwd");
     return HIDVAE_OK;
 }

@@ -276,8 +276,10 @@ struct BwdArgs {
     int64_t ld_gcat;
     const float *g_sum;
     const float *g_z_in;
+    int64_t g_z_rows;  // rows of g_z_in that exist (B for a dense gradient, n_layers for the uniqueness term)
     float gq;
-    const float *gq_items;  // per-item d(loss)/d(qloss[b]) (overrides gq when not null)
+    const float *gq_items;  // per-item d(loss)/d(qloss[b]) at stride gq_stride (0 = one broadcast scalar), times gq
+    int64_t gq_stride;
     float *g_y;
     float *dE_rows;
 };
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(WG_THREADS) void rq_backward_kernel(BwdArgs a) {
             for (int j = 0; j < 8; j++) jt[j] = (go[j] - 2.0f * (wg * w[j])) + 2.0f * (qg * u[j]);
         }
         float de[8];
-        const float gqb = a.gq_items != nullptr ? a.gq_items[src] : a.gq;
+        const float gqb = a.gq_items != nullptr ? a.gq * a.gq_items[src * a.gq_stride] : a.gq;
         const float cq = 2.0f * gqb, cr = 2.0f * a.beta * gqb;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(WG_THREADS) void rq_backward_kernel(BwdArgs a) {
         }
         if (valid && a.dE_rows != nullptr) store8(a.dE_rows + item * (L * D) + i * D + 8 * q, de);
     }
-    if (a.g_z_in != nullptr) {
+    if (a.g_z_in != nullptr && src < a.g_z_rows) {
         float gz[8];
         load8(a.g_z_in + src * D + 8 * q, gz);
 #pragma unroll
@@ -523,13 +525,13 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
 extern "C" int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_input, const float *cb_eff,
                                   const float *cc, int L, int64_t K, int mode, float beta, const int64_t *ids,
                                   const float *g_cat, int64_t ld_gcat, const float *g_sum, const float *g_z_in,
-                                  float gq, const float *gq_items, float *g_y, float *dE_rows, void *stream) {
+                                  int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "rq_backward: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
     HV_REQUIRE(B >= 1 && K >= 1 && z && cb_eff && cc && ids && g_y, "rq_backward: bad arguments");
     HV_REQUIRE(!normalize_input || y, "rq_backward: normalize_input needs y");
     HV_REQUIRE(mode == HIDVAE_MODE_STE || mode == HIDVAE_MODE_ROTATION, "rq_backward: mode %d is not fused", mode);
     HV_REQUIRE(g_cat == nullptr || (ld_gcat >= (int64_t)L * D && ld_gcat % 4 == 0), "rq_backward: ld_gcat=%lld", (long long)ld_gcat);
-    BwdArgs a{y, z, B, normalize_input, cb_eff, cc, K, beta, ids, g_cat, ld_gcat, g_sum, g_z_in, gq, gq_items, g_y, dE_rows};
+    BwdArgs a{y, z, B, normalize_input, cb_eff, cc, K, beta, ids, g_cat, ld_gcat, g_sum, g_z_in, g_z_rows, gq, gq_items, gq_stride, g_y, dE_rows};
     const int grid = (int)hv_cdiv(B, ITEMS_PER_WG);
     if (mode == HIDVAE_MODE_STE) return launch_bwd<HIDVAE_MODE_STE>(a, L, grid, (hipStream_t)stream);
     return launch_bwd<HIDVAE_MODE_ROTATION>(a, L, grid, (hipStream_t)stream);

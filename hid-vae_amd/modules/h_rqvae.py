@@ -1,0 +1,300 @@
+"""HRqVae on the MI355X-native path: same constructor / methods / state-dict keys as the reference
+(modules/h_rqvae.py:230-756), but forward() is a short chain of fused HIP launches:
+
+    x --[MFMA GEMM+SiLU x4]--> y --[fused RQ: l2norm, L x (search, rotation/STE, loss, residual)]--> z, ids, o_i, sum o_i
+      --[tag heads on the concatenated o_i: projector, InfoNCE, predictor, focal+mixup]--
+      --[MFMA GEMM+SiLU x4]--> y_dec --[l2norm + reconstruction loss]--> recon --[total loss + uniqueness term]--> loss
+
+The reference's quirks that change results are reproduced on purpose and cited where they occur
+(Q3 transposed uniqueness call, Q4 double weights, Q5 layer_idx=0, Q6 rotation residuals)."""
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from .. import _C
+from ..data.schemas import HRqVaeComputedLosses, HRqVaeOutput
+from ..ops import RQFn, TotalLossFn
+from .encoder import MLP
+from .loss import QuantizeLoss, ReconstructionLoss, TagAlignmentLoss, TagPredictionLoss  # noqa: F401
+from .quantize import Quantize, QuantizeForwardMode
+
+try:  # the reference mixes in PyTorchModelHubMixin (h_rqvae.py:230); keep it when the hub package is importable
+    from huggingface_hub import PyTorchModelHubMixin as _HubMixin
+except Exception:  # noqa: BLE001
+    class _HubMixin:  # type: ignore
+        pass
+
+
+class SemanticIdUniquenessLoss(nn.Module):
+    """Hinge on the cosine similarity of items that share a full semantic-id tuple (reference h_rqvae.py:25-105)."""
+
+    def __init__(self, margin: float = 0.5, weight: float = 1.0):
+        super().__init__()
+        self.margin = margin
+        self.weight = weight
+
+    def forward(self, sem_ids: Tensor, encoded_features: Tensor) -> Tensor:
+        # literal semantics for a [n, m] id matrix: rows are compared with each other (h_rqvae.py:52-64)
+        loss, _ = _C.uniq_loss(sem_ids.t().contiguous(), encoded_features.detach().contiguous(), self.weight, self.margin)
+        return loss
+
+
+class TagPredictor(nn.Module):
+    """Gated residual MLP classifier over the concatenated code embeddings (reference h_rqvae.py:108-227)."""
+
+    def __init__(self, embed_dim: int, num_classes: int, hidden_dim: Optional[int] = None, dropout_rate: float = 0.2,
+                 use_batch_norm: bool = True, layer_idx: int = 0):
+        super().__init__()
+        hidden_dim = embed_dim * 2 if hidden_dim is None else hidden_dim
+        p = min(0.55, dropout_rate + layer_idx * 0.075)
+        mid = int(hidden_dim * 0.9)
+        norm = (lambda n: nn.LayerNorm(n)) if use_batch_norm else (lambda n: nn.Identity())
+        self.attention = nn.Sequential(nn.Linear(embed_dim, embed_dim // 4), nn.ReLU(), nn.Linear(embed_dim // 4, embed_dim // 2),
+                                       nn.GELU(), nn.Linear(embed_dim // 2, embed_dim), nn.Sigmoid())
+        self.feature_extractor = nn.Sequential(nn.Linear(embed_dim, hidden_dim), norm(hidden_dim), nn.ReLU(), nn.Dropout(p))
+
+        def block():
+            return nn.Sequential(nn.Linear(hidden_dim, mid), norm(mid), nn.ReLU(), nn.Dropout(p),
+                                 nn.Linear(mid, hidden_dim), nn.ReLU(), nn.Dropout(p), norm(hidden_dim))
+
+        self.residual_block1 = block()
+        self.residual_block2 = block()
+        self.classifier = nn.Sequential(nn.Linear(hidden_dim, mid), norm(mid), nn.ReLU(), nn.Dropout(p),
+                                        nn.Linear(mid, mid // 2), nn.ReLU(), nn.Dropout(p * 0.5), nn.Linear(mid // 2, num_classes))
+        self.label_smoothing = 0.1 if layer_idx > 0 else 0.05
+        self.apply_norm = layer_idx > 0
+        self.use_norm = use_batch_norm
+        self.dropout_p = p
+        self.rand = None
+
+    def forward(self, x: Tensor) -> Tensor:
+        from ..tagpath import tag_predictor_forward
+        return tag_predictor_forward(self, x)
+
+
+class HRqVae(nn.Module, _HubMixin):
+    def __init__(self, input_dim: int, embed_dim: int, hidden_dims: List[int], codebook_size: int,
+                 codebook_kmeans_init: bool = True, codebook_normalize: bool = False, codebook_sim_vq: bool = False,
+                 codebook_mode: QuantizeForwardMode = QuantizeForwardMode.GUMBEL_SOFTMAX, n_layers: int = 3,
+                 commitment_weight: float = 0.25, n_cat_features: int = 18, tag_alignment_weight: float = 0.5,
+                 tag_prediction_weight: float = 0.5, tag_class_counts: Optional[List[int]] = None, tag_embed_dim: int = 768,
+                 use_focal_loss: bool = False, focal_loss_params: Optional[Dict] = None, dropout_rate: float = 0.2,
+                 use_batch_norm: bool = True, alignment_temperature: float = 0.1, sem_id_uniqueness_weight: float = 0.5,
+                 sem_id_uniqueness_margin: float = 0.5) -> None:
+        # the reference stores locals() here, `self` included; the module itself is left out on purpose
+        self._config = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
+        super().__init__()
+        if n_cat_features != 0:
+            raise NotImplementedError("n_cat_features != 0 (categorical BCE tail) is unreachable in the reference as shipped "
+                                      "(SURVEY Q1) and unused by both configs; not built on the HIP path")
+        if embed_dim != _C.EMBED_DIM:
+            raise NotImplementedError(f"the fused RQ kernels are specialised for embed_dim={_C.EMBED_DIM} (got {embed_dim})")
+        if not 1 <= n_layers <= _C.MAX_LEVELS:
+            raise ValueError(f"n_layers must be in [1, {_C.MAX_LEVELS}]")
+        self.input_dim, self.embed_dim, self.hidden_dims = input_dim, embed_dim, hidden_dims
+        self.n_layers, self.codebook_size = n_layers, codebook_size
+        self.commitment_weight, self.n_cat_feats = commitment_weight, n_cat_features
+        self.tag_alignment_weight, self.tag_prediction_weight = tag_alignment_weight, tag_prediction_weight
+        self.tag_embed_dim, self.use_focal_loss = tag_embed_dim, use_focal_loss
+        self.focal_loss_params = focal_loss_params or {"gamma": 2.0}
+        self.dropout_rate, self.use_batch_norm = dropout_rate, use_batch_norm
+        self.alignment_temperature = alignment_temperature
+        self.sem_id_uniqueness_weight = sem_id_uniqueness_weight
+        self.codebook_normalize, self.codebook_mode = codebook_normalize, codebook_mode
+        self.tag_class_counts = ([10, 100, 1000] if tag_class_counts is None else list(tag_class_counts))[:n_layers]
+        assert len(self.tag_class_counts) == n_layers, \
+            f"Number of tag classes {len(self.tag_class_counts)} does not match number of layers {n_layers}"
+
+        self.layers = nn.ModuleList([
+            Quantize(embed_dim=embed_dim, n_embed=codebook_size, forward_mode=codebook_mode, do_kmeans_init=codebook_kmeans_init,
+                     codebook_normalize=(i == 0 and codebook_normalize), sim_vq=codebook_sim_vq,
+                     commitment_weight=commitment_weight) for i in range(n_layers)])
+        self.concat_embed_dims = [embed_dim * (i + 1) for i in range(n_layers)]
+        self._stored_tag_class_counts = None
+        self.tag_predictors = nn.ModuleList([
+            TagPredictor(embed_dim=self.concat_embed_dims[i], num_classes=self.tag_class_counts[i],
+                         hidden_dim=hidden_dims[0] // 2 * (i + 1), dropout_rate=dropout_rate, use_batch_norm=use_batch_norm,
+                         layer_idx=i) for i in range(n_layers)])
+        self.tag_projectors = nn.ModuleList([self._make_projector(i, codebook_normalize) for i in range(n_layers)])
+        self.encoder = MLP(input_dim=input_dim, hidden_dims=hidden_dims, out_dim=embed_dim, normalize=codebook_normalize)
+        self.decoder = MLP(input_dim=embed_dim, hidden_dims=hidden_dims[-1::-1], out_dim=input_dim, normalize=True)
+        self.reconstruction_loss = ReconstructionLoss()
+        self.tag_alignment_loss = TagAlignmentLoss(alignment_weight=tag_alignment_weight, temperature=alignment_temperature)
+        self.tag_prediction_loss = TagPredictionLoss(use_focal_loss=use_focal_loss, focal_params=focal_loss_params, class_counts=None)
+        self.sem_id_uniqueness_loss = SemanticIdUniquenessLoss(margin=sem_id_uniqueness_margin, weight=sem_id_uniqueness_weight)
+        self.register_buffer("class_freq_counts", None)
+        self.rand = None  # injectable randomness provider for dropout / mixup / gumbel (hidvae_amd.rand)
+
+    def _make_projector(self, i, with_layer_norm):
+        h0 = self._config["hidden_dims"][0]
+        return nn.Sequential(nn.Linear(self.tag_embed_dim, h0),
+                             nn.BatchNorm1d(h0) if self._config["use_batch_norm"] else nn.Identity(), nn.ReLU(),
+                             nn.Dropout(self._config["dropout_rate"]), nn.Linear(h0, self.concat_embed_dims[i]),
+                             nn.LayerNorm(self.concat_embed_dims[i]) if with_layer_norm else nn.Identity())
+
+    # ------------------------------------------------------------------------------------------ plumbing
+    @property
+    def config(self) -> dict:
+        return self._config
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.encoder.parameters()).device
+
+    def _rand(self):
+        from ..rand import DeviceRand
+        return self.rand if self.rand is not None else DeviceRand(self.tag_prediction_loss.mixup_alpha)
+
+    def load_pretrained(self, path: str) -> None:
+        """Checkpoint loader tolerant of tag-head shape drift (reference h_rqvae.py:382-471)."""
+        state = torch.load(path, map_location=self.device, weights_only=False)
+        theirs, mine = state["model"], self.state_dict()
+        classes = []
+        for i in range(self.n_layers):
+            key = f"tag_predictors.{i}.classifier.7.weight"
+            classes.append(theirs[key].shape[0] if key in theirs else self.tag_class_counts[i])
+        if classes != list(self.tag_class_counts):
+            print(f"Tag predictor mismatch detected. Adjusting number of classes from {self.tag_class_counts} to {classes}")
+            self._stored_tag_class_counts, self.tag_class_counts = self.tag_class_counts, classes
+            self.tag_predictors = nn.ModuleList([
+                TagPredictor(embed_dim=self.concat_embed_dims[i], num_classes=classes[i],
+                             hidden_dim=self._config.get("hidden_dims", [512, 256, 128])[0] // 2 * (i + 1),
+                             dropout_rate=self._config.get("dropout_rate", 0.2),
+                             use_batch_norm=self._config.get("use_batch_norm", True), layer_idx=i)
+                for i in range(self.n_layers)]).to(self.device)
+        if any(f"tag_projectors.{i}.5.weight" in theirs and f"tag_projectors.{i}.5.weight" not in mine for i in range(self.n_layers)):
+            print("Tag projector mismatch detected. Adjusting structure to match the weight file.")
+            self.tag_projectors = nn.ModuleList([self._make_projector(i, True) for i in range(self.n_layers)]).to(self.device)
+        mine = self.state_dict()
+        usable = {k: v for k, v in theirs.items() if k in mine}
+        if len(usable) < len(theirs):
+            print(f"Warning: skipped keys absent from this model: {sorted(set(theirs) - set(usable))}")
+        try:
+            mine.update(usable)
+            self.load_state_dict(mine)
+        except Exception as e:  # noqa: BLE001  same last resort as the reference
+            print(f"Standard loading failed, trying strict=False: {e}")
+            self.load_state_dict(theirs, strict=False)
+        for layer in self.layers:
+            layer.kmeans_initted = True
+        print(f"---Loaded HRQVAE Iter {state['iter']}---")
+
+    def update_class_counts(self, class_counts_dict):
+        # inert for the loss, exactly as in the reference (h_rqvae.py:740-756)
+        for layer_idx, counts in class_counts_dict.items():
+            if not isinstance(counts, torch.Tensor):
+                counts = torch.tensor(counts, device=self.device)
+            self.register_buffer(f"class_freq_counts_{layer_idx}", counts)
+        self.class_freq_layers = list(class_counts_dict.keys())
+
+    # ------------------------------------------------------------------------------------------ pieces
+    def encode(self, x: Tensor) -> Tensor:
+        return self.encoder(x.float())
+
+    def decode(self, x: Tensor) -> Tensor:
+        return self.decoder(x)
+
+    def _tables(self):
+        return [layer.table() for layer in self.layers]
+
+    def _normalize_flags(self):
+        return tuple(layer.codebook_normalize for layer in self.layers)
+
+    def _maybe_kmeans(self, y, normalize_input):
+        """First-batch k-means of every level on that level's input residual (reference quantize.py:103-104 fires
+        inside the level loop; levels are initialised in order, each on the residual the previous ones leave)."""
+        pending = [i for i, layer in enumerate(self.layers) if layer.do_kmeans_init and not layer.kmeans_initted]
+        if not pending:
+            return
+        with torch.no_grad():
+            for i in pending:
+                tabs = [t.detach() for t in self._tables()[: i + 1]]
+                out = RQFn.apply(y.detach(), normalize_input, self._fused_mode(), self.training, self.commitment_weight,
+                                 self._normalize_flags()[: i + 1], True, *tabs)
+                res = out[5][:, i * self.embed_dim:(i + 1) * self.embed_dim].contiguous()
+                self.layers[i]._kmeans_init(res)
+
+    def _fused_mode(self):
+        m = self.codebook_mode.value
+        return _C.MODE_STE if m == QuantizeForwardMode.GUMBEL_SOFTMAX.value else m
+
+    def _quantize_all(self, y, normalize_input, want_res):
+        """-> z, ids [B,L], emb_cat [B,L*D], emb_sum [B,D], qloss [B], res_cat"""
+        self._maybe_kmeans(y, normalize_input)
+        if self.training and self.codebook_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
+            from ..gumbel_path import gumbel_all_levels
+            return gumbel_all_levels(self, y, normalize_input)
+        return RQFn.apply(y.contiguous(), normalize_input, self._fused_mode(), self.training, self.commitment_weight,
+                          self._normalize_flags(), want_res, *self._tables())
+
+    def _tag_heads(self, emb_cat, tags_emb, tags_indices):
+        from ..tagpath import tag_heads_forward
+        return tag_heads_forward(self, emb_cat, tags_emb, tags_indices)
+
+    def get_semantic_ids(self, encoded_x: Tensor, tags_emb: Optional[Tensor] = None, tags_indices: Optional[Tensor] = None,
+                         gumbel_t: float = 0.001) -> HRqVaeOutput:
+        self._gumbel_t = gumbel_t
+        z, ids, emb_cat, emb_sum, qloss, res_cat = self._quantize_all(encoded_x.float().contiguous(), False, True)
+        B, L, D = z.shape[0], self.n_layers, self.embed_dim
+        zero = torch.zeros((), device=z.device)
+        align = pred = acc = zero
+        by_layer = (None, None, None) if tags_emb is not None and tags_indices is not None else ([], [], [])
+        if tags_emb is not None and tags_indices is not None:
+            align, pred, acc, by_layer = self._tag_heads(emb_cat, tags_emb, tags_indices)
+        return HRqVaeOutput(embeddings=emb_cat.view(B, L, D).transpose(1, 2), residuals=res_cat.view(B, L, D).transpose(1, 2),
+                            sem_ids=ids, quantize_loss=qloss, tag_align_loss=align, tag_pred_loss=pred, tag_pred_accuracy=acc,
+                            tag_align_loss_by_layer=by_layer[0], tag_pred_loss_by_layer=by_layer[1],
+                            tag_pred_accuracy_by_layer=by_layer[2])
+
+    # ------------------------------------------------------------------------------------------ the step
+    def forward(self, batch, gumbel_t: float = 1.0) -> HRqVaeComputedLosses:
+        x = batch.x.float().contiguous()
+        tags_emb = getattr(batch, "tags_emb", None)
+        tags_indices = getattr(batch, "tags_indices", None)
+        tagged = tags_emb is not None and tags_indices is not None
+        self._gumbel_t = gumbel_t
+
+        y = self.encoder.body(x)  # the encoder's l2norm (codebook_normalize) happens in the RQ prologue
+        z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)
+
+        align = pred = None
+        acc = torch.zeros((), device=x.device)
+        by_layer = ([], [], [])
+        if tagged:
+            align, pred, acc, by_layer = self._tag_heads(emb_cat, tags_emb.float(), tags_indices)
+
+        recon = ReconstructionLoss.fused(self.decoder.body(emb_sum), x)  # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0)
+        # the alignment / uniqueness weights enter once inside their loss modules and once more here
+        loss, uniq = TotalLossFn.apply(recon, qloss, align, pred, z, ids, self.sem_id_uniqueness_loss.weight,
+                                       self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight, self.tag_prediction_weight,
+                                       self.sem_id_uniqueness_weight)
+        with torch.no_grad():
+            embs_norm, p_unique = _C.id_stats(emb_cat, ids)
+        zero = torch.zeros((), device=x.device)
+        return HRqVaeComputedLosses(
+            loss=loss, reconstruction_loss=recon, rqvae_loss=qloss, tag_align_loss=align if tagged else zero,
+            tag_pred_loss=pred if tagged else zero, tag_pred_accuracy=acc, embs_norm=embs_norm, p_unique_ids=p_unique,
+            tag_align_loss_by_layer=by_layer[0], tag_pred_loss_by_layer=by_layer[1], tag_pred_accuracy_by_layer=by_layer[2],
+            sem_id_uniqueness_loss=uniq)
+
+    @torch.no_grad()
+    def predict_tags(self, x: Tensor, gumbel_t: float = 0.001) -> Dict[str, Tensor]:
+        """argmax tag + confidence per level (reference h_rqvae.py:674-738)."""
+        shape = x.shape
+        flat = x.reshape(-1, shape[-1]) if x.dim() == 3 else x
+        was_training = self.training
+        z = self.encode(flat)
+        out = self.get_semantic_ids(z, None, None, gumbel_t)
+        emb_cat = out.embeddings.transpose(1, 2).reshape(z.shape[0], -1)
+        preds, confs = [], []
+        for i in range(self.n_layers):
+            logits = self.tag_predictors[i](emb_cat[:, : (i + 1) * self.embed_dim])
+            conf, pred = torch.softmax(logits, dim=-1).max(dim=-1)
+            preds.append(pred)
+            confs.append(conf)
+        self.train(was_training)
+        if x.dim() == 3:
+            preds = [p.reshape(shape[0], shape[1]) for p in preds]
+            confs = [c.reshape(shape[0], shape[1]) for c in confs]
+        return {"predictions": torch.stack(preds, dim=-1), "confidences": torch.stack(confs, dim=-1)}

@@ -1,0 +1,189 @@
+"""Autograd operators of the tokenizer step: each forward/backward is one or a few C-ABI launches (_C.py).
+
+No torch arithmetic runs on the hot path: torch supplies device memory, streams and the autograd tape only."""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _C
+
+
+def _weight_grad_split(m_out, n_in, k_batch):
+    """split-K factor for dW = dY^T X (K = batch): enough slabs to give every CU a workgroup."""
+    tiles = math.ceil(m_out / 64) * math.ceil(n_in / 64)
+    return max(1, min(16, k_batch // 64, math.ceil(256 / tiles)))
+
+
+def mlp_body_forward(x, weights, keep_for_backward):
+    """x W0^T -> SiLU -> ... -> W_last^T  (modules/encoder.py:23-31 of the reference, no biases).
+    Returns y and, for the backward, the per-layer (input, pre-activation) tensors."""
+    saved = []
+    h = x
+    last = len(weights) - 1
+    for j, w in enumerate(weights):
+        if j == last:
+            out = _C.gemm(_C.GEMM_NT, h, w)
+            saved.append((h, None))
+        else:
+            pre = torch.empty((h.shape[0], w.shape[0]), device=h.device, dtype=torch.float32) if keep_for_backward else None
+            out = _C.gemm(_C.GEMM_NT, h, w, epilogue=_C.EPI_SILU, aux=pre)
+            saved.append((h, pre))
+        h = out
+    return h, saved
+
+
+def mlp_body_backward(saved, weights, g_y, need_input_grad):
+    grads = [None] * len(weights)
+    g = g_y
+    for j in range(len(weights) - 1, -1, -1):
+        inp, _ = saved[j]
+        w = weights[j]
+        grads[j] = _C.gemm(_C.GEMM_TN, g, inp, split_k=_weight_grad_split(w.shape[0], w.shape[1], g.shape[0]))
+        if j > 0:
+            g = _C.gemm(_C.GEMM_NN, g, w, epilogue=_C.EPI_DSILU, aux=saved[j - 1][1])
+        elif need_input_grad:
+            g = _C.gemm(_C.GEMM_NN, g, w)
+        else:
+            g = None
+    return g, grads
+
+
+class MLPBodyFn(Function):
+    @staticmethod
+    def forward(ctx, x, *weights):
+        y, saved = mlp_body_forward(x, weights, any(ctx.needs_input_grad))
+        ctx.saved = saved
+        ctx.weights = weights
+        ctx.need_x = ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        gx, gws = mlp_body_backward(ctx.saved, ctx.weights, g_y.contiguous(), ctx.need_x)
+        ctx.saved = None
+        return (gx,) + tuple(gws)
+
+
+class L2NormFn(Function):
+    """F.normalize(x, dim=-1, eps) (modules/normalize.py:7-8)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        out, norms = _C.l2norm_fwd(x, eps)
+        ctx.save_for_backward(out, norms)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, norms = ctx.saved_tensors
+        return _C.l2norm_bwd(g.contiguous(), out, norms, ctx.eps), None
+
+
+class RQFn(Function):
+    """All L quantisation levels in one kernel (h_rqvae.py:515-552 + quantize.py:100-153 of the reference).
+
+    inputs : y [B,32] (pre-normalisation iff normalize_input), the L raw codebook tables
+    outputs: z, ids (int64, non-differentiable), emb_cat [B,L*32], emb_sum [B,32], qloss [B], res_cat"""
+
+    @staticmethod
+    def forward(ctx, y, normalize_input, mode, training, beta, normalize_flags, want_res, *tables):
+        cb, cc = _C.codebook_prepare([t.detach() for t in tables], normalize_flags)
+        z, ids, emb_cat, emb_sum, res, qloss = _C.rq_forward(y, cb, cc, normalize_input, mode, training, beta, want_res=want_res)
+        ctx.cfg = (normalize_input, mode, training, beta, tuple(normalize_flags))
+        ctx.tables = tables
+        ctx.stash = (y, z, ids, cb, cc)
+        ctx.mark_non_differentiable(ids)
+        if res is None:
+            res = torch.empty(0, device=y.device)
+        ctx.mark_non_differentiable(res)
+        return z, ids, emb_cat, emb_sum, qloss, res
+
+    @staticmethod
+    def backward(ctx, g_z, _g_ids, g_cat, g_sum, g_q, _g_res):
+        normalize_input, mode, training, beta, flags = ctx.cfg
+        if not training:
+            raise RuntimeError("the eval branch of Quantize (o = codebook[ids]) is not differentiated on the fused path")
+        y, z, ids, cb, cc = ctx.stash
+        if g_cat is not None:
+            g_cat = g_cat.contiguous()
+        if g_sum is not None:
+            g_sum = g_sum.contiguous()
+        if g_z is not None:
+            g_z = g_z.contiguous()
+        if g_q is None:
+            g_q = torch.zeros((), device=z.device)
+        g_y, dE = _C.rq_backward(y, z, cb, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z, 1.0, g_q)
+        gE = _C.codebook_grad(ids, dE, [t.detach() for t in ctx.tables], cb, flags)
+        ctx.stash = None
+        return (g_y, None, None, None, None, None, None) + tuple(gE)
+
+
+class ReconFn(Function):
+    """decoder tail: recon[b] = sum_j (normalize(y)[b,j] - x[b,j])^2  (encoder.py:32 + loss.py:11-12)."""
+
+    @staticmethod
+    def forward(ctx, y, x):
+        recon, _, _ = _C.recon_fwd_bwd(y, x)
+        ctx.save_for_backward(y, x)
+        return recon
+
+    @staticmethod
+    def backward(ctx, g):
+        y, x = ctx.saved_tensors
+        _, _, g_y = _C.recon_fwd_bwd(y, x, gscale=1.0, gscale_items=g, want_grad=True)
+        return g_y, None
+
+
+class TotalLossFn(Function):
+    """loss = mean(recon) + mean(qloss) + w_a*align + w_p*pred + w_u*uniq  (h_rqvae.py:634-640), with the uniqueness
+    term evaluated in the same launch exactly as the reference calls it ([L,B] ids).
+    Returns (loss, uniq); only `loss` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, recon, qloss, align, pred, z, ids, uniq_weight, uniq_margin, w_a, w_p, w_u):
+        want = z is not None and ctx.needs_input_grad[4]
+        loss, uniq, g_rows = _C.total_loss(recon, qloss, align, pred, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want)
+        ctx.meta = (recon.shape[0], ids.shape[1] if ids is not None else 0, w_a, w_p, w_u, align is not None, pred is not None,
+                    z is not None)
+        ctx.g_rows = g_rows
+        ctx.mark_non_differentiable(uniq)
+        return loss, uniq
+
+    @staticmethod
+    def backward(ctx, g, _g_uniq):
+        B, L, w_a, w_p, w_u, has_a, has_p, has_z = ctx.meta
+        scal, g_z = _C.total_loss_bwd(g.contiguous(), B, L, w_a, w_p, w_u, ctx.g_rows, want_gz=has_z and ctx.g_rows is not None)
+        per_item = scal[0].expand(B)  # stride-0 view: the kernels downstream read one device scalar
+        return (per_item, per_item, scal[1] if has_a else None, scal[2] if has_p else None, g_z, None, None, None, None, None, None)
+
+
+class LinearFn(Function):
+    """y = act(x W^T + b) [* keep_mask * keep_scale]  -- nn.Linear with the activation (and dropout) fused into the GEMM
+    epilogue.  act is an _C.EPI_* forward code.  Backward: g_pre = g * act'(.) through the elementwise kernel, then the
+    input gradient (NN GEMM), weight gradient (TN GEMM, split-K) and bias gradient (column sums)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, keep_mask=None, keep_scale=1.0):
+        need = any(ctx.needs_input_grad)
+        pre = None
+        if need and act in (_C.EPI_SILU, _C.EPI_GELU):
+            pre = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32)
+        y = _C.gemm(_C.GEMM_NT, x, w, bias=b, epilogue=act, aux=pre, mask=keep_mask, mask_scale=keep_scale)
+        ctx.act, ctx.keep_scale = act, keep_scale
+        ctx.has_bias = b is not None
+        ctx.need_x = ctx.needs_input_grad[0]
+        ctx.save_for_backward(x, w, pre if pre is not None else y, keep_mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, ref, keep_mask = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.act != _C.EPI_NONE or keep_mask is not None:
+            g = _C.act_bwd(g, ref, ctx.act, keep_mask, ctx.keep_scale)
+        gw = _C.gemm(_C.GEMM_TN, g, x, split_k=_weight_grad_split(w.shape[0], w.shape[1], g.shape[0]))
+        gb = _C.colsum(g) if ctx.has_bias else None
+        gx = _C.gemm(_C.GEMM_NN, g, w) if ctx.need_x else None
+        return gx, gw, gb, None, None, None

@@ -1,0 +1,107 @@
+"""AdamW + CosineAnnealingLR fused into one multi-tensor HIP launch (replaces torch.optim.AdamW + the scheduler of
+reference train_hidvae.py:533-563, 636-640, 762-766).  The step counter and the schedule live on the device, so a
+whole training step (forward, backward, all-reduce, update) can be captured in a HIP graph and replayed."""
+import ctypes
+import math
+
+import torch
+
+from . import _C
+
+
+class HidvaeAdamW(torch.optim.Optimizer):
+    """Same param-group interface as torch.optim.AdamW (lr, weight_decay, betas, eps per group).
+    cosine=(T_max, eta_min) enables CosineAnnealingLR stepped once per optimizer step (the reference calls
+    scheduler.step() right after optimizer.step()).
+
+    flat_grads=True gives every parameter a view of ONE flat gradient buffer as its .grad (autograd then accumulates
+    in place), which is what the data-parallel path all-reduces in a single RCCL collective."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, cosine=None, start_step=0,
+                 flat_grads=False):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        b = {tuple(g["betas"]) for g in self.param_groups}
+        e = {g["eps"] for g in self.param_groups}
+        if len(b) != 1 or len(e) != 1:
+            raise ValueError("one (betas, eps) pair for all groups (the reference uses torch defaults everywhere)")
+        self.betas, self.eps = b.pop(), e.pop()
+        self.T_max, self.eta_min = (cosine if cosine is not None else (0, 0.0))
+        self._desc = None
+        self._start_step = start_step
+        self.flat_grads = flat_grads
+        self.grad_scale = 1.0
+
+    def _build(self):
+        ps, lrs, wds = [], [], []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if not p.requires_grad:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("HidvaeAdamW needs contiguous float32 device parameters")
+                ps.append(p)
+                lrs.append(g["lr"])
+                wds.append(g["weight_decay"])
+        dev = ps[0].device
+        self._params = ps
+        total = sum(p.numel() for p in ps)
+        self._m = torch.zeros(total, device=dev)
+        self._v = torch.zeros(total, device=dev)
+        self.flat_grad = torch.zeros(total, device=dev) if self.flat_grads else None
+        off, mptr, vptr, self.grad_views = 0, [], [], []
+        for p in ps:
+            n = p.numel()
+            mptr.append(self._m[off:off + n].data_ptr())
+            vptr.append(self._v[off:off + n].data_ptr())
+            if self.flat_grads:
+                self.grad_views.append(self.flat_grad[off:off + n].view_as(p))
+            off += n
+        i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)
+        self._desc = dict(p=i64([p.data_ptr() for p in ps]), g_host=None, m=i64(mptr),
+                          v=i64(vptr), numel=i64([p.numel() for p in ps]), lr=torch.tensor(lrs, dtype=torch.float32, device=dev),
+                          wd=torch.tensor(wds, dtype=torch.float32, device=dev), n=len(ps), max_numel=max(p.numel() for p in ps))
+        self._zero = torch.zeros(max(p.numel() for p in ps), device=dev)  # stands in for parameters without a gradient
+        self.step_dev = torch.full((), self._start_step, dtype=torch.int64, device=dev)
+        if self.flat_grads:
+            self._bind_flat()
+
+    def _bind_flat(self):
+        for p, gv in zip(self._params, self.grad_views):
+            p.grad = gv
+
+    def prepare(self):
+        if self._desc is None:
+            self._build()
+        return self
+
+    def zero_grad(self, set_to_none=True):
+        self.prepare()
+        if self.flat_grads:
+            self.flat_grad.zero_()
+            self._bind_flat()
+        else:
+            for p in self._params:
+                p.grad = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.prepare()
+        ptrs = []
+        for p in self._params:
+            g = p.grad
+            if g is None:
+                ptrs.append(self._zero.data_ptr())
+            else:
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    raise RuntimeError("HidvaeAdamW: gradients must be contiguous float32")
+                ptrs.append(g.data_ptr())
+        self._desc["g_host"] = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        _C.adamw_step(self._desc, self.step_dev, True, self.betas[0], self.betas[1], self.eps, self.eta_min, self.T_max,
+                      self.grad_scale)
+
+    def current_lr(self, group=0):
+        t = int(self.step_dev.item())
+        base = self.param_groups[group]["lr"]
+        if self.T_max <= 0:
+            return base
+        return self.eta_min + (base - self.eta_min) * (1 + math.cos(math.pi * t / self.T_max)) / 2

@@ -97,15 +97,15 @@ int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
 
 /* ---- fused RQ backward (autograd of the above) --------------------------------
  *   g_cat [B, ld_gcat] grad wrt each o_i (NULL = 0); g_sum [B,32] grad wrt sum_i o_i (NULL = 0);
- *   g_z_in [B,32] extra grad wrt z (uniqueness loss; NULL = 0); gq: d(loss)/d(qloss[b]) (same for all b),
- *   or gq_items [B] per-item values (overrides gq when not NULL).
+ *   g_z_in [g_z_rows,32] extra grad wrt the first g_z_rows rows of z (uniqueness loss; NULL = 0); gq: d(loss)/d(qloss[b]) (same for all b),
+ *   times gq_items[b*gq_stride] when gq_items != NULL (gq_stride 0 broadcasts one device scalar).
  * outputs: g_y [B,32] grad wrt the encoder output; dE_rows [B, L*32]: per-item codebook-row gradient
  * contributions gq*2*(e_i - r_i), summed per code by hidvae_codebook_grad in ascending item order. */
 int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_input,
                        const float *cb_eff, const float *cc, int L, int64_t K,
                        int mode, float beta, const int64_t *ids,
-                       const float *g_cat, int64_t ld_gcat, const float *g_sum, const float *g_z_in, float gq,
-                       const float *gq_items, float *g_y, float *dE_rows, void *stream);
+                       const float *g_cat, int64_t ld_gcat, const float *g_sum, const float *g_z_in,
+                       int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows, void *stream);
 
 /* gE[i][k][:] (+)= sum_{b: ids[b,i]==k} dE_rows[b, i*32:(i+1)*32], pushed through the row-normalise
  * Jacobian for levels with normalize[i] (E_host: raw tables, needed for |E_k|).  gE_host: L device ptrs. */
@@ -114,10 +114,11 @@ int hidvae_codebook_grad(const int64_t *ids, const float *dE_rows, int64_t B, in
                          float *const *gE_host, int accumulate, void *stream);
 
 /* ---- a3/a14: decoder tail.  x_hat = y / max(|y|,1e-12) (encoder.py:32), recon[b] = sum (x_hat-x)^2
- * (loss.py:11-12) and, if g_y != NULL, g_y = d(sum_b gscale_b * recon[b]) / dy with gscale_b = gscale_items[b]
- * (or the scalar gscale when gscale_items == NULL; 1/B for .mean()). */
+ * (loss.py:11-12) and, if g_y != NULL, g_y = d(sum_b gscale_b * recon[b]) / dy with gscale_b = gscale *
+ * gscale_items[b*gs_stride] (just gscale when gscale_items == NULL; stride 0 broadcasts one device scalar). */
 int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, int64_t N, float gscale,
-                         const float *gscale_items, float *x_hat, float *recon, float *g_y, void *stream);
+                         const float *gscale_items, int64_t gs_stride, float *x_hat, float *recon, float *g_y,
+                         void *stream);
 
 /* rows L2-normalise forward / backward (modules/normalize.py:7-8; F.normalize in h_rqvae.py:212, loss.py:66).
  * out = x / max(|x|, eps); norms[m] = |x_m| saved for the backward.  The N == 32 form uses the RQ kernel's
@@ -129,6 +130,21 @@ int hidvae_l2norm32_fwd(const float *x, int64_t M, int64_t ldx, float eps, float
 int hidvae_l2norm_bwd(const float *g, int64_t ldg, const float *out, int64_t ldo, const float *norms,
                       int64_t M, int64_t N, float eps, float *gx, int64_t ldgx, int accumulate, void *stream);
 
+/* ---- a12: SemanticIdUniquenessLoss exactly as HRqVae.forward calls it (h_rqvae.py:41-105 with the [L,B]
+ * transposed ids of :630-631): level pairs (a<b) whose id vectors agree over the whole batch contribute
+ * relu(cos(z[a], z[b]) - margin); loss = weight * mean over such pairs (0 if none).  g_rows [L,32] (optional) receives
+ * d loss / d z[0:L].  a1: total loss = mean(recon)+mean(qloss)+w_a*align+w_p*pred+w_u*uniq (h_rqvae.py:634-640),
+ * the uniqueness term evaluated in the same launch when ids != NULL; align/pred are device scalars or NULL (= 0). */
+int hidvae_uniq_loss(const int64_t *ids, const float *z, int64_t B, int L, float weight, float margin, float *loss,
+                     float *g_rows, void *stream);
+int hidvae_total_loss(const float *recon, const float *qloss, int64_t B, const float *align, const float *pred,
+                      const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin,
+                      float w_a, float w_p, float w_u, float *loss, float *uniq, float *g_rows, void *stream);
+/* backward of the above for a device scalar g = d/d loss: scal[0] = g/B (per-item grad of recon and qloss),
+ * scal[1] = g*w_a, scal[2] = g*w_p; g_z [B,32] (optional) = g*w_u*g_rows on rows < L, 0 elsewhere. */
+int hidvae_total_loss_bwd(const float *g_loss, int64_t B, int L, float w_a, float w_p, float w_u, const float *g_rows,
+                          float *scal, float *g_z, void *stream);
+
 /* ---- a13: debug statistics (h_rqvae.py:643-648) ----------------------------------------------------
  * embs_norm[b,i] = |emb_cat[b, i*32:(i+1)*32]|; *p_unique = (#distinct id tuples)/B computed by a
  * sort-free hash census (== the reference's O(B^2 L) triu expression).  scratch: >= 4*B int64. */
@@ -138,11 +154,13 @@ int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, in
 /* ---- a16: AdamW (torch.optim.AdamW defaults; train_hidvae.py:533-563,762-766) with the cosine schedule
  * evaluated ON DEVICE from a device step counter, so the whole step is graph-capturable.
  * One launch updates n_tensors tensors described by device arrays (desc_* built once by the host):
- *   p/g/m/v: arrays of device pointers; numel; base_lr; weight_decay per tensor.
+ *   p/m/v: DEVICE arrays of device pointers; numel; base_lr; weight_decay per tensor (built once);
+ *   g_host: HOST array of the n_tensors gradient device pointers (autograd hands out new buffers every step; they
+ *   travel by value in the kernel arguments, so no table upload is needed).
  *   step_dev: int64 device scalar = number of optimizer steps already taken (incremented by the call
  *   when bump_step != 0).  lr_t = eta_min + (base_lr-eta_min)(1+cos(pi*t/T_max))/2 if T_max > 0 else base_lr.
  *   grad_scale multiplies g first (1/world_size after an all-reduce SUM). */
-int hidvae_adamw_step(float *const *p_dev, const float *const *g_dev, float *const *m_dev, float *const *v_dev,
+int hidvae_adamw_step(float *const *p_dev, const float *const *g_host, float *const *m_dev, float *const *v_dev,
                       const int64_t *numel_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
                       int64_t max_numel, int64_t *step_dev, int bump_step,
                       float beta1, float beta2, float eps, float eta_min, int64_t T_max, float grad_scale,

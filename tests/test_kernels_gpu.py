@@ -155,7 +155,7 @@ def test_rq_backward_vs_autograd(C, mode, B, L, K, norm):
     obj.backward()
     cb, cc = C.codebook_prepare([dev(t) for t in tables], [norm and i == 0 for i in range(L)])
     z, ids, *_ = C.rq_forward(dev(y), cb, cc, norm, mode, True, 0.4)
-    g_y, dE = C.rq_backward(dev(y), z, cb, cc, norm, mode, 0.4, ids, dev(g_cat), dev(g_sum), dev(g_z), 0.0, dev(gq))
+    g_y, dE = C.rq_backward(dev(y), z, cb, cc, norm, mode, 0.4, ids, dev(g_cat), dev(g_sum), dev(g_z), 1.0, dev(gq))
     assert H.close(g_y.cpu().numpy(), yt.grad.numpy(), 2e-5, 1e-7)
     gE = C.codebook_grad(ids, dE, [dev(t) for t in tables], cb, [norm and i == 0 for i in range(L)])
     for i in range(L):
