@@ -192,10 +192,12 @@ def main():
 
     last = {}
 
+    one = torch.ones((), device=device)  # d loss / d loss, allocated once instead of a fill kernel per step
+
     def fwd_bwd():
         opt.zero_grad()
         out = m(batch, gumbel_t=0.2)
-        out.loss.backward()
+        out.loss.backward(gradient=one)
         last["loss"] = out.loss.detach()
 
     def step_eager():

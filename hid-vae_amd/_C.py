@@ -22,7 +22,7 @@ EMBED_DIM = 32
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 _SIGNATURES = {
-    "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp],
+    "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _i, _vp, _i, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
@@ -36,7 +36,8 @@ _SIGNATURES = {
     "hidvae_l2norm32_fwd": [_vp, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _f, _vp, _i64, _i, _vp],
     "hidvae_id_stats": [_vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp],
-    "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _i, _f, _f, _f, _f, _i64, _f, _vp],
+    "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _vp, _vp],
+    "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
 }
 
 
@@ -125,11 +126,13 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     ws = None
-    if split_k > 1:
+    if split_k > 1 and ((M + 31) // 32) * ((N + 31) // 32) >= 4096:  # only the LDS-tiled (large-batch) path uses slabs
         ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32)
     ldaux = _row_stride(aux, "aux") if aux is not None else 0
+    ldmask = _row_stride(mask, "mask") if mask is not None else 0
     _check(lib().hidvae_gemm_f32(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(out), _row_stride(out, "C"),
-                                 epilogue, _p(aux), ldaux, split_k, _p(ws), int(accumulate), _stream()), "hidvae_gemm_f32")
+                                 epilogue, _p(aux), ldaux, _p(mask), ldmask, float(mask_scale), split_k, _p(ws),
+                                 int(accumulate), _stream()), "hidvae_gemm_f32")
     return out
 
 
@@ -251,11 +254,16 @@ def id_stats(emb_cat, ids, want_norms=True):
     return norms, pu
 
 
-def adamw_step(desc, step_dev, bump_step, beta1, beta2, eps, eta_min, T_max, grad_scale):
-    """desc: dict of device arrays built by optim.HidvaeAdamW (p/g/m/v pointer tables, numel, lr, wd)."""
-    _check(lib().hidvae_adamw_step(_p(desc["p"]), desc["g_host"], _p(desc["m"]), _p(desc["v"]), _p(desc["numel"]), _p(desc["lr"]),
-                                   _p(desc["wd"]), int(desc["n"]), int(desc["max_numel"]), _p(step_dev), int(bump_step), float(beta1),
-                                   float(beta2), float(eps), float(eta_min), int(T_max), float(grad_scale), _stream()), "hidvae_adamw_step")
+def adamw_prepare(desc, step_dev, beta1, beta2, eta_min, T_max):
+    _check(lib().hidvae_adamw_prepare(_p(step_dev), _p(desc["lr"]), _p(desc["wd"]), int(desc["n"]), float(beta1), float(beta2),
+                                      float(eta_min), int(T_max), _p(desc["hyper"]), _stream()), "hidvae_adamw_prepare")
+
+
+def adamw_step(desc, beta1, beta2, eps, grad_scale):
+    """desc: device tables built by optim.HidvaeAdamW (p/m/v pointer tables, numel, hyper) + the host gradient table."""
+    _check(lib().hidvae_adamw_step(_p(desc["p"]), desc["g_host"], _p(desc["m"]), _p(desc["v"]), _p(desc["numel"]), _p(desc["hyper"]),
+                                   int(desc["n"]), int(desc["max_numel"]), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                   _stream()), "hidvae_adamw_step")
 
 
 def uniq_loss(ids, z, weight, margin, want_grad=False):

@@ -135,25 +135,33 @@ struct AdamArgs {
     float *const *m;
     float *const *v;
     const int64_t *numel;
-    const float *base_lr;
-    const float *wd;
-    const int64_t *step;
-    float beta1, beta2, eps, eta_min, grad_scale;
-    int64_t T_max;
+    const float *hyper;  // [n][3] = {1 - lr*wd, lr / bias_correction1, sqrt(bias_correction2)} from adamw_prepare_kernel
+    float beta1, beta2, eps, grad_scale;
 };
+
+// per-step scalars in double precision, once per tensor (torch computes them on the host in double), and the step
+// counter itself: one tiny launch that depends on nothing, so it runs on the helper stream beside forward/backward
+__global__ void adamw_prepare_kernel(int64_t *step, const float *base_lr, const float *wd, int n, float beta1, float beta2,
+                                     float eta_min, int64_t T_max, float *hyper) {
+    const int64_t t1 = *step + 1;  // torch counts the step being taken from 1
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        double lr = (double)base_lr[t];
+        if (T_max > 0)  // CosineAnnealingLR after (t1 - 1) scheduler steps, closed form
+            lr = (double)eta_min + (lr - (double)eta_min) * (1.0 + cos(M_PI * (double)(t1 - 1) / (double)T_max)) * 0.5;
+        const double bc1 = 1.0 - pow((double)beta1, (double)t1);
+        const double bc2 = 1.0 - pow((double)beta2, (double)t1);
+        hyper[3 * t + 0] = (float)(1.0 - lr * (double)wd[t]);
+        hyper[3 * t + 1] = (float)(lr / bc1);
+        hyper[3 * t + 2] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *step = t1;
+}
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     const int t = a.first + blockIdx.y;
     const int64_t n = a.numel[t];
-    const int64_t step = *a.step + 1;  // torch counts the step being taken from 1
-    double lr = (double)a.base_lr[t];
-    if (a.T_max > 0)  // CosineAnnealingLR after (step-1) scheduler steps, closed form
-        lr = (double)a.eta_min + (lr - (double)a.eta_min) * (1.0 + cos(M_PI * (double)(step - 1) / (double)a.T_max)) * 0.5;
-    const double bc1 = 1.0 - pow((double)a.beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)a.beta2, (double)step);
-    const float decay = (float)(1.0 - lr * (double)a.wd[t]);
-    const float step_size = (float)(lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    const float decay = a.hyper[3 * t], step_size = a.hyper[3 * t + 1], bc2_sqrt = a.hyper[3 * t + 2];
     float *p = a.p[t], *m = a.m[t], *v = a.v[t];
     const float *g = a.g[blockIdx.y];
     const float w1 = 1.0f - a.beta1, w2 = 1.0f - a.beta2;
@@ -169,8 +177,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
         v[i] = vi;
     }
 }
-
-__global__ void bump_step_kernel(int64_t *step) { *step += 1; }
 
 // ---------------------------------------------------------------------------------------------------
 // id statistics
@@ -238,11 +244,19 @@ extern "C" int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, i
     return HIDVAE_OK;
 }
 
+extern "C" int hidvae_adamw_prepare(int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors, float beta1,
+                                    float beta2, float eta_min, int64_t T_max, float *hyper_dev, void *stream) {
+    HV_REQUIRE(step_dev && base_lr_dev && wd_dev && hyper_dev && n_tensors >= 1, "adamw_prepare: bad arguments");
+    hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_dev, base_lr_dev, wd_dev, n_tensors,
+                       beta1, beta2, eta_min, T_max, hyper_dev);
+    HV_LAUNCH_CHECK("adamw_prepare");
+    return HIDVAE_OK;
+}
+
 extern "C" int hidvae_adamw_step(float *const *p_dev, const float *const *g_host, float *const *m_dev, float *const *v_dev,
-                                 const int64_t *numel_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
-                                 int64_t max_numel, int64_t *step_dev, int bump_step, float beta1, float beta2, float eps,
-                                 float eta_min, int64_t T_max, float grad_scale, void *stream) {
-    HV_REQUIRE(p_dev && g_host && m_dev && v_dev && numel_dev && base_lr_dev && wd_dev && step_dev, "adamw: null pointer");
+                                 const int64_t *numel_dev, const float *hyper_dev, int n_tensors, int64_t max_numel, float beta1,
+                                 float beta2, float eps, float grad_scale, void *stream) {
+    HV_REQUIRE(p_dev && g_host && m_dev && v_dev && numel_dev && hyper_dev, "adamw: null pointer");
     HV_REQUIRE(n_tensors >= 1 && max_numel >= 1, "adamw: bad tensor count / size");
     int64_t gx = hv_cdiv(max_numel, 256 * 4);
     if (gx > 256) gx = 256;
@@ -250,8 +264,8 @@ extern "C" int hidvae_adamw_step(float *const *p_dev, const float *const *g_host
     for (int first = 0; first < n_tensors; first += ADAM_CHUNK) {
         const int cnt = n_tensors - first < ADAM_CHUNK ? n_tensors - first : ADAM_CHUNK;
         AdamArgs a{};
-        a.p = p_dev; a.m = m_dev; a.v = v_dev; a.numel = numel_dev; a.base_lr = base_lr_dev; a.wd = wd_dev; a.step = step_dev;
-        a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.eta_min = eta_min; a.grad_scale = grad_scale; a.T_max = T_max;
+        a.p = p_dev; a.m = m_dev; a.v = v_dev; a.numel = numel_dev; a.hyper = hyper_dev;
+        a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
         a.first = first;
         for (int i = 0; i < cnt; i++) {
             HV_REQUIRE(g_host[first + i] != nullptr, "adamw: gradient %d is null", first + i);
@@ -259,10 +273,6 @@ extern "C" int hidvae_adamw_step(float *const *p_dev, const float *const *g_host
         }
         hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, s, a);
         HV_LAUNCH_CHECK("adamw");
-    }
-    if (bump_step) {
-        hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step_dev);
-        HV_LAUNCH_CHECK("adamw bump");
     }
     return HIDVAE_OK;
 }
@@ -372,17 +382,18 @@ struct TotalArgs {
 __global__ __launch_bounds__(256) void total_loss_kernel(TotalArgs a) {
     __shared__ float red[2][4];
     __shared__ float uq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float r = 0.0f, q = 0.0f;
-    for (int64_t i = threadIdx.x; i < a.B; i += 256) { r += a.recon[i]; q += a.qloss[i]; }
+    for (int64_t i = tid; i < a.B; i += 256) { r += a.recon[i]; q += a.qloss[i]; }
     r = hv_wave_sum(r);
     q = hv_wave_sum(q);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = r; red[1][threadIdx.x >> 6] = q; }
-    if (threadIdx.x < 64) {
+    if (lane == 0) { red[0][wave] = r; red[1][wave] = q; }
+    if (wave == 3) {  // the last wave evaluates the uniqueness term meanwhile
         const float v = a.ids != nullptr ? uniq_loss_wave(a.ids, a.z, a.B, a.L, a.uniq_weight, a.uniq_margin, a.g_rows) : 0.0f;
-        if (threadIdx.x == 0) uq = v;
+        if (lane == 0) uq = v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const float rm = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)a.B;
         const float qm = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)a.B;
         float t = rm + qm;

@@ -3,8 +3,8 @@
 // input / weight gradients.
 //
 // v_mfma_f32_32x32x2_f32: per lane ONE A value (row = lane&31, k = lane>>5) and ONE B value, 16 accumulator
-// registers; the result is a k-ordered fmaf chain, so with split_k == 1 an output element is bit-identical to
-// `for k: acc = fmaf(a[k], b[k], acc)` -- the order oracle/exact.c uses (ORDER-G).
+// registers; the result is a k-ordered fmaf chain, so with split_k == 1 an output element is bit-identical to the
+// fmaf chain oracle/exact.c runs (ORDER-G: 16-wide k-blocks ascending, inside a block k = 0,8,1,9,...,7,15).
 //
 // Workgroup tile (32*WM) x (32*WN), one 32x32 accumulator per wave, BK = 16.  Both operand tiles live in LDS
 // k-major (As[k][m], Bs[k][n]) so a fragment read is 32 consecutive floats per half-wave (conflict-free
@@ -35,6 +35,9 @@ struct GemmArgs {
     int64_t k_per_split;  // multiple of BK
     float *partial;       // split-K slabs [splits][M][N] (nullptr when split_k == 1)
     int vecA, vecB;       // 16-byte loads legal for the operand
+    const float *mask;    // optional dropout keep-mask multiplied in after the activation (same shape as C)
+    int64_t ldmask;
+    float mask_scale;
 };
 
 __device__ __forceinline__ float apply_epilogue(int epi, float v, const float *aux, int64_t off) {
@@ -158,8 +161,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
         const float *ap = As[buf] + wm * 32 + i32, *bp = Bs[buf] + wn * 32 + i32;
 #pragma unroll
         for (int s = 0; s < BK / 2; s++) {
-            const float a = ap[(2 * s + h) * LDA];
-            const float b = bp[(2 * s + h) * LDB];
+            const float a = ap[(8 * h + s) * LDA];  // ORDER-G: lane half h supplies k = 8h + s at step s
+            const float b = bp[(8 * h + s) * LDB];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         if (more) {
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE)
                 g.aux[row * g.ldaux + col] = v;
             v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            if (g.mask != nullptr) v = v * (g.mask[row * g.ldmask + col] * g.mask_scale);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
         }
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int spli
     v += g.bias != nullptr ? g.bias[col] : 0.0f;
     if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
     v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+    if (g.mask != nullptr) v = v * (g.mask[row * g.ldmask + col] * g.mask_scale);
     float *dst = g.C + row * g.ldc + col;
     *dst = g.accumulate ? *dst + v : v;
 }
@@ -234,6 +239,141 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *partial,
     out[n] = accumulate ? out[n] + s : s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// "direct" kernel for the small, L2-resident GEMMs of this model (M = batch ~ 1e3, K,N <= 768): one wave per
+// 32x32 output tile, operands loaded from global memory STRAIGHT into the MFMA operand registers (no LDS, no
+// barriers), a 3-deep register ring of 16-wide k-blocks so two blocks of loads are always in flight, and an
+// optional in-workgroup split of K over SPLIT waves reduced through LDS in fixed order (backward GEMMs only).
+// k-order inside a 16-block: lane half h supplies k = 8h + s at MFMA step s, i.e. the chain visits
+// 0,8,1,9,...,7,15 -- that is ORDER-G of oracle/exact.c, so SPLIT == 1 stays bit-exact against the oracle.
+// ------------------------------------------------------------------------------------------------
+// Operands are read with raw BUFFER loads: 128-bit resource (scalar) + 32-bit lane byte offset + scalar k offset, so
+// addressing costs one VGPR per operand, rows need only dword alignment for the 16-byte form, and anything past the
+// end of the matrix reads as 0.  The pipelined loop below is completely branch-free: blocks past a wave's range are
+// "loaded" from an out-of-range offset (zeros) and multiplied in as exact no-ops, so every path issues the same loads
+// in the same order and the compiler can keep two blocks in flight behind counted vmcnt waits.
+// `voff`: lane byte offset (row*ld + 8h for k-contiguous operands, 8h*ld + row otherwise, times 4).
+constexpr int HV_OOB = 0x7FFFFFF0;
+
+template <bool KCONTIG>
+__device__ __forceinline__ void load_block(__amdgpu_buffer_rsrc_t rsrc, int ld4, int voff, int k0, float (&v)[8]) {
+    if (KCONTIG) {
+        const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, k0 * 4, 0));
+        const f32x4 y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, k0 * 4 + 16, 0));
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; v[4] = y[0]; v[5] = y[1]; v[6] = y[2]; v[7] = y[3];
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (k0 + s) * ld4, 0));
+    }
+}
+
+// ragged last block (K % 16 != 0): per-element loads, lanes whose k is past K aim out of range and read 0
+template <bool KCONTIG>
+__device__ __forceinline__ void load_tail(__amdgpu_buffer_rsrc_t rsrc, int ld4, int voff, int k0, int kend, int h, float (&v)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const bool ok = k0 + 8 * h + s < kend;
+        if (KCONTIG) v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? voff + 4 * s : HV_OOB, k0 * 4, 0));
+        else v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? voff : HV_OOB, (k0 + s) * ld4, 0));
+    }
+}
+
+template <int LAYOUT, int SPLIT, int NS>
+__global__ __launch_bounds__(64 * SPLIT) void gemm_direct_kernel(GemmArgs g) {
+    constexpr bool A_KC = (LAYOUT != HIDVAE_GEMM_TN);
+    constexpr bool B_KC = (LAYOUT == HIDVAE_GEMM_NT);
+    __shared__ float part[SPLIT > 1 ? SPLIT * 1024 : 1];
+    const int lane = threadIdx.x & 63;
+    // wave index as a SCALAR: the k offsets derived from it feed the buffer loads' soffset operand, which must be
+    // provably uniform or the compiler wraps every load in a waterfall loop
+    const int w = SPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i32 = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+    const int64_t ra = (m0 + i32 < g.M) ? m0 + i32 : g.M - 1;
+    const int64_t rb = (n0 + i32 < g.N) ? n0 + i32 : g.N - 1;
+    const int va = 4 * (A_KC ? (int)(ra * g.lda) + 8 * h : (int)(8 * h * g.lda + ra));
+    const int vb = 4 * (B_KC ? (int)(rb * g.ldb) + 8 * h : (int)(8 * h * g.ldb + rb));
+    const int lda4 = (int)g.lda * 4, ldb4 = (int)g.ldb * 4, Ki = (int)g.K;
+    // logical extent of each operand in bytes (works for column-slice views too)
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.A), 0, (int)(4 * (A_KC ? (g.M - 1) * g.lda + g.K : (g.K - 1) * g.lda + g.M)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.B), 0, (int)(4 * (B_KC ? (g.N - 1) * g.ldb + g.K : (g.K - 1) * g.ldb + g.N)), 0x00020000);
+    const int nfull = Ki / 16;  // complete 16-wide k-blocks, shared out over the SPLIT waves; the ragged rest goes last
+    const int b_lo = nfull * w / SPLIT, b_hi = nfull * (w + 1) / SPLIT;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    // NS-deep register ring of k-blocks: NS-1 blocks of loads stay in flight behind the MFMAs of the current one
+    float ra_[NS][8], rb_[NS][8];
+    auto load = [&](float (&av)[8], float (&bv)[8], int blk) {
+        const bool in = blk < b_hi;
+        load_block<A_KC>(ra_rsrc, lda4, in ? va : HV_OOB, blk * 16, av);
+        load_block<B_KC>(rb_rsrc, ldb4, in ? vb : HV_OOB, blk * 16, bv);
+    };
+#pragma unroll
+    for (int st = 0; st < NS - 1; st++) load(ra_[st], rb_[st], b_lo + st);
+    for (int blk = b_lo; blk < b_hi; blk += NS) {
+#pragma unroll
+        for (int st = 0; st < NS; st++) {
+            load(ra_[(st + NS - 1) % NS], rb_[(st + NS - 1) % NS], blk + st + NS - 1);
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[st][s8], rb_[st][s8], acc, 0, 0, 0);
+        }
+    }
+    if (w == SPLIT - 1 && nfull * 16 < Ki) {
+        load_tail<A_KC>(ra_rsrc, lda4, va, nfull * 16, Ki, h, ra_[0]);
+        load_tail<B_KC>(rb_rsrc, ldb4, vb, nfull * 16, Ki, h, rb_[0]);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[0][s8], rb_[0][s8], acc, 0, 0, 0);
+    }
+    const float *mk = g.mask;
+    if (SPLIT == 1) {
+        const int64_t col = n0 + i32;
+        if (col >= g.N) return;
+        const float bias = g.bias != nullptr ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= g.M) continue;
+            float v = acc[r] + bias;
+            if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            float *dst = g.C + row * g.ldc + col;
+            *dst = g.accumulate ? *dst + v : v;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) part[w * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i32] = acc[r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 1024; e += 64 * SPLIT) {
+            float v = part[e];
+#pragma unroll
+            for (int sidx = 1; sidx < SPLIT; sidx++) v += part[sidx * 1024 + e];  // fixed order: bit-reproducible
+            const int64_t row = m0 + (e >> 5), col = n0 + (e & 31);
+            if (row >= g.M || col >= g.N) continue;
+            v += g.bias != nullptr ? g.bias[col] : 0.0f;
+            if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            float *dst = g.C + row * g.ldc + col;
+            *dst = g.accumulate ? *dst + v : v;
+        }
+    }
+}
+
+template <int SPLIT, int NS>
+void launch_direct(int layout, const GemmArgs &g, hipStream_t s) {
+    dim3 grid((unsigned)hv_cdiv(g.N, 32), (unsigned)hv_cdiv(g.M, 32));
+    dim3 block(64 * SPLIT);
+    if (layout == HIDVAE_GEMM_NT) hipLaunchKernelGGL((gemm_direct_kernel<HIDVAE_GEMM_NT, SPLIT, NS>), grid, block, 0, s, g);
+    else if (layout == HIDVAE_GEMM_NN) hipLaunchKernelGGL((gemm_direct_kernel<HIDVAE_GEMM_NN, SPLIT, NS>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_direct_kernel<HIDVAE_GEMM_TN, SPLIT, NS>), grid, block, 0, s, g);
+}
+
 template <int WM, int WN>
 void launch_tile(int layout, const GemmArgs &g, int splits, hipStream_t s) {
     dim3 grid((unsigned)hv_cdiv(g.N, 32 * WN), (unsigned)hv_cdiv(g.M, 32 * WM), (unsigned)splits);
@@ -249,8 +389,8 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
                                const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int epilogue,
-                               float *aux, int64_t ldaux, int split_k, float *workspace, int accumulate,
-                               void *stream) {
+                               float *aux, int64_t ldaux, const float *mask, int64_t ldmask, float mask_scale,
+                               int split_k, float *workspace, int accumulate, void *stream) {
     HV_REQUIRE(layout >= 0 && layout <= 2, "gemm: layout %d", layout);
     HV_REQUIRE(M >= 1 && N >= 1 && K >= 1, "gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     HV_REQUIRE(A && B && C, "gemm: null operand");
@@ -258,28 +398,50 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
     HV_REQUIRE(lda >= a_min && ldb >= b_min && ldc >= N, "gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)",
                (long long)lda, (long long)ldb, (long long)ldc);
     HV_REQUIRE(epilogue < HIDVAE_EPI_DSILU || (aux != nullptr && ldaux >= N), "gemm: backward epilogue %d needs aux", epilogue);
-    HV_REQUIRE(split_k >= 1 && (split_k == 1 || workspace != nullptr), "gemm: split_k=%d needs a workspace", split_k);
+    HV_REQUIRE(mask == nullptr || ldmask >= N, "gemm: ldmask=%lld", (long long)ldmask);
+    HV_REQUIRE(split_k >= 0, "gemm: split_k=%d", split_k);
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.bias = bias; g.C = C; g.ldc = ldc;
     g.epilogue = epilogue; g.aux = aux; g.ldaux = aux ? ldaux : 0; g.accumulate = accumulate;
     g.vecA = (lda % 4 == 0) && aligned16(A);
     g.vecB = (ldb % 4 == 0) && aligned16(B);
-    int splits = split_k;
+    g.mask = mask; g.ldmask = ldmask; g.mask_scale = mask_scale;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tiles32 = hv_cdiv(M, 32) * hv_cdiv(N, 32);
+    const int64_t a_rows = (layout == HIDVAE_GEMM_TN) ? K : M, b_rows = (layout == HIDVAE_GEMM_NT) ? N : K;
+    const bool fits32 = a_rows * lda < (1ll << 29) && b_rows * ldb < (1ll << 29);  // the direct kernel uses 32-bit BYTE offsets
+    const bool big = (tiles32 >= 4096 && K >= 64) || !fits32;  // enough tiles that LDS sharing beats per-wave operand loads
+    if (!big || split_k == 1) {
+        if (!big) {
+            // direct path.  split_k == 1: one wave per tile, sequential (ORDER-G) chain; otherwise spread K over up to 16
+            // waves of the workgroup until the chip has ~2 waves per SIMD or the chunks get shorter than 32
+            int sp = 1;
+            if (split_k != 1) {
+                const int cap = split_k == 0 ? 16 : split_k;
+                while (sp < cap && sp < 16 && tiles32 * sp < 2048 && K / (sp * 2) >= 32) sp *= 2;
+            }
+            const bool deep = K / (16 * sp) >= 12;  // long chains per wave: keep 5 blocks of loads in flight instead of 2
+            switch (sp) {
+                case 1: if (deep) launch_direct<1, 6>(layout, g, s); else launch_direct<1, 3>(layout, g, s); break;
+                case 2: if (deep) launch_direct<2, 6>(layout, g, s); else launch_direct<2, 3>(layout, g, s); break;
+                case 4: if (deep) launch_direct<4, 6>(layout, g, s); else launch_direct<4, 3>(layout, g, s); break;
+                case 8: launch_direct<8, 3>(layout, g, s); break;
+                default: launch_direct<16, 3>(layout, g, s); break;
+            }
+            HV_LAUNCH_CHECK("gemm_f32 direct");
+            return HIDVAE_OK;
+        }
+    }
+    // LDS-tiled path (large batches); grid-level split-K through the workspace when asked for and available
+    int splits = (split_k > 1 && workspace != nullptr) ? split_k : 1;
     int64_t kps = hv_cdiv(hv_cdiv(K, splits), BK) * BK;
     splits = (int)hv_cdiv(K, kps);
     g.k_per_split = kps;
     g.partial = splits > 1 ? workspace : nullptr;
-    hipStream_t s = (hipStream_t)stream;
-    // tile choice: biggest tile that still gives the chip >= ~1 workgroup per CU
-    const int64_t t64 = hv_cdiv(M, 64) * hv_cdiv(N, 64) * splits;
-    const int64_t t32x64 = hv_cdiv(M, 32) * hv_cdiv(N, 64) * splits;
-    if (N <= 32 || M <= 32) {
-        if (N <= 32) launch_tile<2, 1>(layout, g, splits, s);
-        else launch_tile<1, 2>(layout, g, splits, s);
-    } else if (t64 >= 256) launch_tile<2, 2>(layout, g, splits, s);
-    else if (t32x64 >= 192) launch_tile<1, 2>(layout, g, splits, s);
-    else launch_tile<1, 1>(layout, g, splits, s);
-    HV_LAUNCH_CHECK("gemm_f32");
+    if (N <= 32) launch_tile<2, 1>(layout, g, splits, s);
+    else if (M <= 32) launch_tile<1, 2>(layout, g, splits, s);
+    else launch_tile<2, 2>(layout, g, splits, s);
+    HV_LAUNCH_CHECK("gemm_f32 tiled");
     if (splits > 1) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)hv_cdiv(M * N, 256)), dim3(256), 0, s, g, splits);
         HV_LAUNCH_CHECK("splitk_reduce");

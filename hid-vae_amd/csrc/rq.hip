@@ -154,9 +154,15 @@ __device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl
     }
 }
 
-template <int MODE, bool TRAIN, bool RESIDENT>
+// CSPLIT (small batches): the 4 waves of a workgroup share ONE 16-item tile and each scans a quarter of the codes;
+// the four (distance, index) candidates meet in LDS and are merged in ascending-quarter order (so equal distances still
+// resolve to the lowest index), then every wave carries on with the same residual.  4x more workgroups, 4x shorter
+// search per wave; results are bit-identical to the unsplit kernel.
+template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT>
 __global__ __launch_bounds__(WG_THREADS) void rq_forward_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float cand_d[2][4][16];
+    __shared__ int cand_i[2][4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int it = lane & 15, q = lane >> 4;
     const int LDK = a.KC + 2;
@@ -166,11 +172,14 @@ __global__ __launch_bounds__(WG_THREADS) void rq_forward_kernel(FwdArgs a) {
         for (int i = 0; i < a.L; i++) stage_codes(lds + i * lvl_floats, a, i, 0);
         __syncthreads();
     }
-    const int64_t ntiles = (a.B + ITEMS_PER_WG - 1) / ITEMS_PER_WG;
+    constexpr int TILE_ITEMS = CSPLIT ? ITEMS_PER_WAVE : ITEMS_PER_WG;
+    int phase = 0;  // running level count across tiles: candidate buffers alternate, one barrier per level suffices
+    const int64_t ntiles = (a.B + TILE_ITEMS - 1) / TILE_ITEMS;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t item = tile * ITEMS_PER_WG + wave * ITEMS_PER_WAVE + it;
-        const bool valid = item < a.B;
-        const int64_t src = valid ? item : a.B - 1;
+        const int64_t item = tile * TILE_ITEMS + (CSPLIT ? 0 : wave * ITEMS_PER_WAVE) + it;
+        const bool in_range = item < a.B;
+        const bool valid = in_range && (!CSPLIT || wave == 0);  // stores: every item once
+        const int64_t src = in_range ? item : a.B - 1;
         float r[8];
         load8(a.y + src * D + 8 * q, r);
         if (a.normalize_input) {  // F.normalize(eps=1e-12), modules/encoder.py:32
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(WG_THREADS) void rq_forward_kernel(FwdArgs a) {
                 const float *arow = Cs + (8 * q) * LDK + it;
                 const int cbase = c * a.KC + 4 * q;
                 // two 16-code tiles per iteration: two independent accumulator chains keep the MFMA pipe full
-                for (int t = 0; t < a.KC; t += 32) {
+                const int t_lo = CSPLIT ? wave * (a.KC / 4) : 0, t_hi = CSPLIT ? (wave + 1) * (a.KC / 4) : a.KC;
+                for (int t = t_lo; t < t_hi; t += 32) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
@@ -231,6 +241,20 @@ __global__ __launch_bounds__(WG_THREADS) void rq_forward_kernel(FwdArgs a) {
                 const float ob = __shfl_xor(best, o);
                 const int oi = __shfl_xor(bidx, o);
                 if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            }
+            if (CSPLIT) {  // merge the four code quarters (double-buffered by level parity: one barrier per level)
+                const int pb = phase & 1;
+                phase++;
+                if (q == 0) { cand_d[pb][wave][it] = best; cand_i[pb][wave][it] = bidx; }
+                __syncthreads();
+                best = cand_d[pb][0][it];
+                bidx = cand_i[pb][0][it];
+#pragma unroll
+                for (int ww = 1; ww < 4; ww++) {
+                    const float ob = cand_d[pb][ww][it];
+                    const int oi = cand_i[pb][ww][it];
+                    if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+                }
             }
             float e[8];
             load8(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 8 * q, e);
@@ -392,22 +416,31 @@ struct CbGradArgs {
 };
 
 __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a) {
+    // Two phases per 1024-item chunk so that no load depends on another: (A) scan the ids of the chunk (independent,
+    // coalesced loads) and append the matching item numbers, in ascending order, to a per-wave LDS list;
+    // (B) walk the list and add the rows (lanes 0..31 hold d).  Ascending item order => bit-reproducible sums.
+    __shared__ int hits[4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= (int64_t)a.L * a.K) return;
     const int lvl = (int)(row / a.K);
     const int64_t k = row - (int64_t)lvl * a.K;
     const int d = lane & 31;
+    int *list = hits[wave];
     float acc = 0.0f;
-    for (int64_t b0 = 0; b0 < a.B; b0 += 64) {
-        const int64_t b = b0 + lane;
-        const bool hit = b < a.B && a.ids[b * a.L + lvl] == k;
-        unsigned long long m = __ballot(hit);
-        while (m) {
-            const int j = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            acc += a.dE_rows[(b0 + j) * ((int64_t)a.L * D) + lvl * D + d];
+    for (int64_t c0 = 0; c0 < a.B; c0 += 1024) {
+        int n = 0;
+#pragma unroll 4
+        for (int j = 0; j < 16; j++) {
+            const int64_t b = c0 + j * 64 + lane;
+            const bool hit = b < a.B && a.ids[b * a.L + lvl] == k;
+            const unsigned long long m = __ballot(hit);
+            if (hit) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (int)(j * 64 + lane);
+            n += __popcll(m);
         }
+        __builtin_amdgcn_wave_barrier();
+        for (int e = 0; e < n; e++) acc += a.dE_rows[(c0 + list[e]) * ((int64_t)a.L * D) + lvl * D + d];
+        __builtin_amdgcn_wave_barrier();
     }
     if (a.normalize[lvl]) {  // c = E / max(|E|, eps)  =>  gE = (g - c (c.g)) / max(|E|, eps)
         const float ev = a.E[lvl][k * D + d];
@@ -449,16 +482,17 @@ __global__ __launch_bounds__(WG_THREADS) void l2norm32_kernel(const float *x, in
 size_t level_lds_bytes(int KC) { return (size_t)(32 * (KC + 2) + KC) * sizeof(float); }
 
 template <int MODE, bool TRAIN>
-int launch_fwd(const FwdArgs &a, bool resident, int grid, size_t lds, hipStream_t s) {
-    if (resident) {
-        auto kern = rq_forward_kernel<MODE, TRAIN, true>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, a);
-    } else {
-        auto kern = rq_forward_kernel<MODE, TRAIN, false>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, a);
+int launch_fwd(const FwdArgs &a, bool resident, bool csplit, int grid, size_t lds, hipStream_t s) {
+#define HV_GO(R, C)                                                                                                        \
+    {                                                                                                                      \
+        auto kern = rq_forward_kernel<MODE, TRAIN, R, C>;                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, a);                                                 \
     }
+    if (resident && csplit) HV_GO(true, true)
+    else if (resident) HV_GO(true, false)
+    else HV_GO(false, false)
+#undef HV_GO
     HV_LAUNCH_CHECK("rq_forward");
     return HIDVAE_OK;
 }
@@ -514,12 +548,14 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     const size_t per_level = level_lds_bytes(a.KC);
     const bool resident = a.nchunks == 1 && per_level * (size_t)L <= 152 * 1024;
     const size_t lds = resident ? per_level * (size_t)L : per_level;
-    const int64_t ntiles = hv_cdiv(B, ITEMS_PER_WG);
+    // small batches: split the codes over the 4 waves of a workgroup (16 items per workgroup) to cut the serial search
+    const bool csplit = resident && a.KC % 128 == 0 && B <= 4096;
+    const int64_t ntiles = hv_cdiv(B, csplit ? ITEMS_PER_WAVE : ITEMS_PER_WG);
     const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU (LDS-limited), grid-stride over tiles
     hipStream_t s = (hipStream_t)stream;
-    if (!training) return launch_fwd<HIDVAE_MODE_STE, false>(a, resident, grid, lds, s);
-    if (mode == HIDVAE_MODE_STE) return launch_fwd<HIDVAE_MODE_STE, true>(a, resident, grid, lds, s);
-    return launch_fwd<HIDVAE_MODE_ROTATION, true>(a, resident, grid, lds, s);
+    if (!training) return launch_fwd<HIDVAE_MODE_STE, false>(a, resident, csplit, grid, lds, s);
+    if (mode == HIDVAE_MODE_STE) return launch_fwd<HIDVAE_MODE_STE, true>(a, resident, csplit, grid, lds, s);
+    return launch_fwd<HIDVAE_MODE_ROTATION, true>(a, resident, csplit, grid, lds, s);
 }
 
 extern "C" int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_input, const float *cb_eff,

@@ -142,6 +142,12 @@ class HRqVae(nn.Module, _HubMixin):
     def device(self) -> torch.device:
         return next(self.encoder.parameters()).device
 
+    def _zero_scalar(self, device):
+        z = getattr(self, "_zero_cache", None)
+        if z is None or z.device != device:
+            z = self._zero_cache = torch.zeros((), device=device)  # one fill for the model's lifetime, not per step
+        return z
+
     def _rand(self):
         from ..rand import DeviceRand
         return self.rand if self.rand is not None else DeviceRand(self.tag_prediction_loss.mixup_alpha)
@@ -211,9 +217,24 @@ class HRqVae(nn.Module, _HubMixin):
             for i in pending:
                 tabs = [t.detach() for t in self._tables()[: i + 1]]
                 out = RQFn.apply(y.detach(), normalize_input, self._fused_mode(), self.training, self.commitment_weight,
-                                 self._normalize_flags()[: i + 1], True, *tabs)
+                                 self._normalize_flags()[: i + 1], True, None, *tabs)
                 res = out[5][:, i * self.embed_dim:(i + 1) * self.embed_dim].contiguous()
                 self.layers[i]._kmeans_init(res)
+
+    def _prepare_codebooks_async(self):
+        if any(layer.do_kmeans_init and not layer.kmeans_initted for layer in self.layers):
+            return None  # tables are about to change
+        from ..ops import side_stream
+        main, side = torch.cuda.current_stream(), side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            tabs = [t.detach() for t in self._tables()] if not self.layers[0].sim_vq else None
+            if tabs is None:
+                return None
+            cb, cc = _C.codebook_prepare(tabs, self._normalize_flags())
+        cb.record_stream(main)
+        cc.record_stream(main)
+        return cb, cc
 
     def _fused_mode(self):
         m = self.codebook_mode.value
@@ -226,7 +247,7 @@ class HRqVae(nn.Module, _HubMixin):
             from ..gumbel_path import gumbel_all_levels
             return gumbel_all_levels(self, y, normalize_input)
         return RQFn.apply(y.contiguous(), normalize_input, self._fused_mode(), self.training, self.commitment_weight,
-                          self._normalize_flags(), want_res, *self._tables())
+                          self._normalize_flags(), want_res, getattr(self, "_prepared", None), *self._tables())
 
     def _tag_heads(self, emb_cat, tags_emb, tags_indices):
         from ..tagpath import tag_heads_forward
@@ -237,7 +258,7 @@ class HRqVae(nn.Module, _HubMixin):
         self._gumbel_t = gumbel_t
         z, ids, emb_cat, emb_sum, qloss, res_cat = self._quantize_all(encoded_x.float().contiguous(), False, True)
         B, L, D = z.shape[0], self.n_layers, self.embed_dim
-        zero = torch.zeros((), device=z.device)
+        zero = self._zero_scalar(z.device)
         align = pred = acc = zero
         by_layer = (None, None, None) if tags_emb is not None and tags_indices is not None else ([], [], [])
         if tags_emb is not None and tags_indices is not None:
@@ -255,23 +276,35 @@ class HRqVae(nn.Module, _HubMixin):
         tagged = tags_emb is not None and tags_indices is not None
         self._gumbel_t = gumbel_t
 
+        self._prepared = self._prepare_codebooks_async()  # effective codebooks + |c|^2 on the helper stream, beside the encoder
         y = self.encoder.body(x)  # the encoder's l2norm (codebook_normalize) happens in the RQ prologue
         z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)
+        self._prepared = None
 
         align = pred = None
-        acc = torch.zeros((), device=x.device)
+        acc = self._zero_scalar(x.device)
         by_layer = ([], [], [])
         if tagged:
             align, pred, acc, by_layer = self._tag_heads(emb_cat, tags_emb.float(), tags_indices)
 
+        # debug statistics of h_rqvae.py:643-648 (embs_norm, p_unique_ids): ready as soon as the ids are, so they run on the
+        # helper stream beside the decoder instead of after it
+        from ..ops import side_stream
+        main, side = torch.cuda.current_stream(), side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            embs_norm, p_unique = _C.id_stats(emb_cat.detach(), ids)
+        for t in (embs_norm, p_unique):
+            t.record_stream(main)
+        for t in (emb_cat, ids):
+            t.record_stream(side)
         recon = ReconstructionLoss.fused(self.decoder.body(emb_sum), x)  # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0)
         # the alignment / uniqueness weights enter once inside their loss modules and once more here
         loss, uniq = TotalLossFn.apply(recon, qloss, align, pred, z, ids, self.sem_id_uniqueness_loss.weight,
                                        self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight, self.tag_prediction_weight,
                                        self.sem_id_uniqueness_weight)
-        with torch.no_grad():
-            embs_norm, p_unique = _C.id_stats(emb_cat, ids)
-        zero = torch.zeros((), device=x.device)
+        main.wait_stream(side)  # the statistics below were computed beside the decoder
+        zero = self._zero_scalar(x.device)
         return HRqVaeComputedLosses(
             loss=loss, reconstruction_loss=recon, rqvae_loss=qloss, tag_align_loss=align if tagged else zero,
             tag_pred_loss=pred if tagged else zero, tag_pred_accuracy=acc, embs_norm=embs_norm, p_unique_ids=p_unique,

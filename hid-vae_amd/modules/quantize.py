@@ -83,5 +83,5 @@ class Quantize(nn.Module):
             from ..gumbel_path import gumbel_level
             return QuantizeOutput(*gumbel_level(self, x, temperature))
         _, ids, emb_cat, _, qloss, _ = RQFn.apply(x.contiguous(), False, mode, self.training, self.quantize_loss.commitment_weight,
-                                                  (self.codebook_normalize,), False, self.table())
+                                                  (self.codebook_normalize,), False, None, self.table())
         return QuantizeOutput(embeddings=emb_cat, ids=ids[:, 0], loss=qloss)

@@ -10,9 +10,35 @@ from . import _C
 
 
 def _weight_grad_split(m_out, n_in, k_batch):
-    """split-K factor for dW = dY^T X (K = batch): enough slabs to give every CU a workgroup."""
-    tiles = math.ceil(m_out / 64) * math.ceil(n_in / 64)
-    return max(1, min(16, k_batch // 64, math.ceil(256 / tiles)))
+    """split-K policy for the backward GEMMs: 0 = let the library spread K over the waves of a workgroup."""
+    return 0
+
+
+_SIDE = {}
+
+
+def side_stream():
+    """One helper stream per device.  Independent launches (weight gradients next to the input-gradient chain, codebook
+    preparation next to the encoder) go there so their fixed per-kernel latencies overlap; under HIP-graph capture the
+    fork/join becomes graph edges."""
+    d = torch.cuda.current_device()
+    if d not in _SIDE:
+        _SIDE[d] = torch.cuda.Stream()
+    return _SIDE[d]
+
+
+def join_side():
+    """Make the current stream wait for everything queued on the helper stream."""
+    d = torch.cuda.current_device()
+    if d in _SIDE:
+        torch.cuda.current_stream().wait_stream(_SIDE[d])
+
+
+def _join_after_backward():
+    """Ask autograd to join the helper stream when the running backward pass ends (so .grad is safe to read on the
+    current stream afterwards, whoever reads it)."""
+    from torch.autograd import Variable
+    Variable._execution_engine.queue_callback(join_side)
 
 
 def mlp_body_forward(x, weights, keep_for_backward):
@@ -34,24 +60,33 @@ def mlp_body_forward(x, weights, keep_for_backward):
 
 
 def mlp_body_backward(saved, weights, g_y, need_input_grad):
+    """Input-gradient chain on the current stream; every weight gradient dW_j = g_j^T h_{j-1} on the side stream."""
     grads = [None] * len(weights)
+    main, side = torch.cuda.current_stream(), side_stream()
+    keep = []  # g_j must outlive the side-stream GEMM that reads it
     g = g_y
     for j in range(len(weights) - 1, -1, -1):
         inp, _ = saved[j]
         w = weights[j]
-        grads[j] = _C.gemm(_C.GEMM_TN, g, inp, split_k=_weight_grad_split(w.shape[0], w.shape[1], g.shape[0]))
+        keep.append(g)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            grads[j] = _C.gemm(_C.GEMM_TN, g, inp, split_k=0)
+            grads[j].record_stream(main)
         if j > 0:
-            g = _C.gemm(_C.GEMM_NN, g, w, epilogue=_C.EPI_DSILU, aux=saved[j - 1][1])
+            g = _C.gemm(_C.GEMM_NN, g, w, epilogue=_C.EPI_DSILU, aux=saved[j - 1][1], split_k=0)
         elif need_input_grad:
-            g = _C.gemm(_C.GEMM_NN, g, w)
+            g = _C.gemm(_C.GEMM_NN, g, w, split_k=0)
         else:
             g = None
-    return g, grads
+    _join_after_backward()
+    return g, grads, keep
 
 
 class MLPBodyFn(Function):
     @staticmethod
     def forward(ctx, x, *weights):
+        ctx.set_materialize_grads(False)
         y, saved = mlp_body_forward(x, weights, any(ctx.needs_input_grad))
         ctx.saved = saved
         ctx.weights = weights
@@ -60,7 +95,11 @@ class MLPBodyFn(Function):
 
     @staticmethod
     def backward(ctx, g_y):
-        gx, gws = mlp_body_backward(ctx.saved, ctx.weights, g_y.contiguous(), ctx.need_x)
+        if g_y is None:
+            return (None,) * (1 + len(ctx.weights))
+        gx, gws, keep = mlp_body_backward(ctx.saved, ctx.weights, g_y.contiguous(), ctx.need_x)
+        for t in keep:
+            t.record_stream(side_stream())  # read by the helper stream after this frame is gone
         ctx.saved = None
         return (gx,) + tuple(gws)
 
@@ -70,6 +109,7 @@ class L2NormFn(Function):
 
     @staticmethod
     def forward(ctx, x, eps):
+        ctx.set_materialize_grads(False)
         out, norms = _C.l2norm_fwd(x, eps)
         ctx.save_for_backward(out, norms)
         ctx.eps = eps
@@ -77,6 +117,8 @@ class L2NormFn(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         out, norms = ctx.saved_tensors
         return _C.l2norm_bwd(g.contiguous(), out, norms, ctx.eps), None
 
@@ -88,8 +130,13 @@ class RQFn(Function):
     outputs: z, ids (int64, non-differentiable), emb_cat [B,L*32], emb_sum [B,32], qloss [B], res_cat"""
 
     @staticmethod
-    def forward(ctx, y, normalize_input, mode, training, beta, normalize_flags, want_res, *tables):
-        cb, cc = _C.codebook_prepare([t.detach() for t in tables], normalize_flags)
+    def forward(ctx, y, normalize_input, mode, training, beta, normalize_flags, want_res, prepared, *tables):
+        ctx.set_materialize_grads(False)
+        if prepared is not None:  # effective codebooks were computed on the helper stream beside the encoder
+            cb, cc = prepared
+            join_side()
+        else:
+            cb, cc = _C.codebook_prepare([t.detach() for t in tables], normalize_flags)
         z, ids, emb_cat, emb_sum, res, qloss = _C.rq_forward(y, cb, cc, normalize_input, mode, training, beta, want_res=want_res)
         ctx.cfg = (normalize_input, mode, training, beta, tuple(normalize_flags))
         ctx.tables = tables
@@ -112,12 +159,19 @@ class RQFn(Function):
             g_sum = g_sum.contiguous()
         if g_z is not None:
             g_z = g_z.contiguous()
-        if g_q is None:
-            g_q = torch.zeros((), device=z.device)
-        g_y, dE = _C.rq_backward(y, z, cb, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z, 1.0, g_q)
-        gE = _C.codebook_grad(ids, dE, [t.detach() for t in ctx.tables], cb, flags)
+        g_y, dE = _C.rq_backward(y, z, cb, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z,
+                                 1.0 if g_q is not None else 0.0, g_q)
+        main, side = torch.cuda.current_stream(), side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):  # the per-code gather runs beside the encoder's backward
+            gE = _C.codebook_grad(ids, dE, [t.detach() for t in ctx.tables], cb, flags)
+        for t in (dE, ids, cb):
+            t.record_stream(side)
+        for t in gE:
+            t.record_stream(main)
+        _join_after_backward()
         ctx.stash = None
-        return (g_y, None, None, None, None, None, None) + tuple(gE)
+        return (g_y, None, None, None, None, None, None, None) + tuple(gE)
 
 
 class ReconFn(Function):
@@ -125,12 +179,15 @@ class ReconFn(Function):
 
     @staticmethod
     def forward(ctx, y, x):
+        ctx.set_materialize_grads(False)
         recon, _, _ = _C.recon_fwd_bwd(y, x)
         ctx.save_for_backward(y, x)
         return recon
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         y, x = ctx.saved_tensors
         _, _, g_y = _C.recon_fwd_bwd(y, x, gscale=1.0, gscale_items=g, want_grad=True)
         return g_y, None
@@ -143,6 +200,7 @@ class TotalLossFn(Function):
 
     @staticmethod
     def forward(ctx, recon, qloss, align, pred, z, ids, uniq_weight, uniq_margin, w_a, w_p, w_u):
+        ctx.set_materialize_grads(False)
         want = z is not None and ctx.needs_input_grad[4]
         loss, uniq, g_rows = _C.total_loss(recon, qloss, align, pred, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want)
         ctx.meta = (recon.shape[0], ids.shape[1] if ids is not None else 0, w_a, w_p, w_u, align is not None, pred is not None,
@@ -153,6 +211,8 @@ class TotalLossFn(Function):
 
     @staticmethod
     def backward(ctx, g, _g_uniq):
+        if g is None:
+            return (None,) * 11
         B, L, w_a, w_p, w_u, has_a, has_p, has_z = ctx.meta
         scal, g_z = _C.total_loss_bwd(g.contiguous(), B, L, w_a, w_p, w_u, ctx.g_rows, want_gz=has_z and ctx.g_rows is not None)
         per_item = scal[0].expand(B)  # stride-0 view: the kernels downstream read one device scalar
@@ -166,6 +226,7 @@ class LinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, act, keep_mask=None, keep_scale=1.0):
+        ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad)
         pre = None
         if need and act in (_C.EPI_SILU, _C.EPI_GELU):
@@ -179,11 +240,13 @@ class LinearFn(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None, None, None, None
         x, w, ref, keep_mask = ctx.saved_tensors
         g = g.contiguous()
         if ctx.act != _C.EPI_NONE or keep_mask is not None:
             g = _C.act_bwd(g, ref, ctx.act, keep_mask, ctx.keep_scale)
         gw = _C.gemm(_C.GEMM_TN, g, x, split_k=_weight_grad_split(w.shape[0], w.shape[1], g.shape[0]))
         gb = _C.colsum(g) if ctx.has_bias else None
-        gx = _C.gemm(_C.GEMM_NN, g, w) if ctx.need_x else None
+        gx = _C.gemm(_C.GEMM_NN, g, w, split_k=0) if ctx.need_x else None
         return gx, gw, gb, None, None, None

@@ -61,7 +61,9 @@ class HidvaeAdamW(torch.optim.Optimizer):
                           v=i64(vptr), numel=i64([p.numel() for p in ps]), lr=torch.tensor(lrs, dtype=torch.float32, device=dev),
                           wd=torch.tensor(wds, dtype=torch.float32, device=dev), n=len(ps), max_numel=max(p.numel() for p in ps))
         self._zero = torch.zeros(max(p.numel() for p in ps), device=dev)  # stands in for parameters without a gradient
-        self.step_dev = torch.full((), self._start_step, dtype=torch.int64, device=dev)
+        self.step_dev = torch.tensor([self._start_step], dtype=torch.int64, device=dev)
+        self._desc["hyper"] = torch.zeros(3 * len(ps), dtype=torch.float32, device=dev)
+        self._prepared = False
         if self.flat_grads:
             self._bind_flat()
 
@@ -74,8 +76,19 @@ class HidvaeAdamW(torch.optim.Optimizer):
             self._build()
         return self
 
+    def _prepare_step_async(self):
+        """schedule / bias-correction scalars + step counter for the coming step, on the helper stream (depends on nothing)"""
+        from .ops import side_stream
+        main, side = torch.cuda.current_stream(), side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _C.adamw_prepare(self._desc, self.step_dev, self.betas[0], self.betas[1], self.eta_min, self.T_max)
+        self._prepared = True
+
     def zero_grad(self, set_to_none=True):
         self.prepare()
+        if not self._prepared:
+            self._prepare_step_async()
         if self.flat_grads:
             self.flat_grad.zero_()
             self._bind_flat()
@@ -86,6 +99,10 @@ class HidvaeAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         self.prepare()
+        from .ops import join_side
+        if not self._prepared:
+            self._prepare_step_async()
+        join_side()  # weight gradients and the step scalars may still be in flight on the helper stream
         ptrs = []
         for p in self._params:
             g = p.grad
@@ -96,11 +113,11 @@ class HidvaeAdamW(torch.optim.Optimizer):
                     raise RuntimeError("HidvaeAdamW: gradients must be contiguous float32")
                 ptrs.append(g.data_ptr())
         self._desc["g_host"] = (ctypes.c_void_p * len(ptrs))(*ptrs)
-        _C.adamw_step(self._desc, self.step_dev, True, self.betas[0], self.betas[1], self.eps, self.eta_min, self.T_max,
-                      self.grad_scale)
+        _C.adamw_step(self._desc, self.betas[0], self.betas[1], self.eps, self.grad_scale)
+        self._prepared = False
 
     def current_lr(self, group=0):
-        t = int(self.step_dev.item())
+        t = int(self.step_dev[0].item())
         base = self.param_groups[group]["lr"]
         if self.T_max <= 0:
             return base

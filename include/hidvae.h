@@ -56,13 +56,19 @@ const char *hidvae_version(void);
 const char *hidvae_last_error(void);
 
 /* ---- a2/a3/a9/a10: Linear layers (modules/encoder.py:23-36, h_rqvae.py:132-188,322-331) ------------
- * C[M,N] (ldc) = epilogue( opA(A) opB(B) + bias[N] ).  fp32 in, fp32 MFMA (exact fmaf chain, k ascending,
- * when split_k == 1).  split_k > 1 needs `workspace` of split_k*M*N floats and is reduced in fixed order
- * (bit-reproducible); accumulate != 0 adds into C instead of overwriting (gradient accumulation). */
+ * C[M,N] (ldc) = epilogue( opA(A) opB(B) + bias[N] ) [* mask * mask_scale].  fp32 in, fp32 MFMA.
+ * split_k == 1: every output element is ONE fmaf chain over k in the fixed order ORDER-G (16-wide k-blocks
+ * ascending, inside a block 0,8,1,9,...,7,15) -- reproducible bit for bit by oracle/exact.c; this is what the
+ * forward (id-determining) GEMMs use.  split_k == 0: the library may split K over the waves of a workgroup and
+ * reduce in fixed order (bit-reproducible run to run, not ORDER-G); split_k > 1 caps that split.
+ * mask (optional, [M,N] at ldmask): dropout keep-mask multiplied in after the activation (nn.Dropout fused).
+ * workspace: split_k * M * N floats, only read for batches large enough to take the LDS-tiled path (may be NULL).
+ * accumulate != 0 adds into C instead of overwriting (gradient accumulation). */
 int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K,
                     const float *A, int64_t lda, const float *B, int64_t ldb,
                     const float *bias, float *C, int64_t ldc,
                     int epilogue, float *aux, int64_t ldaux,
+                    const float *mask, int64_t ldmask, float mask_scale,
                     int split_k, float *workspace, int accumulate, void *stream);
 
 /* out[n] (+)= sum_m X[m,n]   (bias gradients; fixed-order two-pass, bit-reproducible).
@@ -153,18 +159,18 @@ int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, in
 
 /* ---- a16: AdamW (torch.optim.AdamW defaults; train_hidvae.py:533-563,762-766) with the cosine schedule
  * evaluated ON DEVICE from a device step counter, so the whole step is graph-capturable.
- * One launch updates n_tensors tensors described by device arrays (desc_* built once by the host):
- *   p/m/v: DEVICE arrays of device pointers; numel; base_lr; weight_decay per tensor (built once);
- *   g_host: HOST array of the n_tensors gradient device pointers (autograd hands out new buffers every step; they
- *   travel by value in the kernel arguments, so no table upload is needed).
- *   step_dev: int64 device scalar = number of optimizer steps already taken (incremented by the call
- *   when bump_step != 0).  lr_t = eta_min + (base_lr-eta_min)(1+cos(pi*t/T_max))/2 if T_max > 0 else base_lr.
- *   grad_scale multiplies g first (1/world_size after an all-reduce SUM). */
+ * hidvae_adamw_prepare: one tiny launch per optimizer step that depends on nothing (run it beside forward/backward):
+ *   t = *step_dev + 1; lr_t = eta_min + (base_lr-eta_min)(1+cos(pi*(t-1)/T_max))/2 if T_max > 0 else base_lr;
+ *   hyper[i] = {1 - lr_t*wd_i, lr_t/(1-beta1^t), sqrt(1-beta2^t)} (double precision, as torch does on the host);
+ *   *step_dev = t.
+ * hidvae_adamw_step: one launch per <=128 tensors.  p/m/v/numel: DEVICE tables built once; g_host: HOST array of the
+ *   n_tensors gradient device pointers (autograd hands out new buffers every step; they travel by value in the kernel
+ *   arguments).  grad_scale multiplies g first (1/world_size after an all-reduce SUM). */
+int hidvae_adamw_prepare(int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
+                         float beta1, float beta2, float eta_min, int64_t T_max, float *hyper_dev, void *stream);
 int hidvae_adamw_step(float *const *p_dev, const float *const *g_host, float *const *m_dev, float *const *v_dev,
-                      const int64_t *numel_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
-                      int64_t max_numel, int64_t *step_dev, int bump_step,
-                      float beta1, float beta2, float eps, float eta_min, int64_t T_max, float grad_scale,
-                      void *stream);
+                      const int64_t *numel_dev, const float *hyper_dev, int n_tensors, int64_t max_numel,
+                      float beta1, float beta2, float eps, float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }

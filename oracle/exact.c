@@ -13,7 +13,8 @@
  * Parity: pinned against the reference's outputs in tests/golden (tests/test_exact_oracle.py);
  * the association order inside each sum is this file's own (MKL's is unknowable) and is what the
  * HIP kernels implement:
- *   ORDER-G  GEMM: one fmaf chain per output, k ascending, from +0          (f32 MFMA semantics)
+ *   ORDER-G  GEMM: one fmaf chain per output from +0 over 16-wide k-blocks ascending; inside a block the
+ *            chain visits k = 0,8,1,9,...,7,15 (f32 MFMA 32x32x2 with lane half h holding k = 8h+s at step s)
  *   ORDER-Q  sums over D=32: four chains over the contiguous quarters d in [8q,8q+8), then
  *            (p0+p1)+(p2+p3)
  *   ORDER-P  r.c dot: one fmaf chain visiting d = 0,8,16,24, 1,9,17,25, ... 7,15,23,31
@@ -46,7 +47,8 @@ static inline float expE(float x) {
 float orc_exp(float x) { return expE(x); }
 float orc_silu(float a) { return a / (1.0f + expE(-a)); }
 
-/* ORDER-G.  y[m,n] = sum_k x[m,k] w[n,k]  (F.linear without bias, encoder.py:27) */
+/* ORDER-G.  y[m,n] = sum_k x[m,k] w[n,k]  (F.linear without bias, encoder.py:27).  Skipped k >= K slots are
+ * exact no-ops on the GPU too (the kernel feeds 0*0 there). */
 void orc_linear(const float *x, int64_t M, int64_t K, const float *w, int64_t N, float *y, int silu) {
     float *wt = (float *)malloc(sizeof(float) * (size_t)K * (size_t)N); /* [K][N] so n vectorises */
     for (int64_t n = 0; n < N; n++)
@@ -54,11 +56,15 @@ void orc_linear(const float *x, int64_t M, int64_t K, const float *w, int64_t N,
     for (int64_t m = 0; m < M; m++) {
         float *ym = y + m * N;
         for (int64_t n = 0; n < N; n++) ym[n] = 0.0f;
-        for (int64_t k = 0; k < K; k++) {
-            const float xv = x[m * K + k];
-            const float *wk = wt + k * N;
-            for (int64_t n = 0; n < N; n++) ym[n] = fmaf(xv, wk[n], ym[n]);
-        }
+        for (int64_t k0 = 0; k0 < K; k0 += 16)
+            for (int s = 0; s < 8; s++)
+                for (int h = 0; h < 2; h++) {
+                    const int64_t k = k0 + 8 * h + s;
+                    if (k >= K) continue;
+                    const float xv = x[m * K + k];
+                    const float *wk = wt + k * N;
+                    for (int64_t n = 0; n < N; n++) ym[n] = fmaf(xv, wk[n], ym[n]);
+                }
         if (silu)
             for (int64_t n = 0; n < N; n++) ym[n] = orc_silu(ym[n]);
     }

@@ -22,7 +22,7 @@ def dev(a):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (1024, 512, 768), (128, 32, 128), (100, 38, 115), (33, 230, 691),
-                                   (7, 5, 3), (256, 768, 512)])
+                                   (7, 5, 3), (256, 768, 512), (4096, 1024, 96), (8192, 512, 40)])
 def test_gemm_nt_is_the_sequential_fmaf_chain(C, M, N, K):
     x = fill.uniform((M, K), 1, -1, 1)
     w = fill.uniform((N, K), 2, -1, 1)
@@ -42,7 +42,8 @@ def test_gemm_silu_epilogue_bit_exact(C):
 
 
 @pytest.mark.parametrize("layout", ["NN", "TN"])
-@pytest.mark.parametrize("M,N,K,split", [(96, 80, 72, 1), (130, 67, 45, 1), (512, 768, 1024, 4), (32, 128, 1000, 3)])
+@pytest.mark.parametrize("M,N,K,split", [(96, 80, 72, 1), (130, 67, 45, 1), (512, 768, 1024, 0), (32, 128, 1000, 0),
+                                         (1024, 512, 768, 0), (4096, 1024, 200, 4), (8, 8, 5000, 0)])
 def test_gemm_other_layouts(C, layout, M, N, K, split):
     a = fill.uniform((M, K), 5, -1, 1)
     b = fill.uniform((K, N), 6, -1, 1)

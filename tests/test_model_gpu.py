@@ -140,7 +140,7 @@ def test_adamw_kernel_matches_torch_adamw_math():
             ref[i], M[i], V[i] = O.adamw_step(ref[i], gs[i], M[i], V[i], it + 1, O.cosine_lr(base, 1e-6, it, 50), wd)
     for p, r in zip(ps, ref):
         assert H.rel_err(p.detach().cpu().numpy(), r.numpy()) <= 2e-6
-    assert int(opt.step_dev) == 5
+    assert int(opt.step_dev[0]) == 5
 
 
 def test_train_steps_track_the_oracle():
