@@ -28,7 +28,7 @@ _SIGNATURES = {
     "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _vp],
     "hidvae_uniq_loss": [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
-    "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp],
+    "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_total_loss_bwd": [_vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp],
     "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _i64, _vp, _vp, _vp, _vp],
@@ -36,6 +36,17 @@ _SIGNATURES = {
     "hidvae_l2norm32_fwd": [_vp, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _f, _vp, _i64, _i, _vp],
     "hidvae_id_stats": [_vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp],
+    "hidvae_act_bwd": [_vp, _vp, _i64, _i, _vp, _f, _vp, _vp],
+    "hidvae_binary": [_i, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp],
+    "hidvae_sum_prefix_slices": [_vp, _vp, _i, _i64, _i64, _vp, _vp],
+    "hidvae_layernorm_fwd": [_vp, _i64, _i64, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp],
+    "hidvae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp],
+    "hidvae_batchnorm_fwd": [_vp, _i64, _i64, _i64, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp],
+    "hidvae_batchnorm_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp],
+    "hidvae_infonce_rows": [_vp, _i64, _f, _f, _vp, _vp, _vp],
+    "hidvae_infonce_dlogits": [_vp, _i64, _f, _f, _vp, _vp],
+    "hidvae_tag_loss_fwd": [_vp, _i64, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_tag_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
 }
@@ -274,17 +285,20 @@ def uniq_loss(ids, z, weight, margin, want_grad=False):
     return loss, g_rows
 
 
-def total_loss(recon, qloss, align, pred, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want_grad):
-    """-> (loss, uniq, g_rows).  ids/z None skips the uniqueness term."""
+def total_loss(recon, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want_grad):
+    """-> (loss, uniq, g_rows, tagstats).  aligns/preds/accs: lists of per-level 0-d device tensors ([] if untagged)."""
     dev = recon.device
     loss = torch.empty((), device=dev, dtype=torch.float32)
     uniq = torch.empty((), device=dev, dtype=torch.float32)
     L = ids.shape[1] if ids is not None else 0
+    n_tag = len(aligns)
     g_rows = torch.empty((L, EMBED_DIM), device=dev, dtype=torch.float32) if (want_grad and ids is not None) else None
-    _check(lib().hidvae_total_loss(_p(recon), _p(qloss), recon.shape[0], _p(align), _p(pred), _p(ids), _p(z), L, float(uniq_weight),
-                                   float(uniq_margin), float(w_a), float(w_p), float(w_u), _p(loss), _p(uniq), _p(g_rows), _stream()),
-           "hidvae_total_loss")
-    return loss, uniq, g_rows
+    tagstats = torch.empty((3 + 3 * n_tag,), device=dev, dtype=torch.float32) if n_tag else None
+    arr = lambda ts: _host_ptr_array(ts) if ts else None
+    _check(lib().hidvae_total_loss(_p(recon), _p(qloss), recon.shape[0], arr(aligns), arr(preds), arr(accs), n_tag, float(tag_div),
+                                   _p(ids), _p(z), L, float(uniq_weight), float(uniq_margin), float(w_a), float(w_p), float(w_u),
+                                   _p(loss), _p(uniq), _p(g_rows), _p(tagstats), _stream()), "hidvae_total_loss")
+    return loss, uniq, g_rows, tagstats
 
 
 def total_loss_bwd(g_loss, B, L, w_a, w_p, w_u, g_rows, want_gz):
@@ -293,3 +307,108 @@ def total_loss_bwd(g_loss, B, L, w_a, w_p, w_u, g_rows, want_gz):
     _check(lib().hidvae_total_loss_bwd(_p(g_loss), B, L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(scal), _p(g_z), _stream()),
            "hidvae_total_loss_bwd")
     return scal, g_z
+
+
+# ------------------------------------------------------------------------------------------------ tag path
+def act_bwd(g, ref, act, mask=None, mask_scale=1.0):
+    out = torch.empty_like(g)
+    _check(lib().hidvae_act_bwd(_p(g), _p(ref), g.numel(), int(act), _p(mask), float(mask_scale), _p(out), _stream()), "hidvae_act_bwd")
+    return out
+
+
+def binary(op, a, b):
+    """op 0: a*b, op 1: a+b (row-strided views welcome)."""
+    M, N = a.shape
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    _check(lib().hidvae_binary(int(op), _p(a), _row_stride(a, "a"), _p(b), _row_stride(b, "b"), M, N, _p(out), N, _stream()), "hidvae_binary")
+    return out
+
+
+def mul(a, b):
+    return binary(0, a, b)
+
+
+def sum_prefix_slices(srcs, M, N):
+    """srcs: list of contiguous [M, w_i] tensors (or None) -> dst [M, N] with each added into the first w_i columns."""
+    live = [t for t in srcs if t is not None]
+    dst = torch.empty((M, N), device=live[0].device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * len(live))(*[t.data_ptr() for t in live])
+    widths = (ctypes.c_int32 * len(live))(*[t.shape[1] for t in live])
+    _check(lib().hidvae_sum_prefix_slices(ptrs, widths, len(live), M, N, _p(dst), _stream()), "hidvae_sum_prefix_slices")
+    return dst
+
+
+def layernorm_fwd(x, gamma, beta, eps, relu, mask, mask_scale, residual):
+    M, N = x.shape
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    mean = torch.empty((M,), device=x.device, dtype=torch.float32)
+    rstd = torch.empty((M,), device=x.device, dtype=torch.float32)
+    _check(lib().hidvae_layernorm_fwd(_p(x), M, N, _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd), int(relu), _p(mask),
+                                      float(mask_scale), _p(residual), _stream()), "hidvae_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, need_gx=True):
+    M, N = x.shape
+    gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if need_gx else None
+    gg = torch.empty((N,), device=x.device, dtype=torch.float32)
+    gb = torch.empty((N,), device=x.device, dtype=torch.float32)
+    _check(lib().hidvae_layernorm_bwd(_p(gy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), M, N, int(relu), _p(mask),
+                                      float(mask_scale), _p(gx), _p(gg), _p(gb), 0, _stream()), "hidvae_layernorm_bwd")
+    return gx, gg, gb
+
+
+def batchnorm_fwd(x, gamma, beta, eps, momentum, training, running_mean, running_var, relu, mask, mask_scale, num_batches=None):
+    M, N = x.shape
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    sm = torch.empty((N,), device=x.device, dtype=torch.float32) if training else None
+    sr = torch.empty((N,), device=x.device, dtype=torch.float32) if training else None
+    _check(lib().hidvae_batchnorm_fwd(_p(x), _row_stride(x, "x"), M, N, _p(gamma), _p(beta), float(eps), float(momentum), int(training),
+                                      _p(running_mean), _p(running_var), _p(num_batches), _p(y), _p(sm), _p(sr), int(relu), _p(mask),
+                                      float(mask_scale), _stream()), "hidvae_batchnorm_fwd")
+    return y, sm, sr
+
+
+def batchnorm_bwd(gy, x, gamma, beta, save_mean, save_rstd, relu, mask, mask_scale, need_gx=True):
+    M, N = x.shape
+    gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if need_gx else None
+    gg = torch.empty((N,), device=x.device, dtype=torch.float32)
+    gb = torch.empty((N,), device=x.device, dtype=torch.float32)
+    _check(lib().hidvae_batchnorm_bwd(_p(gy), _p(x), _row_stride(x, "x"), _p(gamma), _p(beta), _p(save_mean), _p(save_rstd), M, N,
+                                      int(relu), _p(mask), float(mask_scale), _p(gx), _p(gg), _p(gb), 0, _stream()), "hidvae_batchnorm_bwd")
+    return gx, gg, gb
+
+
+def infonce_rows(S, tau, scale):
+    B = S.shape[0]
+    row_loss = torch.empty((B,), device=S.device, dtype=torch.float32)
+    loss = torch.empty((), device=S.device, dtype=torch.float32)
+    _check(lib().hidvae_infonce_rows(_p(S), B, float(tau), float(scale), _p(row_loss), _p(loss), _stream()), "hidvae_infonce_rows")
+    return loss
+
+
+def infonce_dlogits(P, tau, scale, g):
+    _check(lib().hidvae_infonce_dlogits(_p(P), P.shape[0], float(tau), float(scale), _p(g), _stream()), "hidvae_infonce_dlogits")
+    return P
+
+
+def tag_loss_fwd(logits, target, partner, lam, focal, gamma, alpha, smooth, ce_ls, want_grad):
+    B, C = logits.shape
+    dev = logits.device
+    f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    loss, acc, nv = f(), f(), f()
+    row_loss, row_hit, zbuf = f(B), f(B), f(B, C)
+    dmix = f(B, C) if want_grad else None
+    dkl = f(B, C) if (want_grad and not focal) else None
+    _check(lib().hidvae_tag_loss_fwd(_p(logits), B, C, _p(target), _p(partner), _p(lam), int(bool(focal)), float(gamma), float(alpha),
+                                     float(smooth), float(ce_ls), _p(loss), _p(acc), _p(nv), _p(row_loss), _p(row_hit), _p(zbuf),
+                                     _p(dmix), _p(dkl), _stream()), "hidvae_tag_loss_fwd")
+    return loss, acc, nv, dmix, dkl
+
+
+def tag_loss_bwd(dmix, dkl, target, inverse, lam, g, n_valid):
+    B, C = dmix.shape
+    out = torch.empty((B, C), device=dmix.device, dtype=torch.float32)
+    _check(lib().hidvae_tag_loss_bwd(_p(dmix), _p(dkl), _p(target), _p(inverse), _p(lam), B, C, _p(g), _p(n_valid), _p(out), _stream()),
+           "hidvae_tag_loss_bwd")
+    return out

@@ -370,7 +370,10 @@ __global__ __launch_bounds__(64) void uniq_loss_kernel(const int64_t *ids, const
 struct TotalArgs {
     const float *recon, *qloss;
     int64_t B;
-    const float *align, *pred;
+    const float *align[HIDVAE_MAX_LEVELS], *pred[HIDVAE_MAX_LEVELS], *acc[HIDVAE_MAX_LEVELS];  // per-level device scalars
+    int n_tag;        // levels that carry tag losses (0 = untagged batch)
+    float tag_div;    // the reference divides the level sums by n_layers (h_rqvae.py:561-563)
+    float *tagstats;  // [3 + 3*n_tag]: align, pred, acc means, then the three by-layer vectors
     const int64_t *ids;  // uniqueness term (nullptr = skip)
     const float *z;
     int L;
@@ -396,9 +399,21 @@ __global__ __launch_bounds__(256) void total_loss_kernel(TotalArgs a) {
     if (tid == 0) {
         const float rm = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)a.B;
         const float qm = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)a.B;
+        float al = 0.0f, pr = 0.0f, ac = 0.0f;
+        for (int i = 0; i < a.n_tag; i++) {  // ascending level order, as the reference accumulates (h_rqvae.py:539-547)
+            const float ai = *a.align[i], pi = *a.pred[i], ci = *a.acc[i];
+            al += ai; pr += pi; ac += ci;
+            if (a.tagstats != nullptr) {
+                a.tagstats[3 + i] = ai;
+                a.tagstats[3 + a.n_tag + i] = pi;
+                a.tagstats[3 + 2 * a.n_tag + i] = ci;
+            }
+        }
+        if (a.n_tag > 0) { al = al / a.tag_div; pr = pr / a.tag_div; ac = ac / a.tag_div; }
+        if (a.tagstats != nullptr) { a.tagstats[0] = al; a.tagstats[1] = pr; a.tagstats[2] = ac; }
         float t = rm + qm;
-        t = t + a.w_a * (a.align != nullptr ? *a.align : 0.0f);
-        t = t + a.w_p * (a.pred != nullptr ? *a.pred : 0.0f);
+        t = t + a.w_a * al;
+        t = t + a.w_p * pr;
         t = t + a.w_u * uq;
         *a.loss = t;
         if (a.uniq != nullptr) *a.uniq = uq;
@@ -428,13 +443,23 @@ extern "C" int hidvae_uniq_loss(const int64_t *ids, const float *z, int64_t B, i
     return HIDVAE_OK;
 }
 
-extern "C" int hidvae_total_loss(const float *recon, const float *qloss, int64_t B, const float *align, const float *pred,
+extern "C" int hidvae_total_loss(const float *recon, const float *qloss, int64_t B, const float *const *align_host,
+                                 const float *const *pred_host, const float *const *acc_host, int n_tag, float tag_div,
                                  const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
-                                 float w_p, float w_u, float *loss, float *uniq, float *g_rows, void *stream) {
+                                 float w_p, float w_u, float *loss, float *uniq, float *g_rows, float *tagstats, void *stream) {
     HV_REQUIRE(recon && qloss && loss && B >= 1, "total_loss: bad arguments");
     HV_REQUIRE(ids == nullptr || (z != nullptr && L >= 1 && L <= HIDVAE_MAX_LEVELS),
                "total_loss: uniqueness term needs z and 1 <= n_layers <= %d (L=%d)", HIDVAE_MAX_LEVELS, L);
-    TotalArgs a{recon, qloss, B, align, pred, ids, z, L, uniq_weight, uniq_margin, w_a, w_p, w_u, loss, uniq, g_rows};
+    HV_REQUIRE(n_tag >= 0 && n_tag <= HIDVAE_MAX_LEVELS && (n_tag == 0 || (align_host && pred_host && acc_host && tag_div > 0.0f)),
+               "total_loss: tag terms");
+    TotalArgs a{};
+    a.recon = recon; a.qloss = qloss; a.B = B; a.n_tag = n_tag; a.tag_div = tag_div; a.tagstats = tagstats;
+    for (int i = 0; i < n_tag; i++) {
+        HV_REQUIRE(align_host[i] && pred_host[i] && acc_host[i], "total_loss: null tag scalar at level %d", i);
+        a.align[i] = align_host[i]; a.pred[i] = pred_host[i]; a.acc[i] = acc_host[i];
+    }
+    a.ids = ids; a.z = z; a.L = L; a.uniq_weight = uniq_weight; a.uniq_margin = uniq_margin;
+    a.w_a = w_a; a.w_p = w_p; a.w_u = w_u; a.loss = loss; a.uniq = uniq; a.g_rows = g_rows;
     hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     HV_LAUNCH_CHECK("total_loss");
     return HIDVAE_OK;

@@ -1,0 +1,618 @@
+// Row / elementwise kernels of the tag heads (reference modules/h_rqvae.py:108-227 TagPredictor, :322-331 tag projector)
+// and their losses (modules/loss.py:48-85 InfoNCE, :89-265 focal / CE with mixup) for gfx950.
+// One wave per row wherever a row reduction is needed (rows are <= 768 wide); column reductions (BatchNorm, the affine
+// gradients of LayerNorm) use one workgroup per 64 columns walking the rows in a fixed order, so every result is
+// bit-reproducible run to run.  Everything is fp32.
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// out = g * act'(ref) * mask * scale          (backward through activation + dropout of a Linear)
+//   RELU: ref = forward OUTPUT (after dropout): y > 0 <=> pre > 0 and kept, so the mask is implied
+//   GELU / SILU: ref = pre-activation;  SIGMOID: ref = forward output
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const float *ref, int64_t n, int act, const float *mask,
+                                                      float scale, float *out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = g[i];
+        const float r = ref != nullptr ? ref[i] : 0.0f;
+        const float ms = mask != nullptr ? mask[i] * scale : 1.0f;
+        switch (act) {
+            case HIDVAE_EPI_RELU: v = r > 0.0f ? v * (mask != nullptr ? scale : 1.0f) : 0.0f; break;
+            case HIDVAE_EPI_GELU: v = v * hv_dgelu(r) * ms; break;
+            case HIDVAE_EPI_SIGMOID: v = v * (r * (1.0f - r)) * ms; break;
+            case HIDVAE_EPI_SILU: v = v * hv_dsilu(r) * ms; break;
+            default: v = v * ms; break;
+        }
+        out[i] = v;
+    }
+}
+
+// out = a * b  (op 0)  or  a + b  (op 1), elementwise, row strides allowed
+__global__ __launch_bounds__(256) void mul_kernel(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M, int64_t N,
+                                                  float *out, int64_t ldo, int op) {
+    const int64_t n = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / N, c = i - r * N;
+        out[r * ldo + c] = op ? a[r * lda + c] + b[r * ldb + c] : a[r * lda + c] * b[r * ldb + c];
+    }
+}
+
+// dst[:, c] = sum over sources s with c < width[s] of src_s[:, c]   (gradient of the concatenated-embedding views)
+constexpr int MAX_SLICES = 24;
+struct SliceArgs {
+    const float *src[MAX_SLICES];
+    int width[MAX_SLICES];
+    int n;
+    int64_t M, N;
+    float *dst;
+};
+__global__ __launch_bounds__(256) void sum_prefix_slices_kernel(SliceArgs a) {
+    const int64_t tot = a.M * a.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.N;
+        const int c = (int)(i - r * a.N);
+        float v = 0.0f;
+        for (int s = 0; s < a.n; s++)
+            if (c < a.width[s]) v += a.src[s][r * a.width[s] + c];
+        a.dst[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (biased variance) + optional ReLU + dropout mask + residual:  y = drop(relu(LN(x))) + res
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *x, int64_t M, int64_t N, const float *gamma,
+                                                            const float *beta, float eps, float *y, float *mean, float *rstd,
+                                                            int relu, const float *mask, float scale, const float *res) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float *xr = x + row * N;
+    float s = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) s += xr[i];
+    const float mu = hv_wave_sum(s) / (float)N;
+    float v = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) { const float d = xr[i] - mu; v += d * d; }
+    const float rs = 1.0f / sqrtf(hv_wave_sum(v) / (float)N + eps);
+    for (int64_t i = lane; i < N; i += 64) {
+        float o = (xr[i] - mu) * rs * gamma[i] + beta[i];
+        if (relu) o = fmaxf(o, 0.0f);
+        if (mask != nullptr) o = o * (mask[row * N + i] * scale);
+        if (res != nullptr) o = o + res[row * N + i];
+        y[row * N + i] = o;
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// gh = gy * mask*scale * (h > 0 if relu), h = xhat*gamma+beta;  dy = gh*gamma
+// gx = rstd * (dy - mean(dy) - xhat * mean(dy*xhat))
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *gy, const float *x, const float *gamma, const float *beta,
+                                                            const float *mean, const float *rstd, int64_t M, int64_t N, int relu,
+                                                            const float *mask, float scale, float *gx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) {
+        const float xh = (x[row * N + i] - mu) * rs;
+        float g = gy[row * N + i];
+        if (mask != nullptr) g = g * (mask[row * N + i] * scale);
+        if (relu && !(xh * gamma[i] + beta[i] > 0.0f)) g = 0.0f;
+        const float dy = g * gamma[i];
+        s1 += dy;
+        s2 += dy * xh;
+    }
+    s1 = hv_wave_sum(s1) / (float)N;
+    s2 = hv_wave_sum(s2) / (float)N;
+    for (int64_t i = lane; i < N; i += 64) {
+        const float xh = (x[row * N + i] - mu) * rs;
+        float g = gy[row * N + i];
+        if (mask != nullptr) g = g * (mask[row * N + i] * scale);
+        if (relu && !(xh * gamma[i] + beta[i] > 0.0f)) g = 0.0f;
+        gx[row * N + i] = rs * ((g * gamma[i] - s1) - xh * s2);
+    }
+}
+
+// affine gradients of LayerNorm: one workgroup per 64 columns, 4 row-lanes walk all rows, fixed combine order
+__global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const float *gy, const float *x, const float *gamma,
+                                                                   const float *beta, const float *mean, const float *rstd,
+                                                                   int64_t M, int64_t N, int relu, const float *mask, float scale,
+                                                                   float *ggamma, float *gbeta, int accumulate) {
+    __shared__ float red[2][4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    float sg = 0.0f, sb = 0.0f;
+    if (n < N) {
+        const float ga = gamma[n], be = beta[n];
+        for (int64_t m = rl; m < M; m += 4) {
+            const float xh = (x[m * N + n] - mean[m]) * rstd[m];
+            float g = gy[m * N + n];
+            if (mask != nullptr) g = g * (mask[m * N + n] * scale);
+            if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+            sg += g * xh;
+            sb += g;
+        }
+    }
+    red[0][rl][c] = sg;
+    red[1][rl][c] = sb;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        const float a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+        ggamma[n] = accumulate ? ggamma[n] + a : a;
+        gbeta[n] = accumulate ? gbeta[n] + b : b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm1d (h_rqvae.py:325).  One workgroup (1024 threads = 64 columns x 16 row-lanes) per 64 columns.
+// training: batch mean / biased variance (two passes), running stats <- (1-mom)*old + mom*{mean, unbiased var};
+// eval: the running stats.  y = drop(relu(xhat*gamma+beta)).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float colreduce16(float v, float (*red)[64], int c, int rl) {
+    red[rl][c] = v;
+    __syncthreads();
+    float s = 0.0f;
+    if (rl == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += red[j][c];
+        red[0][c] = s;
+    }
+    __syncthreads();
+    s = red[0][c];
+    __syncthreads();
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float *x, int64_t ldx, int64_t M, int64_t N, const float *gamma,
+                                                             const float *beta, float eps, float momentum, int training,
+                                                             float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                                                             float *y, float *save_mean, float *save_rstd, int relu,
+                                                             const float *mask, float scale) {
+    __shared__ float red[16][64];
+    if (training && num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    const bool ok = n < N;
+    float mu, rs;
+    if (training) {
+        float s = 0.0f;
+        if (ok) for (int64_t m = rl; m < M; m += 16) s += x[m * ldx + n];
+        mu = colreduce16(s, red, c, rl) / (float)M;
+        float v = 0.0f;
+        if (ok) for (int64_t m = rl; m < M; m += 16) { const float d = x[m * ldx + n] - mu; v += d * d; }
+        const float var = colreduce16(v, red, c, rl) / (float)M;
+        rs = 1.0f / sqrtf(var + eps);
+        if (ok && rl == 0) {
+            save_mean[n] = mu;
+            save_rstd[n] = rs;
+            if (running_mean != nullptr) {
+                const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+                running_mean[n] = (1.0f - momentum) * running_mean[n] + momentum * mu;
+                running_var[n] = (1.0f - momentum) * running_var[n] + momentum * unbiased;
+            }
+        }
+    } else {
+        mu = ok ? running_mean[n] : 0.0f;
+        rs = ok ? 1.0f / sqrtf(running_var[n] + eps) : 0.0f;
+    }
+    if (!ok) return;
+    const float ga = gamma != nullptr ? gamma[n] : 1.0f, be = beta != nullptr ? beta[n] : 0.0f;
+    for (int64_t m = rl; m < M; m += 16) {
+        float o = (x[m * ldx + n] - mu) * rs * ga + be;
+        if (relu) o = fmaxf(o, 0.0f);
+        if (mask != nullptr) o = o * (mask[m * N + n] * scale);
+        y[m * N + n] = o;
+    }
+}
+
+// training-mode backward: gh = gy*mask*scale*(h>0); ggamma = sum gh*xhat; gbeta = sum gh;
+// gx = gamma*rstd/M * (M*gh - gbeta - xhat*ggamma)
+__global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float *gy, const float *x, int64_t ldx, const float *gamma,
+                                                             const float *beta, const float *save_mean, const float *save_rstd,
+                                                             int64_t M, int64_t N, int relu, const float *mask, float scale,
+                                                             float *gx, float *ggamma, float *gbeta, int accumulate) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    const bool ok = n < N;
+    const float mu = ok ? save_mean[n] : 0.0f, rs = ok ? save_rstd[n] : 0.0f;
+    const float ga = ok ? gamma[n] : 0.0f, be = ok ? beta[n] : 0.0f;
+    float sg = 0.0f, sb = 0.0f;
+    if (ok)
+        for (int64_t m = rl; m < M; m += 16) {
+            const float xh = (x[m * ldx + n] - mu) * rs;
+            float g = gy[m * N + n];
+            if (mask != nullptr) g = g * (mask[m * N + n] * scale);
+            if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+            sg += g * xh;
+            sb += g;
+        }
+    sg = colreduce16(sg, red, c, rl);
+    sb = colreduce16(sb, red, c, rl);
+    if (!ok) return;
+    if (rl == 0) {
+        ggamma[n] = accumulate ? ggamma[n] + sg : sg;
+        gbeta[n] = accumulate ? gbeta[n] + sb : sb;
+    }
+    if (gx != nullptr) {
+        const float k = ga * rs / (float)M;
+        for (int64_t m = rl; m < M; m += 16) {
+            const float xh = (x[m * ldx + n] - mu) * rs;
+            float g = gy[m * N + n];
+            if (mask != nullptr) g = g * (mask[m * N + n] * scale);
+            if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+            gx[m * N + n] = k * (((float)M * g - sb) - xh * sg);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// InfoNCE rows (loss.py:70-77): S = cn tn^T already in `S` [B,B]; per row b: loss_b = logsumexp_j(S_bj/tau) - S_bb/tau,
+// and S is overwritten with the softmax P (the backward needs it).  row_loss [B].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void infonce_rows_kernel(float *S, int64_t B, float inv_tau, float *row_loss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float *s = S + row * B;
+    float mx = -INFINITY;
+    for (int64_t j = lane; j < B; j += 64) mx = fmaxf(mx, s[j] * inv_tau);
+    mx = hv_wave_max(mx);
+    float sum = 0.0f;
+    for (int64_t j = lane; j < B; j += 64) sum += expf(s[j] * inv_tau - mx);
+    sum = hv_wave_sum(sum);
+    const float lse = mx + logf(sum);
+    const float diag = s[row] * inv_tau;
+    for (int64_t j = lane; j < B; j += 64) s[j] = expf(s[j] * inv_tau - mx) / sum;
+    if (lane == 0) row_loss[row] = lse - diag;
+}
+
+// out[0] = scale * mean(v)   (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void vec_mean_kernel(const float *v, int64_t n, float scale, float *out) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
+    s = hv_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = scale * (((red[0] + red[1]) + (red[2] + red[3])) / (float)n);
+}
+
+// dS = (g * coef) * (P - I)     coef = scale / (B * tau), g = upstream device scalar
+__global__ __launch_bounds__(256) void infonce_dlogits_kernel(float *P, int64_t B, const float *g, float coef) {
+    const float k = *g * coef;
+    const int64_t n = B * B;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / B, c = i - r * B;
+        P[i] = k * (P[i] - (r == c ? 1.0f : 0.0f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tag prediction loss rows (loss.py:107-265, layer_idx = 0 semantics).  One wave per row.
+//   partner[b]: mixup partner row (original indexing) or -1 => no mixup for the whole call when partner == nullptr
+//   mode 1 = focal with smoothing, 0 = CE(label_smoothing=0.05) + 0.05*KL(uniform || softmax(unmixed)+1e-8)
+// Writes per row: row_loss (0 for invalid rows), row_hit (argmax(unmixed) == target), and -- if dmix != nullptr --
+// dmix[b,:] = d row_loss / d mixed_logits[b,:] and (CE mode) dkl[b,:] = d kl_row / d logits[b,:].
+// ------------------------------------------------------------------------------------------------
+struct TagLossArgs {
+    const float *logits;
+    int64_t B, C;
+    const int64_t *target;
+    const int64_t *partner;
+    const float *lam_dev;  // mixup weight (device scalar: it changes every step, also under graph replay)
+    int focal;
+    float gamma, alpha, smooth, ce_ls;
+    float *row_loss, *row_hit, *dmix, *dkl;
+};
+
+__device__ __forceinline__ float focal_row(const float *z, int64_t C, int64_t cls, float smooth, float gamma, float alpha, int lane,
+                                           float mx, float sum, float coef, float *dz) {
+    // p_k = exp(z_k - mx)/sum; oh_k = (k==cls)(1-s) + s/C
+    float pt = 0.0f, ce = 0.0f;
+    const float lsum = logf(sum);
+    for (int64_t k = lane; k < C; k += 64) {
+        const float oh = (k == cls ? 1.0f - smooth : 0.0f) + smooth / (float)C;
+        const float logp = (z[k] - mx) - lsum;
+        pt += oh * expf(logp);
+        ce -= oh * logp;
+    }
+    pt = hv_wave_sum(pt);
+    ce = hv_wave_sum(ce);
+    const float om = 1.0f - pt;
+    const float w = alpha * powf(om, gamma);
+    if (dz != nullptr) {
+        const float dw = -alpha * gamma * powf(om, gamma - 1.0f);  // d w / d pt
+        for (int64_t k = lane; k < C; k += 64) {
+            const float oh = (k == cls ? 1.0f - smooth : 0.0f) + smooth / (float)C;
+            const float p = expf((z[k] - mx) - lsum);
+            dz[k] += coef * (dw * (p * (oh - pt)) * ce + w * (p - oh));
+        }
+    }
+    return w * ce;
+}
+
+__device__ __forceinline__ float ce_row(const float *z, int64_t C, int64_t cls, float ls, int lane, float mx, float sum, float coef,
+                                        float *dz) {
+    const float lsum = logf(sum);
+    float nll = 0.0f, all = 0.0f;
+    for (int64_t k = lane; k < C; k += 64) {
+        const float logp = (z[k] - mx) - lsum;
+        if (k == cls) nll = -logp;
+        all -= logp;
+    }
+    nll = hv_wave_sum(nll);
+    all = hv_wave_sum(all);
+    if (dz != nullptr)
+        for (int64_t k = lane; k < C; k += 64) {
+            const float p = expf((z[k] - mx) - lsum);
+            const float oh = (k == cls ? 1.0f - ls : 0.0f) + ls / (float)C;
+            dz[k] += coef * (p - oh);
+        }
+    return (1.0f - ls) * nll + ls * (all / (float)C);
+}
+
+__global__ __launch_bounds__(256) void tag_loss_rows_kernel(TagLossArgs a, float *zbuf) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.B) return;
+    const int64_t cls = a.target[row];
+    const int64_t C = a.C;
+    float *dz = a.dmix != nullptr ? a.dmix + row * C : nullptr;
+    if (dz != nullptr)
+        for (int64_t k = lane; k < C; k += 64) dz[k] = 0.0f;
+    if (a.dkl != nullptr)
+        for (int64_t k = lane; k < C; k += 64) a.dkl[row * C + k] = 0.0f;
+    if (cls < 0) {
+        if (lane == 0) { a.row_loss[row] = 0.0f; a.row_hit[row] = 0.0f; }
+        return;
+    }
+    const float *z0 = a.logits + row * C;
+    // accuracy on the un-mixed logits (first maximum, like torch.argmax)
+    float bm = -INFINITY;
+    int64_t bi = 0;
+    for (int64_t k = lane; k < C; k += 64)
+        if (z0[k] > bm) { bm = z0[k]; bi = k; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(bm, o);
+        const int64_t oi = __shfl_xor(bi, o);
+        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+    }
+    // mixed logits (loss.py:150) into this row's scratch
+    float *z = zbuf + row * C;
+    const int64_t pr = a.partner != nullptr ? a.partner[row] : -1;
+    const bool mixed = pr >= 0;
+    const float lam = mixed ? *a.lam_dev : 1.0f;
+    for (int64_t k = lane; k < C; k += 64) z[k] = mixed ? lam * z0[k] + (1.0f - lam) * a.logits[pr * C + k] : z0[k];
+    float mx = -INFINITY;
+    for (int64_t k = lane; k < C; k += 64) mx = fmaxf(mx, z[k]);
+    mx = hv_wave_max(mx);
+    float sum = 0.0f;
+    for (int64_t k = lane; k < C; k += 64) sum += expf(z[k] - mx);
+    sum = hv_wave_sum(sum);
+    float loss;
+    if (a.focal) {
+        loss = focal_row(z, C, cls, a.smooth, a.gamma, a.alpha, lane, mx, sum, lam, dz);
+        if (mixed) loss = lam * loss + (1.0f - lam) * focal_row(z, C, a.target[pr], a.smooth, a.gamma, a.alpha, lane, mx, sum, 1.0f - lam, dz);
+    } else {
+        loss = ce_row(z, C, cls, a.ce_ls, lane, mx, sum, lam, dz);
+        if (mixed) loss = lam * loss + (1.0f - lam) * ce_row(z, C, a.target[pr], a.ce_ls, lane, mx, sum, 1.0f - lam, dz);
+        // + 0.05 * KL(uniform || softmax(unmixed) + 1e-8), batchmean  (loss.py:222-223)
+        float m0 = -INFINITY;
+        for (int64_t k = lane; k < C; k += 64) m0 = fmaxf(m0, z0[k]);
+        m0 = hv_wave_max(m0);
+        float s0 = 0.0f;
+        for (int64_t k = lane; k < C; k += 64) s0 += expf(z0[k] - m0);
+        s0 = hv_wave_sum(s0);
+        const float u = 1.0f / (float)C, logu = logf(u);
+        float kl = 0.0f, t = 0.0f;
+        for (int64_t k = lane; k < C; k += 64) {
+            const float p = expf(z0[k] - m0) / s0;
+            kl += u * (logu - logf(p + 1e-8f));
+            t += p / (p + 1e-8f) * p;  // sum_j w_j p_j, w_j = p_j/(p_j+eps)
+        }
+        kl = hv_wave_sum(kl);
+        t = hv_wave_sum(t);
+        loss += 0.05f * kl;
+        if (a.dkl != nullptr) {
+            // d/dz_k [ -u sum_j log(p_j+eps) ] = -u ( w_k p_k - p_k sum_j w_j p_j )... with w_j = p_j/(p_j+eps):
+            // d log(p_j+eps)/dz_k = (p_j/(p_j+eps)) (delta_jk - p_k)
+            float wsum = 0.0f;
+            for (int64_t k = lane; k < C; k += 64) { const float p = expf(z0[k] - m0) / s0; wsum += p / (p + 1e-8f); }
+            wsum = hv_wave_sum(wsum);
+            for (int64_t k = lane; k < C; k += 64) {
+                const float p = expf(z0[k] - m0) / s0;
+                a.dkl[row * C + k] = 0.05f * (-u) * (p / (p + 1e-8f) - p * wsum);
+            }
+        }
+        (void)t;
+    }
+    if (lane == 0) { a.row_loss[row] = loss; a.row_hit[row] = (bi == cls) ? 1.0f : 0.0f; }
+}
+
+// loss = sum(row_loss)/n_valid, acc = sum(row_hit)/n_valid (0,0 if no valid row: loss.py:123-125); single workgroup
+__global__ __launch_bounds__(256) void tag_loss_reduce_kernel(const float *row_loss, const float *row_hit, const int64_t *target,
+                                                              int64_t B, float *loss, float *acc, float *n_valid_out) {
+    __shared__ float red[3][4];
+    float l = 0.0f, h = 0.0f, n = 0.0f;
+    for (int64_t i = threadIdx.x; i < B; i += 256) {
+        if (target[i] >= 0) { l += row_loss[i]; h += row_hit[i]; n += 1.0f; }
+    }
+    l = hv_wave_sum(l); h = hv_wave_sum(h); n = hv_wave_sum(n);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = l; red[1][threadIdx.x >> 6] = h; red[2][threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ls = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float hs = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const float ns = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        *loss = ns > 0.0f ? ls / ns : 0.0f;
+        *acc = ns > 0.0f ? hs / ns : 0.0f;
+        *n_valid_out = ns;
+    }
+}
+
+// L = (1/n) sum_b row_loss_b with mixed_b = lam z_b + (1-lam) z_partner(b)  =>
+// g_logits[r,:] = (g / n_valid) * ( lam*dmix[r,:] + (1-lam)*dmix[inverse[r],:] + dkl[r,:] )   (invalid rows: 0)
+__global__ __launch_bounds__(256) void tag_loss_bwd_kernel(const float *dmix, const float *dkl, const int64_t *target,
+                                                           const int64_t *inverse, const float *lam_dev, int64_t B, int64_t C,
+                                                           const float *g, const float *n_valid, float *g_logits) {
+    const float nv = *n_valid;
+    const float lam = inverse != nullptr ? *lam_dev : 1.0f;
+    const float k = nv > 0.0f ? *g / nv : 0.0f;
+    const int64_t n = B * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C, c = i - r * C;
+        float v = 0.0f;
+        if (target[r] >= 0) {
+            if (inverse != nullptr) v = lam * dmix[i] + (1.0f - lam) * dmix[inverse[r] * C + c];
+            else v = dmix[i];
+            if (dkl != nullptr) v += dkl[i];
+        }
+        g_logits[i] = k * v;
+    }
+}
+
+}  // namespace
+
+static inline unsigned ew_grid(int64_t n) {
+    int64_t g = hv_cdiv(n, 256);
+    return (unsigned)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
+}
+
+extern "C" int hidvae_act_bwd(const float *g, const float *ref, int64_t numel, int act, const float *mask, float mask_scale,
+                              float *out, void *stream) {
+    HV_REQUIRE(g && out && numel >= 1, "act_bwd: bad arguments");
+    HV_REQUIRE(act == HIDVAE_EPI_NONE || ref != nullptr, "act_bwd: activation %d needs its reference tensor", act);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(numel)), dim3(256), 0, (hipStream_t)stream, g, ref, numel, act, mask, mask_scale, out);
+    HV_LAUNCH_CHECK("act_bwd");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_binary(int op, const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M, int64_t N, float *out,
+                             int64_t ldo, void *stream) {
+    HV_REQUIRE(a && b && out && M >= 1 && N >= 1 && lda >= N && ldb >= N && ldo >= N && (op == 0 || op == 1), "binary: bad arguments");
+    hipLaunchKernelGGL(mul_kernel, dim3(ew_grid(M * N)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, M, N, out, ldo, op);
+    HV_LAUNCH_CHECK("binary");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_sum_prefix_slices(const float *const *src_host, const int32_t *width_host, int n, int64_t M, int64_t N,
+                                        float *dst, void *stream) {
+    HV_REQUIRE(src_host && width_host && dst && n >= 0 && n <= MAX_SLICES && M >= 1 && N >= 1, "sum_prefix_slices: bad arguments");
+    SliceArgs a{};
+    a.n = 0;
+    for (int i = 0; i < n; i++) {
+        if (src_host[i] == nullptr) continue;
+        HV_REQUIRE(width_host[i] >= 1 && width_host[i] <= N, "sum_prefix_slices: width %d", width_host[i]);
+        a.src[a.n] = src_host[i];
+        a.width[a.n] = width_host[i];
+        a.n++;
+    }
+    a.M = M; a.N = N; a.dst = dst;
+    hipLaunchKernelGGL(sum_prefix_slices_kernel, dim3(ew_grid(M * N)), dim3(256), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("sum_prefix_slices");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_layernorm_fwd(const float *x, int64_t M, int64_t N, const float *gamma, const float *beta, float eps, float *y,
+                                    float *mean, float *rstd, int relu, const float *keep_mask, float keep_scale,
+                                    const float *residual, void *stream) {
+    HV_REQUIRE(x && gamma && beta && y && mean && rstd && M >= 1 && N >= 1, "layernorm_fwd: bad arguments");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, N, gamma, beta,
+                       eps, y, mean, rstd, relu, keep_mask, keep_scale, residual);
+    HV_LAUNCH_CHECK("layernorm_fwd");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
+                                    const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask, float keep_scale,
+                                    float *gx, float *ggamma, float *gbeta, int accumulate, void *stream) {
+    HV_REQUIRE(gy && x && gamma && beta && mean && rstd && M >= 1 && N >= 1, "layernorm_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (gx != nullptr) {
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, s, gy, x, gamma, beta, mean, rstd, M, N,
+                           relu, keep_mask, keep_scale, gx);
+        HV_LAUNCH_CHECK("layernorm_bwd");
+    }
+    if (ggamma != nullptr && gbeta != nullptr) {
+        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((unsigned)hv_cdiv(N, 64)), dim3(256), 0, s, gy, x, gamma, beta, mean, rstd,
+                           M, N, relu, keep_mask, keep_scale, ggamma, gbeta, accumulate);
+        HV_LAUNCH_CHECK("layernorm_param_grad");
+    }
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_batchnorm_fwd(const float *x, int64_t ldx, int64_t M, int64_t N, const float *gamma, const float *beta, float eps,
+                                    float momentum, int training, float *running_mean, float *running_var,
+                                    int64_t *num_batches_tracked, float *y, float *save_mean, float *save_rstd, int relu,
+                                    const float *keep_mask, float keep_scale, void *stream) {
+    HV_REQUIRE(x && y && M >= 1 && N >= 1 && ldx >= N, "batchnorm_fwd: bad arguments");
+    HV_REQUIRE(training ? (save_mean && save_rstd) : (running_mean && running_var), "batchnorm_fwd: statistics buffers missing");
+    hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3((unsigned)hv_cdiv(N, 64)), dim3(1024), 0, (hipStream_t)stream, x, ldx, M, N, gamma,
+                       beta, eps, momentum, training, running_mean, running_var, num_batches_tracked, y, save_mean, save_rstd, relu, keep_mask,
+                       keep_scale);
+    HV_LAUNCH_CHECK("batchnorm_fwd");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx, const float *gamma, const float *beta,
+                                    const float *save_mean, const float *save_rstd, int64_t M, int64_t N, int relu,
+                                    const float *keep_mask, float keep_scale, float *gx, float *ggamma, float *gbeta, int accumulate,
+                                    void *stream) {
+    HV_REQUIRE(gy && x && gamma && beta && save_mean && save_rstd && ggamma && gbeta && M >= 1 && N >= 1 && ldx >= N,
+               "batchnorm_bwd: bad arguments");
+    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((unsigned)hv_cdiv(N, 64)), dim3(1024), 0, (hipStream_t)stream, gy, x, ldx, gamma, beta,
+                       save_mean, save_rstd, M, N, relu, keep_mask, keep_scale, gx, ggamma, gbeta, accumulate);
+    HV_LAUNCH_CHECK("batchnorm_bwd");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_infonce_rows(float *S, int64_t B, float tau, float scale, float *row_loss, float *loss, void *stream) {
+    HV_REQUIRE(S && row_loss && loss && B >= 1 && tau > 0.0f, "infonce_rows: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(infonce_rows_kernel, dim3((unsigned)hv_cdiv(B, 4)), dim3(256), 0, s, S, B, 1.0f / tau, row_loss);
+    HV_LAUNCH_CHECK("infonce_rows");
+    hipLaunchKernelGGL(vec_mean_kernel, dim3(1), dim3(256), 0, s, row_loss, B, scale, loss);
+    HV_LAUNCH_CHECK("infonce mean");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_infonce_dlogits(float *P, int64_t B, float tau, float scale, const float *g_dev, void *stream) {
+    HV_REQUIRE(P && g_dev && B >= 1 && tau > 0.0f, "infonce_dlogits: bad arguments");
+    hipLaunchKernelGGL(infonce_dlogits_kernel, dim3(ew_grid(B * B)), dim3(256), 0, (hipStream_t)stream, P, B, g_dev,
+                       scale / ((float)B * tau));
+    HV_LAUNCH_CHECK("infonce_dlogits");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_tag_loss_fwd(const float *logits, int64_t B, int64_t C, const int64_t *target, const int64_t *partner,
+                                   const float *lam_dev,
+                                   int focal, float gamma, float alpha, float smooth, float ce_label_smoothing, float *loss,
+                                   float *acc, float *n_valid, float *row_loss, float *row_hit, float *zbuf, float *dmix, float *dkl,
+                                   void *stream) {
+    HV_REQUIRE(logits && target && loss && acc && n_valid && row_loss && row_hit && zbuf && B >= 1 && C >= 1, "tag_loss_fwd: bad arguments");
+    HV_REQUIRE(partner == nullptr || lam_dev != nullptr, "tag_loss_fwd: mixup needs lam");
+    TagLossArgs a{logits, B, C, target, partner, lam_dev, focal, gamma, alpha, smooth, ce_label_smoothing, row_loss, row_hit, dmix, dkl};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tag_loss_rows_kernel, dim3((unsigned)hv_cdiv(B, 4)), dim3(256), 0, s, a, zbuf);
+    HV_LAUNCH_CHECK("tag_loss_rows");
+    hipLaunchKernelGGL(tag_loss_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, row_hit, target, B, loss, acc, n_valid);
+    HV_LAUNCH_CHECK("tag_loss_reduce");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_tag_loss_bwd(const float *dmix, const float *dkl, const int64_t *target, const int64_t *inverse,
+                                   const float *lam_dev,
+                                   int64_t B, int64_t C, const float *g_dev, const float *n_valid, float *g_logits, void *stream) {
+    HV_REQUIRE(dmix && target && g_dev && n_valid && g_logits && B >= 1 && C >= 1, "tag_loss_bwd: bad arguments");
+    hipLaunchKernelGGL(tag_loss_bwd_kernel, dim3(ew_grid(B * C)), dim3(256), 0, (hipStream_t)stream, dmix, dkl, target, inverse, lam_dev, B,
+                       C, g_dev, n_valid, g_logits);
+    HV_LAUNCH_CHECK("tag_loss_bwd");
+    return HIDVAE_OK;
+}

@@ -262,7 +262,10 @@ class HRqVae(nn.Module, _HubMixin):
         align = pred = acc = zero
         by_layer = (None, None, None) if tags_emb is not None and tags_indices is not None else ([], [], [])
         if tags_emb is not None and tags_indices is not None:
-            align, pred, acc, by_layer = self._tag_heads(emb_cat, tags_emb, tags_indices)
+            sc = self._tag_heads(emb_cat, tags_emb.float(), tags_indices)
+            n = len(sc) // 3
+            by_layer = (torch.stack(sc[:n]), torch.stack(sc[n:2 * n]), torch.stack(sc[2 * n:]))  # (API path, not the hot step)
+            align, pred, acc = by_layer[0].sum() / self.n_layers, by_layer[1].sum() / self.n_layers, by_layer[2].sum() / self.n_layers
         return HRqVaeOutput(embeddings=emb_cat.view(B, L, D).transpose(1, 2), residuals=res_cat.view(B, L, D).transpose(1, 2),
                             sem_ids=ids, quantize_loss=qloss, tag_align_loss=align, tag_pred_loss=pred, tag_pred_accuracy=acc,
                             tag_align_loss_by_layer=by_layer[0], tag_pred_loss_by_layer=by_layer[1],
@@ -281,11 +284,9 @@ class HRqVae(nn.Module, _HubMixin):
         z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)
         self._prepared = None
 
-        align = pred = None
-        acc = self._zero_scalar(x.device)
-        by_layer = ([], [], [])
+        tag_scalars = ()
         if tagged:
-            align, pred, acc, by_layer = self._tag_heads(emb_cat, tags_emb.float(), tags_indices)
+            tag_scalars = self._tag_heads(emb_cat, tags_emb.float(), tags_indices)  # (A_0.., P_0.., acc_0..) device scalars
 
         # debug statistics of h_rqvae.py:643-648 (embs_norm, p_unique_ids): ready as soon as the ids are, so they run on the
         # helper stream beside the decoder instead of after it
@@ -300,16 +301,24 @@ class HRqVae(nn.Module, _HubMixin):
             t.record_stream(side)
         recon = ReconstructionLoss.fused(self.decoder.body(emb_sum), x)  # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0)
         # the alignment / uniqueness weights enter once inside their loss modules and once more here
-        loss, uniq = TotalLossFn.apply(recon, qloss, align, pred, z, ids, self.sem_id_uniqueness_loss.weight,
-                                       self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight, self.tag_prediction_weight,
-                                       self.sem_id_uniqueness_weight)
-        main.wait_stream(side)  # the statistics below were computed beside the decoder
+        n_tag = len(tag_scalars) // 3
+        loss, uniq, stats = TotalLossFn.apply(recon, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
+                                              self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight,
+                                              self.tag_prediction_weight, self.sem_id_uniqueness_weight, n_tag, float(self.n_layers),
+                                              *tag_scalars)
+        main.wait_stream(side)  # the statistics above were computed beside the decoder
         zero = self._zero_scalar(x.device)
+        if tagged:
+            L = n_tag
+            return HRqVaeComputedLosses(
+                loss=loss, reconstruction_loss=recon, rqvae_loss=qloss, tag_align_loss=stats[0], tag_pred_loss=stats[1],
+                tag_pred_accuracy=stats[2], embs_norm=embs_norm, p_unique_ids=p_unique, tag_align_loss_by_layer=stats[3:3 + L],
+                tag_pred_loss_by_layer=stats[3 + L:3 + 2 * L], tag_pred_accuracy_by_layer=stats[3 + 2 * L:3 + 3 * L],
+                sem_id_uniqueness_loss=uniq)
         return HRqVaeComputedLosses(
-            loss=loss, reconstruction_loss=recon, rqvae_loss=qloss, tag_align_loss=align if tagged else zero,
-            tag_pred_loss=pred if tagged else zero, tag_pred_accuracy=acc, embs_norm=embs_norm, p_unique_ids=p_unique,
-            tag_align_loss_by_layer=by_layer[0], tag_pred_loss_by_layer=by_layer[1], tag_pred_accuracy_by_layer=by_layer[2],
-            sem_id_uniqueness_loss=uniq)
+            loss=loss, reconstruction_loss=recon, rqvae_loss=qloss, tag_align_loss=zero, tag_pred_loss=zero, tag_pred_accuracy=zero,
+            embs_norm=embs_norm, p_unique_ids=p_unique, tag_align_loss_by_layer=[], tag_pred_loss_by_layer=[],
+            tag_pred_accuracy_by_layer=[], sem_id_uniqueness_loss=uniq)
 
     @torch.no_grad()
     def predict_tags(self, x: Tensor, gumbel_t: float = 0.001) -> Dict[str, Tensor]:

@@ -38,7 +38,7 @@ class TagAlignmentLoss(nn.Module):
     def forward(self, codebook_emb, tag_emb, layer_idx: int):
         from ..tagpath import InfoNCEFn
         scale = self.alignment_weight * (1.0 / (layer_idx * 0.5 + 1))
-        return InfoNCEFn.apply(codebook_emb, tag_emb, self.temperature, scale)
+        return InfoNCEFn.apply(codebook_emb, tag_emb.contiguous(), self.temperature, scale)
 
 
 class TagPredictionLoss(nn.Module):

@@ -195,28 +195,36 @@ class ReconFn(Function):
 
 class TotalLossFn(Function):
     """loss = mean(recon) + mean(qloss) + w_a*align + w_p*pred + w_u*uniq  (h_rqvae.py:634-640), with the uniqueness
-    term evaluated in the same launch exactly as the reference calls it ([L,B] ids).
-    Returns (loss, uniq); only `loss` is differentiable."""
+    term evaluated in the same launch exactly as the reference calls it ([L,B] ids) and the per-level tag
+    losses averaged the reference's way (sum over levels / n_layers, h_rqvae.py:561-563).
+    Inputs after the hyper-parameters: n_tag alignment scalars, n_tag prediction scalars, n_tag accuracy scalars.
+    Returns (loss, uniq, tagstats); only `loss` is differentiable."""
 
     @staticmethod
-    def forward(ctx, recon, qloss, align, pred, z, ids, uniq_weight, uniq_margin, w_a, w_p, w_u):
+    def forward(ctx, recon, qloss, z, ids, uniq_weight, uniq_margin, w_a, w_p, w_u, n_tag, tag_div, *tag_scalars):
         ctx.set_materialize_grads(False)
-        want = z is not None and ctx.needs_input_grad[4]
-        loss, uniq, g_rows = _C.total_loss(recon, qloss, align, pred, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want)
-        ctx.meta = (recon.shape[0], ids.shape[1] if ids is not None else 0, w_a, w_p, w_u, align is not None, pred is not None,
-                    z is not None)
+        want = z is not None and ctx.needs_input_grad[2]
+        aligns, preds, accs = list(tag_scalars[:n_tag]), list(tag_scalars[n_tag:2 * n_tag]), list(tag_scalars[2 * n_tag:3 * n_tag])
+        loss, uniq, g_rows, tagstats = _C.total_loss(recon, qloss, [t.detach() for t in aligns], [t.detach() for t in preds],
+                                                     [t.detach() for t in accs], tag_div, ids, z, uniq_weight, uniq_margin, w_a, w_p,
+                                                     w_u, want)
+        ctx.meta = (recon.shape[0], ids.shape[1] if ids is not None else 0, w_a, w_p, w_u, n_tag, tag_div, z is not None)
         ctx.g_rows = g_rows
-        ctx.mark_non_differentiable(uniq)
-        return loss, uniq
+        if tagstats is None:
+            tagstats = torch.empty(0, device=loss.device)
+        ctx.mark_non_differentiable(uniq, tagstats)
+        return loss, uniq, tagstats
 
     @staticmethod
-    def backward(ctx, g, _g_uniq):
+    def backward(ctx, g, _g_uniq, _g_stats):
+        B, L, w_a, w_p, w_u, n_tag, tag_div, has_z = ctx.meta
         if g is None:
-            return (None,) * 11
-        B, L, w_a, w_p, w_u, has_a, has_p, has_z = ctx.meta
-        scal, g_z = _C.total_loss_bwd(g.contiguous(), B, L, w_a, w_p, w_u, ctx.g_rows, want_gz=has_z and ctx.g_rows is not None)
+            return (None,) * (11 + 3 * n_tag)
+        scal, g_z = _C.total_loss_bwd(g.contiguous(), B, L, w_a / tag_div, w_p / tag_div, w_u, ctx.g_rows,
+                                      want_gz=has_z and ctx.g_rows is not None)
         per_item = scal[0].expand(B)  # stride-0 view: the kernels downstream read one device scalar
-        return (per_item, per_item, scal[1] if has_a else None, scal[2] if has_p else None, g_z, None, None, None, None, None, None)
+        tags = (scal[1],) * n_tag + (scal[2],) * n_tag + (None,) * n_tag
+        return (per_item, per_item, g_z, None, None, None, None, None, None, None, None) + tags
 
 
 class LinearFn(Function):

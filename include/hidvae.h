@@ -140,14 +140,19 @@ int hidvae_l2norm_bwd(const float *g, int64_t ldg, const float *out, int64_t ldo
  * transposed ids of :630-631): level pairs (a<b) whose id vectors agree over the whole batch contribute
  * relu(cos(z[a], z[b]) - margin); loss = weight * mean over such pairs (0 if none).  g_rows [L,32] (optional) receives
  * d loss / d z[0:L].  a1: total loss = mean(recon)+mean(qloss)+w_a*align+w_p*pred+w_u*uniq (h_rqvae.py:634-640),
- * the uniqueness term evaluated in the same launch when ids != NULL; align/pred are device scalars or NULL (= 0). */
+ * the uniqueness term evaluated in the same launch when ids != NULL.  align/pred/acc: HOST arrays of n_tag per-level
+ * device scalars (n_tag = 0 for an untagged batch); tag_align = sum_i align_i / tag_div etc. (h_rqvae.py:561-563);
+ * tagstats [3+3*n_tag] (optional) receives the three means followed by the three by-layer vectors. */
 int hidvae_uniq_loss(const int64_t *ids, const float *z, int64_t B, int L, float weight, float margin, float *loss,
                      float *g_rows, void *stream);
-int hidvae_total_loss(const float *recon, const float *qloss, int64_t B, const float *align, const float *pred,
+int hidvae_total_loss(const float *recon, const float *qloss, int64_t B,
+                      const float *const *align_host, const float *const *pred_host, const float *const *acc_host,
+                      int n_tag, float tag_div,
                       const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin,
-                      float w_a, float w_p, float w_u, float *loss, float *uniq, float *g_rows, void *stream);
+                      float w_a, float w_p, float w_u, float *loss, float *uniq, float *g_rows, float *tagstats,
+                      void *stream);
 /* backward of the above for a device scalar g = d/d loss: scal[0] = g/B (per-item grad of recon and qloss),
- * scal[1] = g*w_a, scal[2] = g*w_p; g_z [B,32] (optional) = g*w_u*g_rows on rows < L, 0 elsewhere. */
+ * scal[1] = g*w_a, scal[2] = g*w_p (pass w_a/tag_div, w_p/tag_div to get the per-level gradients); g_z [B,32] (optional) = g*w_u*g_rows on rows < L, 0 elsewhere. */
 int hidvae_total_loss_bwd(const float *g_loss, int64_t B, int L, float w_a, float w_p, float w_u, const float *g_rows,
                           float *scal, float *g_z, void *stream);
 
@@ -171,6 +176,58 @@ int hidvae_adamw_prepare(int64_t *step_dev, const float *base_lr_dev, const floa
 int hidvae_adamw_step(float *const *p_dev, const float *const *g_host, float *const *m_dev, float *const *v_dev,
                       const int64_t *numel_dev, const float *hyper_dev, int n_tensors, int64_t max_numel,
                       float beta1, float beta2, float eps, float grad_scale, void *stream);
+
+/* ======== tag path (a8-a11): element / row kernels ================================================================ */
+/* out = g * act'(ref) * mask*scale: backward through the activation (+dropout) fused into a Linear's epilogue.
+ * act = HIDVAE_EPI_{NONE,RELU,GELU,SIGMOID,SILU}; ref = forward OUTPUT for RELU/SIGMOID, pre-activation for GELU/SILU. */
+int hidvae_act_bwd(const float *g, const float *ref, int64_t numel, int act, const float *mask, float mask_scale,
+                   float *out, void *stream);
+/* out = a * b (op 0: TagPredictor gate, h_rqvae.py:208) or a + b (op 1: residual add, :219), row strides in elements */
+int hidvae_binary(int op, const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M, int64_t N, float *out,
+                  int64_t ldo, void *stream);
+/* dst[M,N] = sum_s src_s[:, :width_s] zero-extended: gradient of the column-prefix views concat_emb = cat(embs[:i+1])
+ * (h_rqvae.py:526) taken of one [B, L*32] buffer.  src_host / width_host: HOST arrays (n <= 24, NULL entries skipped). */
+int hidvae_sum_prefix_slices(const float *const *src_host, const int32_t *width_host, int n, int64_t M, int64_t N,
+                             float *dst, void *stream);
+/* y = dropout(relu?(LayerNorm(x))) + residual   (nn.LayerNorm eps; h_rqvae.py:145,156,162,181,329) and its backward:
+ * gx (may be NULL), ggamma/gbeta (may both be NULL).  The residual's gradient is gy itself. */
+int hidvae_layernorm_fwd(const float *x, int64_t M, int64_t N, const float *gamma, const float *beta, float eps, float *y,
+                         float *mean, float *rstd, int relu, const float *keep_mask, float keep_scale,
+                         const float *residual, void *stream);
+int hidvae_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
+                         const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask, float keep_scale,
+                         float *gx, float *ggamma, float *gbeta, int accumulate, void *stream);
+/* BatchNorm1d (h_rqvae.py:325): y = dropout(relu?(BN(x))).  training != 0: batch statistics (biased variance for the
+ * normalisation, unbiased for the running update with `momentum`), saved mean / rstd for the backward;
+ * training == 0: running statistics.  num_batches_tracked (optional int64 device scalar) is incremented in training. */
+int hidvae_batchnorm_fwd(const float *x, int64_t ldx, int64_t M, int64_t N, const float *gamma, const float *beta, float eps,
+                         float momentum, int training, float *running_mean, float *running_var,
+                         int64_t *num_batches_tracked, float *y, float *save_mean, float *save_rstd, int relu,
+                         const float *keep_mask, float keep_scale, void *stream);
+int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx, const float *gamma, const float *beta,
+                         const float *save_mean, const float *save_rstd, int64_t M, int64_t N, int relu,
+                         const float *keep_mask, float keep_scale, float *gx, float *ggamma, float *gbeta, int accumulate,
+                         void *stream);
+/* InfoNCE (loss.py:54-85) on the similarity matrix S = normalize(c) normalize(t)^T [B,B] produced by hidvae_gemm_f32:
+ * rows: loss = scale * mean_b( logsumexp_j(S_bj/tau) - S_bb/tau ), S overwritten by softmax(S/tau);
+ * dlogits: P <- (g*scale/(B*tau)) (P - I) in place, g a device scalar -- feed it to two GEMMs for d c / d t. */
+int hidvae_infonce_rows(float *S, int64_t B, float tau, float scale, float *row_loss, float *loss, void *stream);
+int hidvae_infonce_dlogits(float *P, int64_t B, float tau, float scale, const float *g_dev, void *stream);
+/* TagPredictionLoss (loss.py:107-265) with the model's layer_idx = 0 call.  target -1 = invalid row.
+ * partner[b] (NULL = no mixup): original-index row mixed into row b with weight 1-lam (loss.py:144-154); lam is a
+ * DEVICE scalar (it is drawn per step, also under graph replay).
+ * focal != 0: focal loss with label smoothing `smooth` (0 under no_grad), gamma, alpha (loss.py:230-265);
+ * focal == 0: cross entropy with label smoothing ce_label_smoothing + 0.05*KL(uniform || softmax(unmixed)+1e-8).
+ * Writes loss/acc/n_valid (device scalars); row_loss,row_hit [B] and zbuf [B,C] are scratch; dmix/dkl [B,C] (optional)
+ * hold what hidvae_tag_loss_bwd needs: g_logits = (g/n_valid)(lam*dmix[r] + (1-lam)*dmix[inverse[r]] + dkl[r]). */
+int hidvae_tag_loss_fwd(const float *logits, int64_t B, int64_t C, const int64_t *target, const int64_t *partner,
+                        const float *lam_dev,
+                        int focal, float gamma, float alpha, float smooth, float ce_label_smoothing, float *loss,
+                        float *acc, float *n_valid, float *row_loss, float *row_hit, float *zbuf, float *dmix, float *dkl,
+                        void *stream);
+int hidvae_tag_loss_bwd(const float *dmix, const float *dkl, const int64_t *target, const int64_t *inverse,
+                        const float *lam_dev,
+                        int64_t B, int64_t C, const float *g_dev, const float *n_valid, float *g_logits, void *stream);
 
 #ifdef __cplusplus
 }
