@@ -233,7 +233,9 @@ def main():
                     step_eager()
                 graphs = (g1,)
         except Exception as e:  # noqa: BLE001  report and run eagerly rather than die
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            import traceback
+            print(f"[bench] graph capture failed ({type(e).__name__}); running eagerly\n" + "".join(traceback.format_exc().splitlines(True)[-14:]),
+                  file=sys.stderr)
             graphs, use_graph = None, False
             torch.cuda.synchronize()
 

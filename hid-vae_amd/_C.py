@@ -40,7 +40,8 @@ _SIGNATURES = {
     "hidvae_binary": [_i, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "hidvae_sum_prefix_slices": [_vp, _vp, _i, _i64, _i64, _vp, _vp],
     "hidvae_layernorm_fwd": [_vp, _i64, _i64, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp],
-    "hidvae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp],
+    "hidvae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp],
+    "hidvae_layernorm_param_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _i, _vp, _vp],
     "hidvae_batchnorm_fwd": [_vp, _i64, _i64, _i64, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp],
     "hidvae_batchnorm_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp],
     "hidvae_infonce_rows": [_vp, _i64, _f, _f, _vp, _vp, _vp],
@@ -348,14 +349,22 @@ def layernorm_fwd(x, gamma, beta, eps, relu, mask, mask_scale, residual):
     return y, mean, rstd
 
 
-def layernorm_bwd(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, need_gx=True):
+def layernorm_bwd(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale):
     M, N = x.shape
-    gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if need_gx else None
+    gx = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    _check(lib().hidvae_layernorm_bwd(_p(gy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), M, N, int(relu), _p(mask),
+                                      float(mask_scale), _p(gx), _stream()), "hidvae_layernorm_bwd")
+    return gx
+
+
+def layernorm_param_grad(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale):
+    M, N = x.shape
     gg = torch.empty((N,), device=x.device, dtype=torch.float32)
     gb = torch.empty((N,), device=x.device, dtype=torch.float32)
-    _check(lib().hidvae_layernorm_bwd(_p(gy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), M, N, int(relu), _p(mask),
-                                      float(mask_scale), _p(gx), _p(gg), _p(gb), 0, _stream()), "hidvae_layernorm_bwd")
-    return gx, gg, gb
+    ws = torch.empty((2 * ((M + 127) // 128) * N,), device=x.device, dtype=torch.float32)
+    _check(lib().hidvae_layernorm_param_grad(_p(gy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), M, N, int(relu), _p(mask),
+                                             float(mask_scale), _p(gg), _p(gb), 0, _p(ws), _stream()), "hidvae_layernorm_param_grad")
+    return gg, gb
 
 
 def batchnorm_fwd(x, gamma, beta, eps, momentum, training, running_mean, running_var, relu, mask, mask_scale, num_batches=None):

@@ -117,49 +117,65 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *gy, con
     }
 }
 
-// affine gradients of LayerNorm: one workgroup per 64 columns, 4 row-lanes walk all rows, fixed combine order
-__global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const float *gy, const float *x, const float *gamma,
-                                                                   const float *beta, const float *mean, const float *rstd,
-                                                                   int64_t M, int64_t N, int relu, const float *mask, float scale,
-                                                                   float *ggamma, float *gbeta, int accumulate) {
+// affine gradients of LayerNorm, two fixed-order passes: (1) one workgroup per (64 columns x 128 rows) writes partial
+// sums, (2) the row chunks are added in ascending order.  Bit-reproducible, and parallel over rows as well as columns.
+constexpr int LN_CHUNK = 128;
+__global__ __launch_bounds__(256) void layernorm_param_partial_kernel(const float *gy, const float *x, const float *gamma,
+                                                                      const float *beta, const float *mean, const float *rstd,
+                                                                      int64_t M, int64_t N, int relu, const float *mask, float scale,
+                                                                      float *part) {
     __shared__ float red[2][4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    const int64_t m0 = (int64_t)blockIdx.y * LN_CHUNK;
     float sg = 0.0f, sb = 0.0f;
     if (n < N) {
         const float ga = gamma[n], be = beta[n];
-        for (int64_t m = rl; m < M; m += 4) {
-            const float xh = (x[m * N + n] - mean[m]) * rstd[m];
-            float g = gy[m * N + n];
-            if (mask != nullptr) g = g * (mask[m * N + n] * scale);
-            if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
-            sg += g * xh;
-            sb += g;
+#pragma unroll 4
+        for (int j = 0; j < LN_CHUNK / 4; j++) {
+            const int64_t m = m0 + rl + 4 * j;
+            if (m < M) {
+                const float xh = (x[m * N + n] - mean[m]) * rstd[m];
+                float g = gy[m * N + n];
+                if (mask != nullptr) g = g * (mask[m * N + n] * scale);
+                if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+                sg += g * xh;
+                sb += g;
+            }
         }
     }
     red[0][rl][c] = sg;
     red[1][rl][c] = sb;
     __syncthreads();
     if (rl == 0 && n < N) {
-        const float a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-        const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
-        ggamma[n] = accumulate ? ggamma[n] + a : a;
-        gbeta[n] = accumulate ? gbeta[n] + b : b;
+        part[((int64_t)blockIdx.y * 2 + 0) * N + n] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        part[((int64_t)blockIdx.y * 2 + 1) * N + n] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
     }
 }
 
+__global__ __launch_bounds__(256) void layernorm_param_final_kernel(const float *part, int64_t chunks, int64_t N, float *ggamma,
+                                                                    float *gbeta, int accumulate) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.0f, b = 0.0f;
+    for (int64_t c = 0; c < chunks; c++) { a += part[(c * 2 + 0) * N + n]; b += part[(c * 2 + 1) * N + n]; }
+    ggamma[n] = accumulate ? ggamma[n] + a : a;
+    gbeta[n] = accumulate ? gbeta[n] + b : b;
+}
+
 // ------------------------------------------------------------------------------------------------
-// BatchNorm1d (h_rqvae.py:325).  One workgroup (1024 threads = 64 columns x 16 row-lanes) per 64 columns.
+// BatchNorm1d (h_rqvae.py:325).  One workgroup (1024 threads = 32 columns x 32 row-lanes) per 32 columns.
 // training: batch mean / biased variance (two passes), running stats <- (1-mom)*old + mom*{mean, unbiased var};
 // eval: the running stats.  y = drop(relu(xhat*gamma+beta)).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float colreduce16(float v, float (*red)[64], int c, int rl) {
+constexpr int BN_COLS = 32, BN_LANES = 32;
+__device__ __forceinline__ float colreduce16(float v, float (*red)[BN_COLS], int c, int rl) {
     red[rl][c] = v;
     __syncthreads();
     float s = 0.0f;
     if (rl == 0) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) s += red[j][c];
+        for (int j = 0; j < BN_LANES; j++) s += red[j][c];
         red[0][c] = s;
     }
     __syncthreads();
@@ -173,18 +189,18 @@ __global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float *x, int
                                                              float *running_mean, float *running_var, int64_t *num_batches_tracked,
                                                              float *y, float *save_mean, float *save_rstd, int relu,
                                                              const float *mask, float scale) {
-    __shared__ float red[16][64];
+    __shared__ float red[BN_LANES][BN_COLS];
     if (training && num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    const int c = threadIdx.x & (BN_COLS - 1), rl = threadIdx.x / BN_COLS;
+    const int64_t n = (int64_t)blockIdx.x * BN_COLS + c;
     const bool ok = n < N;
     float mu, rs;
     if (training) {
         float s = 0.0f;
-        if (ok) for (int64_t m = rl; m < M; m += 16) s += x[m * ldx + n];
+        if (ok) for (int64_t m = rl; m < M; m += BN_LANES) s += x[m * ldx + n];
         mu = colreduce16(s, red, c, rl) / (float)M;
         float v = 0.0f;
-        if (ok) for (int64_t m = rl; m < M; m += 16) { const float d = x[m * ldx + n] - mu; v += d * d; }
+        if (ok) for (int64_t m = rl; m < M; m += BN_LANES) { const float d = x[m * ldx + n] - mu; v += d * d; }
         const float var = colreduce16(v, red, c, rl) / (float)M;
         rs = 1.0f / sqrtf(var + eps);
         if (ok && rl == 0) {
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float *x, int
     }
     if (!ok) return;
     const float ga = gamma != nullptr ? gamma[n] : 1.0f, be = beta != nullptr ? beta[n] : 0.0f;
-    for (int64_t m = rl; m < M; m += 16) {
+    for (int64_t m = rl; m < M; m += BN_LANES) {
         float o = (x[m * ldx + n] - mu) * rs * ga + be;
         if (relu) o = fmaxf(o, 0.0f);
         if (mask != nullptr) o = o * (mask[m * N + n] * scale);
@@ -216,15 +232,15 @@ __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float *gy, co
                                                              const float *beta, const float *save_mean, const float *save_rstd,
                                                              int64_t M, int64_t N, int relu, const float *mask, float scale,
                                                              float *gx, float *ggamma, float *gbeta, int accumulate) {
-    __shared__ float red[16][64];
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    __shared__ float red[BN_LANES][BN_COLS];
+    const int c = threadIdx.x & (BN_COLS - 1), rl = threadIdx.x / BN_COLS;
+    const int64_t n = (int64_t)blockIdx.x * BN_COLS + c;
     const bool ok = n < N;
     const float mu = ok ? save_mean[n] : 0.0f, rs = ok ? save_rstd[n] : 0.0f;
     const float ga = ok ? gamma[n] : 0.0f, be = ok ? beta[n] : 0.0f;
     float sg = 0.0f, sb = 0.0f;
     if (ok)
-        for (int64_t m = rl; m < M; m += 16) {
+        for (int64_t m = rl; m < M; m += BN_LANES) {
             const float xh = (x[m * ldx + n] - mu) * rs;
             float g = gy[m * N + n];
             if (mask != nullptr) g = g * (mask[m * N + n] * scale);
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float *gy, co
     }
     if (gx != nullptr) {
         const float k = ga * rs / (float)M;
-        for (int64_t m = rl; m < M; m += 16) {
+        for (int64_t m = rl; m < M; m += BN_LANES) {
             const float xh = (x[m * ldx + n] - mu) * rs;
             float g = gy[m * N + n];
             if (mask != nullptr) g = g * (mask[m * N + n] * scale);
@@ -532,19 +548,28 @@ extern "C" int hidvae_layernorm_fwd(const float *x, int64_t M, int64_t N, const 
 
 extern "C" int hidvae_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
                                     const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask, float keep_scale,
-                                    float *gx, float *ggamma, float *gbeta, int accumulate, void *stream) {
-    HV_REQUIRE(gy && x && gamma && beta && mean && rstd && M >= 1 && N >= 1, "layernorm_bwd: bad arguments");
+                                    float *gx, void *stream) {
+    HV_REQUIRE(gy && x && gamma && beta && mean && rstd && gx && M >= 1 && N >= 1, "layernorm_bwd: bad arguments");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, gy, x, gamma, beta, mean,
+                       rstd, M, N, relu, keep_mask, keep_scale, gx);
+    HV_LAUNCH_CHECK("layernorm_bwd");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_layernorm_param_grad(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
+                                           const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask,
+                                           float keep_scale, float *ggamma, float *gbeta, int accumulate, float *workspace,
+                                           void *stream) {
+    HV_REQUIRE(gy && x && gamma && beta && mean && rstd && ggamma && gbeta && workspace && M >= 1 && N >= 1,
+               "layernorm_param_grad: bad arguments");
+    const int64_t chunks = hv_cdiv(M, LN_CHUNK);
     hipStream_t s = (hipStream_t)stream;
-    if (gx != nullptr) {
-        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, s, gy, x, gamma, beta, mean, rstd, M, N,
-                           relu, keep_mask, keep_scale, gx);
-        HV_LAUNCH_CHECK("layernorm_bwd");
-    }
-    if (ggamma != nullptr && gbeta != nullptr) {
-        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((unsigned)hv_cdiv(N, 64)), dim3(256), 0, s, gy, x, gamma, beta, mean, rstd,
-                           M, N, relu, keep_mask, keep_scale, ggamma, gbeta, accumulate);
-        HV_LAUNCH_CHECK("layernorm_param_grad");
-    }
+    hipLaunchKernelGGL(layernorm_param_partial_kernel, dim3((unsigned)hv_cdiv(N, 64), (unsigned)chunks), dim3(256), 0, s, gy, x, gamma,
+                       beta, mean, rstd, M, N, relu, keep_mask, keep_scale, workspace);
+    HV_LAUNCH_CHECK("layernorm_param_partial");
+    hipLaunchKernelGGL(layernorm_param_final_kernel, dim3((unsigned)hv_cdiv(N, 256)), dim3(256), 0, s, workspace, chunks, N, ggamma,
+                       gbeta, accumulate);
+    HV_LAUNCH_CHECK("layernorm_param_final");
     return HIDVAE_OK;
 }
 
@@ -554,7 +579,7 @@ extern "C" int hidvae_batchnorm_fwd(const float *x, int64_t ldx, int64_t M, int6
                                     const float *keep_mask, float keep_scale, void *stream) {
     HV_REQUIRE(x && y && M >= 1 && N >= 1 && ldx >= N, "batchnorm_fwd: bad arguments");
     HV_REQUIRE(training ? (save_mean && save_rstd) : (running_mean && running_var), "batchnorm_fwd: statistics buffers missing");
-    hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3((unsigned)hv_cdiv(N, 64)), dim3(1024), 0, (hipStream_t)stream, x, ldx, M, N, gamma,
+    hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3((unsigned)hv_cdiv(N, BN_COLS)), dim3(1024), 0, (hipStream_t)stream, x, ldx, M, N, gamma,
                        beta, eps, momentum, training, running_mean, running_var, num_batches_tracked, y, save_mean, save_rstd, relu, keep_mask,
                        keep_scale);
     HV_LAUNCH_CHECK("batchnorm_fwd");
@@ -567,7 +592,7 @@ extern "C" int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx
                                     void *stream) {
     HV_REQUIRE(gy && x && gamma && beta && save_mean && save_rstd && ggamma && gbeta && M >= 1 && N >= 1 && ldx >= N,
                "batchnorm_bwd: bad arguments");
-    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((unsigned)hv_cdiv(N, 64)), dim3(1024), 0, (hipStream_t)stream, gy, x, ldx, gamma, beta,
+    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((unsigned)hv_cdiv(N, BN_COLS)), dim3(1024), 0, (hipStream_t)stream, gy, x, ldx, gamma, beta,
                        save_mean, save_rstd, M, N, relu, keep_mask, keep_scale, gx, ggamma, gbeta, accumulate);
     HV_LAUNCH_CHECK("batchnorm_bwd");
     return HIDVAE_OK;

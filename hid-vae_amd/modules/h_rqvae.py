@@ -149,8 +149,14 @@ class HRqVae(nn.Module, _HubMixin):
         return z
 
     def _rand(self):
+        if self.rand is not None:
+            return self.rand
         from ..rand import DeviceRand
-        return self.rand if self.rand is not None else DeviceRand(self.tag_prediction_loss.mixup_alpha)
+        alpha = self.tag_prediction_loss.mixup_alpha
+        r = getattr(self, "_device_rand", None)
+        if r is None or r.mixup_alpha != alpha:
+            r = self._device_rand = DeviceRand(alpha)  # kept: it caches device-side distribution objects
+        return r
 
     def load_pretrained(self, path: str) -> None:
         """Checkpoint loader tolerant of tag-head shape drift (reference h_rqvae.py:382-471)."""

@@ -239,7 +239,7 @@ class LinearFn(Function):
         pre = None
         if need and act in (_C.EPI_SILU, _C.EPI_GELU):
             pre = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32)
-        y = _C.gemm(_C.GEMM_NT, x, w, bias=b, epilogue=act, aux=pre, mask=keep_mask, mask_scale=keep_scale)
+        y = _C.gemm(_C.GEMM_NT, x, w, bias=b, epilogue=act, aux=pre, mask=keep_mask, mask_scale=keep_scale, split_k=0)
         ctx.act, ctx.keep_scale = act, keep_scale
         ctx.has_bias = b is not None
         ctx.need_x = ctx.needs_input_grad[0]
@@ -254,7 +254,15 @@ class LinearFn(Function):
         g = g.contiguous()
         if ctx.act != _C.EPI_NONE or keep_mask is not None:
             g = _C.act_bwd(g, ref, ctx.act, keep_mask, ctx.keep_scale)
-        gw = _C.gemm(_C.GEMM_TN, g, x, split_k=_weight_grad_split(w.shape[0], w.shape[1], g.shape[0]))
-        gb = _C.colsum(g) if ctx.has_bias else None
+        main, side = torch.cuda.current_stream(), side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):  # parameter gradients beside the input-gradient chain
+            gw = _C.gemm(_C.GEMM_TN, g, x, split_k=0)
+            gb = _C.colsum(g) if ctx.has_bias else None
+        gw.record_stream(main)
+        if gb is not None:
+            gb.record_stream(main)
+        g.record_stream(side)
+        _join_after_backward()
         gx = _C.gemm(_C.GEMM_NN, g, w, split_k=0) if ctx.need_x else None
         return gx, gw, gb, None, None, None

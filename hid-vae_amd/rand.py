@@ -29,7 +29,7 @@ class DeviceRand:
         partner = torch.where(valid, order[rank.clamp(min=0)], torch.full_like(rank, -1))
         inv_ext = torch.full((B + 1,), -1, dtype=torch.int64, device=device)
         inv_ext.scatter_(0, torch.where(valid, partner, torch.full_like(partner, B)), torch.arange(B, device=device))
-        if self._beta is None or self._beta.concentration0.device != device:
+        if self._beta is None:  # built once (a host->device scalar copy is not allowed inside a graph capture)
             a = torch.tensor(self.mixup_alpha, device=device)
             self._beta = torch.distributions.Beta(a, a)
         return partner, inv_ext[:B].contiguous(), self._beta.sample().to(torch.float32)

@@ -12,7 +12,7 @@ from torch import nn
 from torch.autograd import Function
 
 from . import _C
-from .ops import L2NormFn, LinearFn
+from .ops import L2NormFn, LinearFn, _join_after_backward, side_stream
 
 
 def _keep_scale(p):
@@ -82,7 +82,15 @@ class LayerNormFn(Function):
         x, gamma, beta, mean, rstd, mask = ctx.saved_tensors
         relu, mask_scale, has_res = ctx.cfg
         gy = gy.contiguous()
-        gx, gg, gb = _C.layernorm_bwd(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, need_gx=ctx.needs_input_grad[0])
+        main, side = torch.cuda.current_stream(), side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):  # the affine gradients are off the critical path
+            gg, gb = _C.layernorm_param_grad(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale)
+        for t in (gg, gb):
+            t.record_stream(main)
+        gy.record_stream(side)
+        _join_after_backward()
+        gx = _C.layernorm_bwd(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale) if ctx.needs_input_grad[0] else None
         return gx, gg, gb, None, None, None, None, (gy if has_res else None)
 
 

@@ -190,13 +190,19 @@ int hidvae_binary(int op, const float *a, int64_t lda, const float *b, int64_t l
 int hidvae_sum_prefix_slices(const float *const *src_host, const int32_t *width_host, int n, int64_t M, int64_t N,
                              float *dst, void *stream);
 /* y = dropout(relu?(LayerNorm(x))) + residual   (nn.LayerNorm eps; h_rqvae.py:145,156,162,181,329) and its backward:
- * gx (may be NULL), ggamma/gbeta (may both be NULL).  The residual's gradient is gy itself. */
+ * gx.  The residual's gradient is gy itself. */
 int hidvae_layernorm_fwd(const float *x, int64_t M, int64_t N, const float *gamma, const float *beta, float eps, float *y,
                          float *mean, float *rstd, int relu, const float *keep_mask, float keep_scale,
                          const float *residual, void *stream);
 int hidvae_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
                          const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask, float keep_scale,
-                         float *gx, float *ggamma, float *gbeta, int accumulate, void *stream);
+                         float *gx, void *stream);
+/* affine gradients (ggamma, gbeta) of the same op, fixed-order two-pass; workspace >= 2*ceil(M/128)*N floats.
+ * Independent of hidvae_layernorm_bwd, so it can run on another stream. */
+int hidvae_layernorm_param_grad(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
+                                const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask,
+                                float keep_scale, float *ggamma, float *gbeta, int accumulate, float *workspace,
+                                void *stream);
 /* BatchNorm1d (h_rqvae.py:325): y = dropout(relu?(BN(x))).  training != 0: batch statistics (biased variance for the
  * normalisation, unbiased for the running update with `momentum`), saved mean / rstd for the backward;
  * training == 0: running statistics.  num_batches_tracked (optional int64 device scalar) is incremented in training. */
