@@ -47,14 +47,16 @@ class HidvaeAdamW(torch.optim.Optimizer):
         total = sum(p.numel() for p in ps)
         self._m = torch.zeros(total, device=dev)
         self._v = torch.zeros(total, device=dev)
-        self.flat_grad = torch.zeros(total, device=dev) if self.flat_grads else None
-        off, mptr, vptr, self.grad_views = 0, [], [], []
+        self.grad_buffer = None
+        if self.flat_grads:
+            from .parallel import FlatGradBuffer
+            self.grad_buffer = FlatGradBuffer(ps)
+        self.flat_grad = self.grad_buffer.flat if self.grad_buffer is not None else None
+        off, mptr, vptr = 0, [], []
         for p in ps:
             n = p.numel()
             mptr.append(self._m[off:off + n].data_ptr())
             vptr.append(self._v[off:off + n].data_ptr())
-            if self.flat_grads:
-                self.grad_views.append(self.flat_grad[off:off + n].view_as(p))
             off += n
         i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)
         self._desc = dict(p=i64([p.data_ptr() for p in ps]), g_host=None, m=i64(mptr),
@@ -64,12 +66,6 @@ class HidvaeAdamW(torch.optim.Optimizer):
         self.step_dev = torch.tensor([self._start_step], dtype=torch.int64, device=dev)
         self._desc["hyper"] = torch.zeros(3 * len(ps), dtype=torch.float32, device=dev)
         self._prepared = False
-        if self.flat_grads:
-            self._bind_flat()
-
-    def _bind_flat(self):
-        for p, gv in zip(self._params, self.grad_views):
-            p.grad = gv
 
     def prepare(self):
         if self._desc is None:
@@ -90,8 +86,7 @@ class HidvaeAdamW(torch.optim.Optimizer):
         if not self._prepared:
             self._prepare_step_async()
         if self.flat_grads:
-            self.flat_grad.zero_()
-            self._bind_flat()
+            self.grad_buffer.zero()
         else:
             for p in self._params:
                 p.grad = None
