@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Launch the kernels quoted in bench.py's `roofline`/`kernels` a few times each, for rocprofv3 passes:
+    rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python3 tools/profile_kernels.py
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE  --output-format csv -d OUT -- python3 tools/profile_kernels.py
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE  --output-format csv -d OUT -- python3 tools/profile_kernels.py
+(counters in their own passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import hidvae_amd  # noqa: E402,F401
+from hidvae_amd import _C  # noqa: E402
+
+dev = torch.device("cuda")
+torch.manual_seed(0)
+B, L, K = 1024, 3, 256
+x = torch.randn(B, 768, device=dev)
+w0 = torch.randn(512, 768, device=dev) * 0.03
+o0, a0 = torch.empty(B, 512, device=dev), torch.empty(B, 512, device=dev)
+g = torch.randn(B, 512, device=dev)
+gw = torch.empty(512, 768, device=dev)
+tabs = [(torch.rand(K, 32, device=dev) * 2 - 1) * (1.0 if i == 0 else 0.35 * 0.5 ** i) for i in range(L)]
+cb, cc = _C.codebook_prepare(tabs, [i == 0 for i in range(L)])
+y_small = torch.randn(B, 32, device=dev)
+y_big = torch.randn(1 << 20, 32, device=dev)
+for _ in range(10):
+    _C.gemm(_C.GEMM_NT, x, w0, out=o0, epilogue=_C.EPI_SILU, aux=a0)
+    _C.gemm(_C.GEMM_TN, g, x, out=gw, split_k=0)
+    _C.rq_forward(y_small, cb, cc, True, 3, True, 0.4)
+for _ in range(5):
+    _C.rq_forward(y_big, cb, cc, True, 3, True, 0.4)
+torch.cuda.synchronize()
+print("done")
