@@ -48,6 +48,7 @@ _SIGNATURES = {
     "hidvae_infonce_dlogits": [_vp, _i64, _f, _f, _vp, _vp],
     "hidvae_tag_loss_fwd": [_vp, _i64, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
+    "hidvae_kmeans_iter": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
 }
@@ -421,3 +422,8 @@ def tag_loss_bwd(dmix, dkl, target, inverse, lam, g, n_valid):
     _check(lib().hidvae_tag_loss_bwd(_p(dmix), _p(dkl), _p(target), _p(inverse), _p(lam), B, C, _p(g), _p(n_valid), _p(out), _stream()),
            "hidvae_tag_loss_bwd")
     return out
+
+
+def kmeans_iter(x, centroids, assign, reseed_idx, new_centroids, shift_scratch, shift):
+    _check(lib().hidvae_kmeans_iter(_p(x), x.shape[0], _p(centroids), centroids.shape[0], _p(assign), _p(reseed_idx), _p(new_centroids),
+                                    _p(shift_scratch), _p(shift), _stream()), "hidvae_kmeans_iter")

@@ -235,6 +235,13 @@ int hidvae_tag_loss_bwd(const float *dmix, const float *dkl, const int64_t *targ
                         const float *lam_dev,
                         int64_t B, int64_t C, const float *g_dev, const float *n_valid, float *g_logits, void *stream);
 
+/* ---- a15: one Lloyd iteration of the first-batch k-means codebook init (init/kmeans.py:34-77; quantize.py:91-95), D = 32:
+ * assign[i] = argmin_k sum_d (x_id - c_kd)^2 (first minimum), new_centroids[k] = mean of its items (ascending item order;
+ * an empty cluster takes x[reseed_idx[k]]), *shift = max_k |new_k - old_k|_2 (the reference stops below 1e-10).
+ * shift_scratch: K floats. */
+int hidvae_kmeans_iter(const float *x, int64_t N, const float *centroids, int64_t K, int32_t *assign,
+                       const int64_t *reseed_idx, float *new_centroids, float *shift_scratch, float *shift, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,3 +196,24 @@ def test_id_stats(C):
     assert abs(float(pu) - float(O.p_unique_fast(ids.cpu()))) < 1e-7
     assert abs(float(O.p_unique(ids.cpu()[:600])) - float(C.id_stats(emb[:600], ids[:600])[1])) < 1e-7
     assert H.rel_err(norms.cpu().numpy(), emb.cpu().reshape(5000, 3, 32).norm(dim=-1).numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("name", H.case_names("kmeans"))
+def test_kmeans_matches_reference_golden(C, name):
+    """Lloyd to convergence from the same seeding the reference was given (init/kmeans.py:34-77)."""
+    from hidvae_amd.init.kmeans import Kmeans
+    fx, desc = H.load(name)
+    x = torch.from_numpy(fill.gauss((desc["N"], desc["D"]), desc["seed"])).cuda()
+    init = fill.perm(desc["N"], desc["seed"] + 1)[: desc["K"]]
+    out = Kmeans(k=desc["K"], init_indices=init).run(x)
+    assert H.rel_err(out.centroids.cpu().numpy(), fx["centroids"]) <= 1e-5
+    agree = (out.assignment.cpu().numpy() == fx["assignment"]).mean()
+    assert agree == 1.0, f"assignment agreement {agree}"
+    # a fixed point: one more iteration changes nothing
+    again = Kmeans(k=desc["K"], init_indices=init, max_iters=1)
+    again.init_indices = None
+    c = out.centroids.clone()
+    a2 = torch.empty(desc["N"], dtype=torch.int32, device="cuda")
+    nxt, sc, sh = torch.empty_like(c), torch.empty(desc["K"], device="cuda"), torch.empty((), device="cuda")
+    C.kmeans_iter(x, c, a2, torch.zeros(desc["K"], dtype=torch.int64, device="cuda"), nxt, sc, sh)
+    assert float(sh) == 0.0
