@@ -111,6 +111,19 @@ class HidvaeAdamW(torch.optim.Optimizer):
         _C.adamw_step(self._desc, self.betas[0], self.betas[1], self.eps, self.grad_scale)
         self._prepared = False
 
+    def flat_state(self):
+        """Checkpoint payload (goes under the reference's "optimizer" key): moments, step, hyper-parameters."""
+        self.prepare()
+        return {"hidvae_m": self._m.detach().cpu(), "hidvae_v": self._v.detach().cpu(), "step": int(self.step_dev[0].item()),
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                "cosine": (self.T_max, self.eta_min)}
+
+    def load_flat_state(self, state):
+        self.prepare()
+        self._m.copy_(state["hidvae_m"].to(self._m.device))
+        self._v.copy_(state["hidvae_v"].to(self._v.device))
+        self.step_dev.fill_(int(state["step"]))
+
     def current_lr(self, group=0):
         t = int(self.step_dev[0].item())
         base = self.param_groups[group]["lr"]

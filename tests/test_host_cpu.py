@@ -1,0 +1,93 @@
+"""CPU: host-side logic that needs no kernel -- the gin subset parser, the rare-tag remap, package plumbing."""
+import os
+
+import pytest
+import torch
+
+import hidvae_amd  # noqa: F401
+from hidvae_amd import gin_compat as gin
+
+CONFIG = '''
+import data.tags_processed
+import modules.quantize
+
+# comment line
+train.iterations=400000
+train.learning_rate=0.00028
+train.batch_size=128
+train.vae_hidden_dims=[512, 256, 128]
+train.vae_codebook_normalize=True
+train.dataset=%data.tags_processed.RecDataset.AMAZON
+train.save_dir_root="out/hrqvae/amazon/"
+train.vae_codebook_mode=%modules.quantize.QuantizeForwardMode.ROTATION_TRICK
+train.tag_class_counts=[38, 168, 348]   # trailing comment
+train.lr_scheduler_type='cosine'
+train.lr_scheduler_eta_min=7e-8
+'''
+
+
+def test_gin_subset_parser_binds_train_arguments():
+    from hidvae_amd.data.items import RecDataset
+    from hidvae_amd.modules.quantize import QuantizeForwardMode
+    gin.clear_config()
+    gin.parse_config(CONFIG, import_aliases={"data.tags_processed": "hidvae_amd.data.items", "modules.quantize": "hidvae_amd.modules.quantize"})
+    b = gin.bindings("train")
+    assert b["iterations"] == 400000 and b["learning_rate"] == 0.00028 and b["batch_size"] == 128
+    assert b["vae_hidden_dims"] == [512, 256, 128] and b["vae_codebook_normalize"] is True
+    assert b["vae_codebook_mode"] is QuantizeForwardMode.ROTATION_TRICK and b["dataset"] is RecDataset.AMAZON
+    assert b["tag_class_counts"] == [38, 168, 348] and b["lr_scheduler_type"] == "cosine" and b["lr_scheduler_eta_min"] == 7e-8
+    assert b["save_dir_root"] == "out/hrqvae/amazon/"
+
+    @gin.configurable
+    def train(iterations=1, batch_size=2, **kw):
+        return iterations, batch_size, kw
+
+    with pytest.raises(TypeError):
+        train()  # unknown bound names are rejected, like gin
+    gin.clear_config()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/configs"), reason="reference configs only exist in the build container")
+@pytest.mark.parametrize("cfg", ["h_rqvae_amazon.gin", "h_rqvae_kuairand.gin"])
+def test_reference_gin_files_parse(cfg):
+    """Every binding of the two tokenizer configs is accepted and names an argument of train()."""
+    import inspect
+    from hidvae_amd.train_hidvae import train
+    gin.clear_config()
+    gin.parse_config_file(os.path.join("/root/reference/configs", cfg),
+                          import_aliases={"data.tags_processed": "hidvae_amd.data.items", "modules.quantize": "hidvae_amd.modules.quantize"})
+    b = gin.bindings("train")
+    params = set(inspect.signature(train.__wrapped__).parameters)
+    assert b and set(b) <= params, set(b) - params
+    assert b["vae_codebook_mode"].name == "ROTATION_TRICK" and b["vae_n_layers"] == 3 and b["vae_embed_dim"] == 32
+    gin.clear_config()
+
+
+def test_rare_tag_remap_matches_literal_restatement():
+    from hidvae_amd.train_hidvae import remap_rare_tags
+    g = torch.Generator().manual_seed(0)
+    ti = torch.stack([torch.randint(0, c, (4000,), generator=g) for c in (12, 40)], dim=1)
+    ti[torch.rand(ti.shape, generator=g) < 0.1] = -1
+    ti[:, 1][ti[:, 1] > 30] = -1  # classes 31..39 never occur
+    ev = ti[:500].clone()
+    want_tr, want_ev = ti.clone(), ev.clone()
+    new_counts = []
+    for i, C in enumerate((12, 40)):  # reference train_hidvae.py:366-455, written out literally
+        col = ti[:, i]
+        counts = torch.zeros(C, dtype=torch.long)
+        u, c = torch.unique(col[col >= 0], return_counts=True)
+        counts[u] = c
+        rare = torch.nonzero((counts > 0) & (counts < 110)).squeeze(-1)
+        new_counts.append(int(((counts >= 110) | (counts == 0)).sum()) + 1)
+        keep = torch.ones(C, dtype=torch.bool)
+        keep[rare] = False
+        mapping = torch.arange(C)
+        mapping[keep] = (torch.cumsum(keep, 0) - 1)[keep]
+        mapping[rare] = new_counts[-1] - 1
+        for w in (want_tr, want_ev):
+            ok = w[:, i] >= 0
+            w[ok, i] = mapping[w[ok, i]]
+    tr, evc = ti.clone(), ev.clone()
+    got_counts, rare_ids, _ = remap_rare_tags(tr, evc, [12, 40], 2, 110)
+    assert got_counts == new_counts
+    assert torch.equal(tr, want_tr) and torch.equal(evc, want_ev)
