@@ -69,6 +69,7 @@ def mlp_body_backward(saved, weights, g_y, need_input_grad):
         inp, _ = saved[j]
         w = weights[j]
         keep.append(g)
+        keep.append(inp)  # saved activations die with the autograd node: the helper stream must be done with them first
         side.wait_stream(main)
         with torch.cuda.stream(side):
             grads[j] = _C.gemm(_C.GEMM_TN, g, inp, split_k=0)
@@ -263,6 +264,7 @@ class LinearFn(Function):
         if gb is not None:
             gb.record_stream(main)
         g.record_stream(side)
+        x.record_stream(side)  # a saved tensor that may be freed as soon as this node returns
         _join_after_backward()
         gx = _C.gemm(_C.GEMM_NN, g, w, split_k=0) if ctx.need_x else None
         return gx, gw, gb, None, None, None

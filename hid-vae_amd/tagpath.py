@@ -88,7 +88,9 @@ class LayerNormFn(Function):
             gg, gb = _C.layernorm_param_grad(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale)
         for t in (gg, gb):
             t.record_stream(main)
-        gy.record_stream(side)
+        for t in (gy, x, mean, rstd, mask):  # read by the helper stream; saved tensors die when this node returns
+            if t is not None:
+                t.record_stream(side)
         _join_after_backward()
         gx = _C.layernorm_bwd(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale) if ctx.needs_input_grad[0] else None
         return gx, gg, gb, None, None, None, None, (gy if has_res else None)

@@ -91,3 +91,17 @@ def test_rare_tag_remap_matches_literal_restatement():
     got_counts, rare_ids, _ = remap_rare_tags(tr, evc, [12, 40], 2, 110)
     assert got_counts == new_counts
     assert torch.equal(tr, want_tr) and torch.equal(evc, want_ev)
+
+
+def test_install_dropin_aliases_reference_module_names():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import hidvae_amd; hidvae_amd.install_dropin(); "
+            "from modules.h_rqvae import HRqVae; from modules.quantize import QuantizeForwardMode, Quantize; "
+            "from data.schemas import HRqVaeComputedLosses, TaggedSeqBatch; from modules.tokenizer.h_semids import HSemanticIdTokenizer; "
+            "from init.kmeans import kmeans_init_; "
+            "assert HRqVae.__module__ == 'hidvae_amd.modules.h_rqvae' and QuantizeForwardMode.ROTATION_TRICK.value == 3; "
+            "assert HRqVaeComputedLosses._fields[0] == 'loss' and len(HRqVaeComputedLosses._fields) == 12; print('ok')"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
