@@ -4,7 +4,7 @@
 //
 // v_mfma_f32_32x32x2_f32: per lane ONE A value (row = lane&31, k = lane>>5) and ONE B value, 16 accumulator
 // registers; the result is a k-ordered fmaf chain, so with split_k == 1 an output element is bit-identical to the
-// fmaf chain oracle/exact.c runs (ORDER-G: 16-wide k-blocks ascending, inside a block k = 0,8,1,9,...,7,15).
+// fmaf chain oracle/exact.c runs (ORDER-G16: 16-wide k-blocks ascending, inside a block k = 0,4,8,12,1,5,9,13,...).
 //
 // Workgroup tile (32*WM) x (32*WN), one 32x32 accumulator per wave, BK = 16.  Both operand tiles live in LDS
 // k-major (As[k][m], Bs[k][n]) so a fragment read is 32 consecutive floats per half-wave (conflict-free
@@ -161,8 +161,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
         const float *ap = As[buf] + wm * 32 + i32, *bp = Bs[buf] + wn * 32 + i32;
 #pragma unroll
         for (int s = 0; s < BK / 2; s++) {
-            const float a = ap[(8 * h + s) * LDA];  // ORDER-G: lane half h supplies k = 8h + s at step s
-            const float b = bp[(8 * h + s) * LDB];
+            const int kk = (s >> 1) + 8 * (s & 1) + 4 * h;  // ORDER-G16 (see kmap32)
+            const float a = ap[kk * LDA];
+            const float b = bp[kk * LDB];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         if (more) {
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *partial,
 // 32x32 output tile, operands loaded from global memory STRAIGHT into the MFMA operand registers (no LDS, no
 // barriers), a 3-deep register ring of 16-wide k-blocks so two blocks of loads are always in flight, and an
 // optional in-workgroup split of K over SPLIT waves reduced through LDS in fixed order (backward GEMMs only).
-// k-order inside a 16-block: lane half h supplies k = 8h + s at MFMA step s, i.e. the chain visits
-// 0,8,1,9,...,7,15 -- that is ORDER-G of oracle/exact.c, so SPLIT == 1 stays bit-exact against the oracle.
+// k-order inside a 16-block: ORDER-G16 of oracle/exact.c (0,4,8,12,1,5,...), identical in all three kernels of this file,
+// so SPLIT == 1 stays bit-exact against the oracle whichever tile form the dispatcher picks.
 // ------------------------------------------------------------------------------------------------
 // Operands are read with raw BUFFER loads: 128-bit resource (scalar) + 32-bit lane byte offset + scalar k offset, so
 // addressing costs one VGPR per operand, rows need only dword alignment for the 16-byte form, and anything past the
@@ -256,16 +257,20 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *partial,
 // `voff`: lane byte offset (row*ld + 8h for k-contiguous operands, 8h*ld + row otherwise, times 4).
 constexpr int HV_OOB = 0x7FFFFFF0;
 
+// k visited by MFMA step j on lane half h of the 32x32x2 form: the chain order inside a 16-block is ORDER-G16 =
+// 0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15 (what the 16x16x4 form does natively: step s, lane quarter q -> k = 4q + s)
+__device__ __forceinline__ int kmap32(int j, int h) { return (j >> 1) + 8 * (j & 1) + 4 * h; }
+
 template <bool KCONTIG>
 __device__ __forceinline__ void load_block(__amdgpu_buffer_rsrc_t rsrc, int ld4, int voff, int k0, float (&v)[8]) {
-    if (KCONTIG) {
+    if (KCONTIG) {  // voff already carries +4h floats: x = k0+4h.., y = k0+8+4h..
         const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, k0 * 4, 0));
-        const f32x4 y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, k0 * 4 + 16, 0));
-        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; v[4] = y[0]; v[5] = y[1]; v[6] = y[2]; v[7] = y[3];
-    } else {
+        const f32x4 y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, k0 * 4 + 32, 0));
+        v[0] = x[0]; v[1] = y[0]; v[2] = x[1]; v[3] = y[1]; v[4] = x[2]; v[5] = y[2]; v[6] = x[3]; v[7] = y[3];
+    } else {        // voff carries +4h rows
 #pragma unroll
-        for (int s = 0; s < 8; s++)
-            v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (k0 + s) * ld4, 0));
+        for (int j = 0; j < 8; j++)
+            v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (k0 + (j >> 1) + 8 * (j & 1)) * ld4, 0));
     }
 }
 
@@ -273,28 +278,148 @@ __device__ __forceinline__ void load_block(__amdgpu_buffer_rsrc_t rsrc, int ld4,
 template <bool KCONTIG>
 __device__ __forceinline__ void load_tail(__amdgpu_buffer_rsrc_t rsrc, int ld4, int voff, int k0, int kend, int h, float (&v)[8]) {
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
-        const bool ok = k0 + 8 * h + s < kend;
+    for (int j = 0; j < 8; j++) {
+        const int kk = (j >> 1) + 8 * (j & 1);  // + 4h is inside voff
+        const bool ok = k0 + kk + 4 * h < kend;
+        if (KCONTIG) v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? voff + 4 * kk : HV_OOB, k0 * 4, 0));
+        else v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? voff : HV_OOB, (k0 + kk) * ld4, 0));
+    }
+}
+
+// ---- 16x16 tiles (v_mfma_f32_16x16x4_f32): lane = (i = lane&15, q = lane>>4) supplies k = k0 + 4q + s at step s.
+// Four times as many waves as the 32x32 form for the same problem and a 40-cycle dependent chain per 4 k instead of 64 per
+// 2 k: this is the latency-optimised form the small-batch GEMMs of the step use.
+template <bool KCONTIG>
+__device__ __forceinline__ void load_block16(__amdgpu_buffer_rsrc_t rsrc, int ld4, int voff, int k0, float (&v)[4]) {
+    if (KCONTIG) {
+        const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, k0 * 4, 0));
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (k0 + s) * ld4, 0));
+    }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void load_tail16(__amdgpu_buffer_rsrc_t rsrc, int ld4, int voff, int k0, int kend, int q, float (&v)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const bool ok = k0 + 4 * q + s < kend;
         if (KCONTIG) v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? voff + 4 * s : HV_OOB, k0 * 4, 0));
         else v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? voff : HV_OOB, (k0 + s) * ld4, 0));
     }
 }
 
 template <int LAYOUT, int SPLIT, int NS>
-__global__ __launch_bounds__(64 * SPLIT) void gemm_direct_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * SPLIT) void gemm_direct16_kernel(GemmArgs g) {
     constexpr bool A_KC = (LAYOUT != HIDVAE_GEMM_TN);
     constexpr bool B_KC = (LAYOUT == HIDVAE_GEMM_NT);
+    __shared__ float part[SPLIT > 1 ? SPLIT * 256 : 1];
+    const int lane = threadIdx.x & 63;
+    const int w = SPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.y * 16, n0 = (int64_t)blockIdx.x * 16;
+    const int64_t ra = (m0 + i16 < g.M) ? m0 + i16 : g.M - 1;
+    const int64_t rb = (n0 + i16 < g.N) ? n0 + i16 : g.N - 1;
+    const int va = 4 * (A_KC ? (int)(ra * g.lda) + 4 * q : (int)(4 * q * g.lda + ra));
+    const int vb = 4 * (B_KC ? (int)(rb * g.ldb) + 4 * q : (int)(4 * q * g.ldb + rb));
+    const int lda4 = (int)g.lda * 4, ldb4 = (int)g.ldb * 4, Ki = (int)g.K;
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.A), 0, (int)(4 * (A_KC ? (g.M - 1) * g.lda + g.K : (g.K - 1) * g.lda + g.M)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.B), 0, (int)(4 * (B_KC ? (g.N - 1) * g.ldb + g.K : (g.K - 1) * g.ldb + g.N)), 0x00020000);
+    const int nfull = Ki / 16;
+    const int b_lo = nfull * w / SPLIT, b_hi = nfull * (w + 1) / SPLIT;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float ra_[NS][4], rb_[NS][4];
+    auto load = [&](float (&av)[4], float (&bv)[4], int blk) {
+        const bool in = blk < b_hi;
+        load_block16<A_KC>(ra_rsrc, lda4, in ? va : HV_OOB, blk * 16, av);
+        load_block16<B_KC>(rb_rsrc, ldb4, in ? vb : HV_OOB, blk * 16, bv);
+    };
+#pragma unroll
+    for (int st = 0; st < NS - 1; st++) load(ra_[st], rb_[st], b_lo + st);
+    for (int blk = b_lo; blk < b_hi; blk += NS) {
+#pragma unroll
+        for (int st = 0; st < NS; st++) {
+            load(ra_[(st + NS - 1) % NS], rb_[(st + NS - 1) % NS], blk + st + NS - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra_[st][s4], rb_[st][s4], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (w == SPLIT - 1 && nfull * 16 < Ki) {
+        load_tail16<A_KC>(ra_rsrc, lda4, va, nfull * 16, Ki, q, ra_[0]);
+        load_tail16<B_KC>(rb_rsrc, ldb4, vb, nfull * 16, Ki, q, rb_[0]);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra_[0][s4], rb_[0][s4], acc, 0, 0, 0);
+    }
+    const float *mk = g.mask;
+    // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+    if (SPLIT == 1) {
+        const int64_t col = n0 + i16;
+        if (col >= g.N) return;
+        const float bias = g.bias != nullptr ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t row = m0 + 4 * q + r;
+            if (row >= g.M) continue;
+            float v = acc[r] + bias;
+            if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            float *dst = g.C + row * g.ldc + col;
+            *dst = g.accumulate ? *dst + v : v;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[w * 256 + (4 * q + r) * 16 + i16] = acc[r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 256; e += 64 * SPLIT) {
+            float v = part[e];
+#pragma unroll
+            for (int sidx = 1; sidx < SPLIT; sidx++) v += part[sidx * 256 + e];  // fixed order: bit-reproducible
+            const int64_t row = m0 + (e >> 4), col = n0 + (e & 15);
+            if (row >= g.M || col >= g.N) continue;
+            v += g.bias != nullptr ? g.bias[col] : 0.0f;
+            if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            float *dst = g.C + row * g.ldc + col;
+            *dst = g.accumulate ? *dst + v : v;
+        }
+    }
+}
+
+template <int SPLIT, int NS>
+void launch_direct16(int layout, const GemmArgs &g, hipStream_t s) {
+    dim3 grid((unsigned)hv_cdiv(g.N, 16), (unsigned)hv_cdiv(g.M, 16));
+    dim3 block(64 * SPLIT);
+    if (layout == HIDVAE_GEMM_NT) hipLaunchKernelGGL((gemm_direct16_kernel<HIDVAE_GEMM_NT, SPLIT, NS>), grid, block, 0, s, g);
+    else if (layout == HIDVAE_GEMM_NN) hipLaunchKernelGGL((gemm_direct16_kernel<HIDVAE_GEMM_NN, SPLIT, NS>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_direct16_kernel<HIDVAE_GEMM_TN, SPLIT, NS>), grid, block, 0, s, g);
+}
+
+// NWN > 1 (only with SPLIT == 1): the workgroup's NWN waves take NWN neighbouring column tiles of the SAME row tile, so the
+// A rows they all read are fetched into the CU's L1 once instead of NWN times.
+template <int LAYOUT, int SPLIT, int NS, int NWN = 1>
+__global__ __launch_bounds__(64 * SPLIT * NWN) void gemm_direct_kernel(GemmArgs g) {
+    constexpr bool A_KC = (LAYOUT != HIDVAE_GEMM_TN);
+    constexpr bool B_KC = (LAYOUT == HIDVAE_GEMM_NT);
+    static_assert(SPLIT == 1 || NWN == 1, "column-tile sharing is for the unsplit kernel");
     __shared__ float part[SPLIT > 1 ? SPLIT * 1024 : 1];
     const int lane = threadIdx.x & 63;
     // wave index as a SCALAR: the k offsets derived from it feed the buffer loads' soffset operand, which must be
     // provably uniform or the compiler wraps every load in a waterfall loop
     const int w = SPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i32 = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+    const int wn = NWN == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = ((int64_t)blockIdx.x * NWN + wn) * 32;
+    if (NWN > 1 && n0 >= g.N) return;  // (no barrier follows in the unsplit kernel)
     const int64_t ra = (m0 + i32 < g.M) ? m0 + i32 : g.M - 1;
     const int64_t rb = (n0 + i32 < g.N) ? n0 + i32 : g.N - 1;
-    const int va = 4 * (A_KC ? (int)(ra * g.lda) + 8 * h : (int)(8 * h * g.lda + ra));
-    const int vb = 4 * (B_KC ? (int)(rb * g.ldb) + 8 * h : (int)(8 * h * g.ldb + rb));
+    const int va = 4 * (A_KC ? (int)(ra * g.lda) + 4 * h : (int)(4 * h * g.lda + ra));  // ORDER-G16: lane half h starts at k0+4h
+    const int vb = 4 * (B_KC ? (int)(rb * g.ldb) + 4 * h : (int)(4 * h * g.ldb + rb));
     const int lda4 = (int)g.lda * 4, ldb4 = (int)g.ldb * 4, Ki = (int)g.K;
     // logical extent of each operand in bytes (works for column-slice views too)
     const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -318,9 +443,14 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_direct_kernel(GemmArgs g) {
     for (int blk = b_lo; blk < b_hi; blk += NS) {
 #pragma unroll
         for (int st = 0; st < NS; st++) {
+            // keep THIS order in the instruction stream: issue block (blk+st+NS-1)'s loads, then the MFMAs of block blk+st.
+            // Left to itself hipcc sinks all loads of an iteration behind its MFMAs and waits vmcnt(0) at the loop top,
+            // which serialises load latency and compute (seen in the .s: 2.3x the chain bound).
             load(ra_[(st + NS - 1) % NS], rb_[(st + NS - 1) % NS], blk + st + NS - 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[st][s8], rb_[st][s8], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (w == SPLIT - 1 && nfull * 16 < Ki) {
@@ -365,13 +495,13 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_direct_kernel(GemmArgs g) {
     }
 }
 
-template <int SPLIT, int NS>
+template <int SPLIT, int NS, int NWN = 1>
 void launch_direct(int layout, const GemmArgs &g, hipStream_t s) {
-    dim3 grid((unsigned)hv_cdiv(g.N, 32), (unsigned)hv_cdiv(g.M, 32));
-    dim3 block(64 * SPLIT);
-    if (layout == HIDVAE_GEMM_NT) hipLaunchKernelGGL((gemm_direct_kernel<HIDVAE_GEMM_NT, SPLIT, NS>), grid, block, 0, s, g);
-    else if (layout == HIDVAE_GEMM_NN) hipLaunchKernelGGL((gemm_direct_kernel<HIDVAE_GEMM_NN, SPLIT, NS>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_direct_kernel<HIDVAE_GEMM_TN, SPLIT, NS>), grid, block, 0, s, g);
+    dim3 grid((unsigned)hv_cdiv(hv_cdiv(g.N, 32), NWN), (unsigned)hv_cdiv(g.M, 32));
+    dim3 block(64 * SPLIT * NWN);
+    if (layout == HIDVAE_GEMM_NT) hipLaunchKernelGGL((gemm_direct_kernel<HIDVAE_GEMM_NT, SPLIT, NS, NWN>), grid, block, 0, s, g);
+    else if (layout == HIDVAE_GEMM_NN) hipLaunchKernelGGL((gemm_direct_kernel<HIDVAE_GEMM_NN, SPLIT, NS, NWN>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_direct_kernel<HIDVAE_GEMM_TN, SPLIT, NS, NWN>), grid, block, 0, s, g);
 }
 
 template <int WM, int WN>
@@ -415,6 +545,25 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
         if (!big) {
             // direct path.  split_k == 1: one wave per tile, sequential (ORDER-G) chain; otherwise spread K over up to 16
             // waves of the workgroup until the chip has ~2 waves per SIMD or the chunks get shorter than 32
+            // few tiles: 16x16 tiles (4x the waves, shorter dependent MFMA chains) -- the latency-optimised form
+            if (tiles32 <= 256 || (tiles32 <= 512 && K <= 256)) {
+                const int64_t tiles16 = hv_cdiv(M, 16) * hv_cdiv(N, 16);
+                int sp16 = 1;
+                if (split_k != 1) {
+                    const int cap = split_k == 0 ? 16 : split_k;
+                    while (sp16 < cap && sp16 < 16 && tiles16 * sp16 < 4096 && K / (sp16 * 2) >= 32) sp16 *= 2;
+                }
+                const bool deep16 = K / (16 * sp16) >= 12;
+                switch (sp16) {
+                    case 1: if (deep16) launch_direct16<1, 6>(layout, g, s); else launch_direct16<1, 3>(layout, g, s); break;
+                    case 2: if (deep16) launch_direct16<2, 6>(layout, g, s); else launch_direct16<2, 3>(layout, g, s); break;
+                    case 4: if (deep16) launch_direct16<4, 6>(layout, g, s); else launch_direct16<4, 3>(layout, g, s); break;
+                    case 8: launch_direct16<8, 3>(layout, g, s); break;
+                    default: launch_direct16<16, 3>(layout, g, s); break;
+                }
+                HV_LAUNCH_CHECK("gemm_f32 direct16");
+                return HIDVAE_OK;
+            }
             int sp = 1;
             if (split_k != 1) {
                 const int cap = split_k == 0 ? 16 : split_k;

@@ -2,6 +2,7 @@
 
 No torch arithmetic runs on the hot path: torch supplies device memory, streams and the autograd tape only."""
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -21,6 +22,12 @@ def side_stream():
     """One helper stream per device.  Independent launches (weight gradients next to the input-gradient chain, codebook
     preparation next to the encoder) go there so their fixed per-kernel latencies overlap; under HIP-graph capture the
     fork/join becomes graph edges."""
+    if os.environ.get("HIDVAE_SIDE_STREAM", "0") != "1":
+        # DEFAULT: everything on the caller's stream.  Measured on MI355X / ROCm 7.2 (bench.py, B=1024, HIP graph): forking the
+        # parameter-gradient GEMMs, codebook preparation and id statistics to a second stream made the step SLOWER (0.385 ms
+        # vs 0.315 ms untagged, 4.05 ms vs 3.45 ms tagged): every cross-stream edge of the captured graph costs ~5-10 us,
+        # more than the ~5 us launches it overlaps.  HIDVAE_SIDE_STREAM=1 re-enables the fork/join structure.
+        return torch.cuda.current_stream()
     d = torch.cuda.current_device()
     if d not in _SIDE:
         _SIDE[d] = torch.cuda.Stream()

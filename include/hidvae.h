@@ -57,8 +57,8 @@ const char *hidvae_last_error(void);
 
 /* ---- a2/a3/a9/a10: Linear layers (modules/encoder.py:23-36, h_rqvae.py:132-188,322-331) ------------
  * C[M,N] (ldc) = epilogue( opA(A) opB(B) + bias[N] ) [* mask * mask_scale].  fp32 in, fp32 MFMA.
- * split_k == 1: every output element is ONE fmaf chain over k in the fixed order ORDER-G (16-wide k-blocks
- * ascending, inside a block 0,8,1,9,...,7,15) -- reproducible bit for bit by oracle/exact.c; this is what the
+ * split_k == 1: every output element is ONE fmaf chain over k in the fixed order ORDER-G16 (16-wide k-blocks
+ * ascending, inside a block 0,4,8,12,1,5,9,13,...) -- reproducible bit for bit by oracle/exact.c; this is what the
  * forward (id-determining) GEMMs use.  split_k == 0: the library may split K over the waves of a workgroup and
  * reduce in fixed order (bit-reproducible run to run, not ORDER-G); split_k > 1 caps that split.
  * mask (optional, [M,N] at ldmask): dropout keep-mask multiplied in after the activation (nn.Dropout fused).

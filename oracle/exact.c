@@ -14,7 +14,8 @@
  * the association order inside each sum is this file's own (MKL's is unknowable) and is what the
  * HIP kernels implement:
  *   ORDER-G  GEMM: one fmaf chain per output from +0 over 16-wide k-blocks ascending; inside a block the
- *            chain visits k = 0,8,1,9,...,7,15 (f32 MFMA 32x32x2 with lane half h holding k = 8h+s at step s)
+ *            chain visits k = 0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15 ("ORDER-G16": f32 MFMA 16x16x4 with lane
+ *            quarter q holding k = 4q+s at step s; the 32x32x2 kernels feed their operands in the same order)
  *   ORDER-Q  sums over D=32: four chains over the contiguous quarters d in [8q,8q+8), then
  *            (p0+p1)+(p2+p3)
  *   ORDER-P  r.c dot: one fmaf chain visiting d = 0,8,16,24, 1,9,17,25, ... 7,15,23,31
@@ -57,9 +58,9 @@ void orc_linear(const float *x, int64_t M, int64_t K, const float *w, int64_t N,
         float *ym = y + m * N;
         for (int64_t n = 0; n < N; n++) ym[n] = 0.0f;
         for (int64_t k0 = 0; k0 < K; k0 += 16)
-            for (int s = 0; s < 8; s++)
-                for (int h = 0; h < 2; h++) {
-                    const int64_t k = k0 + 8 * h + s;
+            for (int s = 0; s < 4; s++)
+                for (int h = 0; h < 4; h++) {
+                    const int64_t k = k0 + 4 * h + s;
                     if (k >= K) continue;
                     const float xv = x[m * K + k];
                     const float *wk = wt + k * N;
