@@ -58,18 +58,21 @@ __device__ __forceinline__ void level_output(const float (&r)[8], const float (&
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = r[j] + (e[j] - r[j]);
     } else {
-        const float nr = sqrtf(xx) + 1e-8f;
-        const float ne = sqrtf(cce) + 1e-8f;
+        // x / (|x| + eps) as x * (1 / (|x| + eps)): one IEEE division per vector instead of one per component (the
+        // component-wise divisions were ~2/3 of this kernel's VALU work); <= 1 ulp from the reference's quotient, and
+        // oracle/exact.c does the same, so the GPU/oracle comparison stays bit for bit
+        const float inr = 1.0f / (sqrtf(xx) + 1e-8f);
+        const float ine = 1.0f / (sqrtf(cce) + 1e-8f);
         float s[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            u[j] = r[j] / nr;
-            qv[j] = e[j] / ne;
+            u[j] = r[j] * inr;
+            qv[j] = e[j] * ine;
             s[j] = u[j] + qv[j];
         }
-        const float nw = fmaxf(sqrtf(dotQ(s, s)), 1e-6f);
+        const float inw = 1.0f / fmaxf(sqrtf(dotQ(s, s)), 1e-6f);
 #pragma unroll
-        for (int j = 0; j < 8; j++) w[j] = s[j] / nw;
+        for (int j = 0; j < 8; j++) w[j] = s[j] * inw;
         const float rw = dotQ(r, w), ru = dotQ(r, u);
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = (r[j] - 2.0f * (rw * w[j])) + 2.0f * (ru * qv[j]);
@@ -138,7 +141,7 @@ __device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl
     const int LDK = a.KC + 2;
     float *ccs = Cs + 32 * LDK;
     const float *src = a.cb_eff + (int64_t)lvl * a.K * D;
-    for (int idx = threadIdx.x; idx < a.KC * 8; idx += WG_THREADS) {
+    for (int idx = threadIdx.x; idx < a.KC * 8; idx += blockDim.x) {
         const int kl = idx >> 3, d4 = idx & 7;
         const int64_t k = (int64_t)c0 + kl;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -148,7 +151,7 @@ __device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl
         Cs[(4 * d4 + 2) * LDK + kl] = v.z;
         Cs[(4 * d4 + 3) * LDK + kl] = v.w;
     }
-    for (int kl = threadIdx.x; kl < a.KC; kl += WG_THREADS) {
+    for (int kl = threadIdx.x; kl < a.KC; kl += blockDim.x) {
         const int64_t k = (int64_t)c0 + kl;
         ccs[kl] = k < a.K ? a.cc[(int64_t)lvl * a.K + k] : INFINITY;
     }
@@ -158,8 +161,8 @@ __device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl
 // the four (distance, index) candidates meet in LDS and are merged in ascending-quarter order (so equal distances still
 // resolve to the lowest index), then every wave carries on with the same residual.  4x more workgroups, 4x shorter
 // search per wave; results are bit-identical to the unsplit kernel.
-template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT>
-__global__ __launch_bounds__(WG_THREADS) void rq_forward_kernel(FwdArgs a) {
+template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT, int NW>
+__global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float cand_d[2][4][16];
     __shared__ int cand_i[2][4][16];
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(WG_THREADS) void rq_forward_kernel(FwdArgs a) {
         for (int i = 0; i < a.L; i++) stage_codes(lds + i * lvl_floats, a, i, 0);
         __syncthreads();
     }
-    constexpr int TILE_ITEMS = CSPLIT ? ITEMS_PER_WAVE : ITEMS_PER_WG;
+    static_assert(!CSPLIT || NW == 4, "the code-split variant merges four quarter searches");
+    constexpr int TILE_ITEMS = CSPLIT ? ITEMS_PER_WAVE : ITEMS_PER_WAVE * NW;
     int phase = 0;  // running level count across tiles: candidate buffers alternate, one barrier per level suffices
     const int64_t ntiles = (a.B + TILE_ITEMS - 1) / TILE_ITEMS;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -482,16 +486,18 @@ __global__ __launch_bounds__(WG_THREADS) void l2norm32_kernel(const float *x, in
 size_t level_lds_bytes(int KC) { return (size_t)(32 * (KC + 2) + KC) * sizeof(float); }
 
 template <int MODE, bool TRAIN>
-int launch_fwd(const FwdArgs &a, bool resident, bool csplit, int grid, size_t lds, hipStream_t s) {
-#define HV_GO(R, C)                                                                                                        \
+int launch_fwd(const FwdArgs &a, bool resident, bool csplit, int nw, int grid, size_t lds, hipStream_t s) {
+#define HV_GO(R, C, W)                                                                                                     \
     {                                                                                                                      \
-        auto kern = rq_forward_kernel<MODE, TRAIN, R, C>;                                                                  \
+        auto kern = rq_forward_kernel<MODE, TRAIN, R, C, W>;                                                               \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, a);                                                 \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, s, a);                                                     \
     }
-    if (resident && csplit) HV_GO(true, true)
-    else if (resident) HV_GO(true, false)
-    else HV_GO(false, false)
+    if (resident && csplit) HV_GO(true, true, 4)
+    else if (resident && nw == 8) HV_GO(true, false, 8)
+    else if (resident) HV_GO(true, false, 4)
+    else if (nw == 8) HV_GO(false, false, 8)
+    else HV_GO(false, false, 4)
 #undef HV_GO
     HV_LAUNCH_CHECK("rq_forward");
     return HIDVAE_OK;
@@ -550,12 +556,15 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     const size_t lds = resident ? per_level * (size_t)L : per_level;
     // small batches: split the codes over the 4 waves of a workgroup (16 items per workgroup) to cut the serial search
     const bool csplit = resident && a.KC % 128 == 0 && B <= 4096;
-    const int64_t ntiles = hv_cdiv(B, csplit ? ITEMS_PER_WAVE : ITEMS_PER_WG);
+    // large batches: 8 waves per workgroup (two per SIMD) share one LDS copy of the codebooks, so one wave's per-level VALU
+    // work (rotation, loss, argmin merge) overlaps the other's MFMAs; LDS allows only one workgroup per CU either way
+    const int nw = (!csplit && B >= 256 * 128) ? 8 : 4;
+    const int64_t ntiles = hv_cdiv(B, csplit ? ITEMS_PER_WAVE : ITEMS_PER_WAVE * nw);
     const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU (LDS-limited), grid-stride over tiles
     hipStream_t s = (hipStream_t)stream;
-    if (!training) return launch_fwd<HIDVAE_MODE_STE, false>(a, resident, csplit, grid, lds, s);
-    if (mode == HIDVAE_MODE_STE) return launch_fwd<HIDVAE_MODE_STE, true>(a, resident, csplit, grid, lds, s);
-    return launch_fwd<HIDVAE_MODE_ROTATION, true>(a, resident, csplit, grid, lds, s);
+    if (!training) return launch_fwd<HIDVAE_MODE_STE, false>(a, resident, csplit, nw, grid, lds, s);
+    if (mode == HIDVAE_MODE_STE) return launch_fwd<HIDVAE_MODE_STE, true>(a, resident, csplit, nw, grid, lds, s);
+    return launch_fwd<HIDVAE_MODE_ROTATION, true>(a, resident, csplit, nw, grid, lds, s);
 }
 
 extern "C" int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_input, const float *cb_eff,

@@ -134,11 +134,12 @@ static void rq_item(const float *z, int L, int64_t K, const float *const *cbs, c
             for (int d = 0; d < D; d++) o[d] = r[d] + (e[d] - r[d]);
         } else {
             float u[D], q[D], s[D], w[D];
-            const float nr = sqrtf(xx) + 1e-8f;
-            const float ne = sqrtf(cc[bi]) + 1e-8f;
-            for (int d = 0; d < D; d++) { u[d] = r[d] / nr; q[d] = e[d] / ne; s[d] = u[d] + q[d]; }
-            const float nw = fmaxf(sqrtf(dotQ(s, s)), 1e-6f);
-            for (int d = 0; d < D; d++) w[d] = s[d] / nw;
+            /* x / (|x| + eps) evaluated as x * (1 / (|x| + eps)): one division per vector (<= 1 ulp from the quotient) */
+            const float inr = 1.0f / (sqrtf(xx) + 1e-8f);
+            const float ine = 1.0f / (sqrtf(cc[bi]) + 1e-8f);
+            for (int d = 0; d < D; d++) { u[d] = r[d] * inr; q[d] = e[d] * ine; s[d] = u[d] + q[d]; }
+            const float inw = 1.0f / fmaxf(sqrtf(dotQ(s, s)), 1e-6f);
+            for (int d = 0; d < D; d++) w[d] = s[d] * inw;
             const float rw = dotQ(r, w), ru = dotQ(r, u);
             for (int d = 0; d < D; d++) o[d] = (r[d] - 2.0f * (rw * w[d])) + 2.0f * (ru * q[d]);
         }
