@@ -49,6 +49,11 @@ _SIGNATURES = {
     "hidvae_tag_loss_fwd": [_vp, _i64, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "hidvae_kmeans_iter": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_gumbel_rows_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _f, _vp, _vp],
+    "hidvae_gumbel_loss": [_vp, _vp, _i64, _f, _vp, _vp],
+    "hidvae_gumbel_gemb": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp],
+    "hidvae_gumbel_rows_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
+    "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
 }
@@ -319,7 +324,7 @@ def act_bwd(g, ref, act, mask=None, mask_scale=1.0):
 
 
 def binary(op, a, b):
-    """op 0: a*b, op 1: a+b (row-strided views welcome)."""
+    """op 0: a*b, op 1: a+b, op 2: a-b (row-strided views welcome)."""
     M, N = a.shape
     out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     _check(lib().hidvae_binary(int(op), _p(a), _row_stride(a, "a"), _p(b), _row_stride(b, "b"), M, N, _p(out), N, _stream()), "hidvae_binary")
@@ -427,3 +432,35 @@ def tag_loss_bwd(dmix, dkl, target, inverse, lam, g, n_valid):
 def kmeans_iter(x, centroids, assign, reseed_idx, new_centroids, shift_scratch, shift):
     _check(lib().hidvae_kmeans_iter(_p(x), x.shape[0], _p(centroids), centroids.shape[0], _p(assign), _p(reseed_idx), _p(new_centroids),
                                     _p(shift_scratch), _p(shift), _stream()), "hidvae_kmeans_iter")
+
+
+# ------------------------------------------------------------------------------------------------ gumbel branch
+def gumbel_rows_fwd(S, x, cc, U, temperature):
+    B, K = S.shape
+    ids = torch.empty((B,), device=S.device, dtype=torch.int64)
+    _check(lib().hidvae_gumbel_rows_fwd(_p(S), _p(x), _p(cc), _p(U), B, K, float(temperature), _p(ids), _stream()), "hidvae_gumbel_rows_fwd")
+    return ids
+
+
+def gumbel_loss(x, emb, beta):
+    loss = torch.empty((x.shape[0],), device=x.device, dtype=torch.float32)
+    _check(lib().hidvae_gumbel_loss(_p(x), _p(emb), x.shape[0], float(beta), _p(loss), _stream()), "hidvae_gumbel_loss")
+    return loss
+
+
+def gumbel_gemb(g_out, g_l, x, emb):
+    out = torch.empty_like(x)
+    _check(lib().hidvae_gumbel_gemb(_p(g_out), _p(g_l), _vec_stride(g_l), _p(x), _p(emb), x.shape[0], _p(out), _stream()), "hidvae_gumbel_gemb")
+    return out
+
+
+def gumbel_rows_bwd(P, gP, temperature):
+    B, K = P.shape
+    g_xx = torch.empty((B,), device=P.device, dtype=torch.float32)
+    _check(lib().hidvae_gumbel_rows_bwd(_p(P), _p(gP), B, K, float(temperature), _p(g_xx), _stream()), "hidvae_gumbel_rows_bwd")
+    return g_xx
+
+
+def gumbel_finish(g_x, x, emb, g_xx, g_l, beta, g_cb, cb, gS_colsum):
+    _check(lib().hidvae_gumbel_finish(_p(g_x), _p(x), _p(emb), _p(g_xx), _p(g_l), _vec_stride(g_l), float(beta), x.shape[0], _p(g_cb), _p(cb),
+                                      _p(gS_colsum), cb.shape[0], _stream()), "hidvae_gumbel_finish")

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void mul_kernel(const float *a, int64_t lda, c
     const int64_t n = M * N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / N, c = i - r * N;
-        out[r * ldo + c] = op ? a[r * lda + c] + b[r * ldb + c] : a[r * lda + c] * b[r * ldb + c];
+        const float av = a[r * lda + c], bv = b[r * ldb + c];
+        out[r * ldo + c] = op == 0 ? av * bv : (op == 1 ? av + bv : av - bv);
     }
 }
 
@@ -512,7 +513,7 @@ extern "C" int hidvae_act_bwd(const float *g, const float *ref, int64_t numel, i
 
 extern "C" int hidvae_binary(int op, const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M, int64_t N, float *out,
                              int64_t ldo, void *stream) {
-    HV_REQUIRE(a && b && out && M >= 1 && N >= 1 && lda >= N && ldb >= N && ldo >= N && (op == 0 || op == 1), "binary: bad arguments");
+    HV_REQUIRE(a && b && out && M >= 1 && N >= 1 && lda >= N && ldb >= N && ldo >= N && op >= 0 && op <= 2, "binary: bad arguments");
     hipLaunchKernelGGL(mul_kernel, dim3(ew_grid(M * N)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, M, N, out, ldo, op);
     HV_LAUNCH_CHECK("binary");
     return HIDVAE_OK;

@@ -1,18 +1,90 @@
 """GUMBEL_SOFTMAX training branch of Quantize (reference modules/quantize.py:125-130 + distributions/gumbel.py:8-18).
 
-No shipped config selects it (both gin files bind ROTATION_TRICK) although it is the HRqVae constructor default; the
-eval branch (used by the tokenizer) never reaches it.  The fused RQ kernel covers STE / ROTATION / eval; the Gumbel
-training branch is not built yet and fails loudly rather than falling back to anything else."""
+No shipped config selects it (both gin files bind ROTATION_TRICK) although it is the HRqVae constructor default, so it is
+composed level by level from the MFMA GEMM entry points and the row kernels of csrc/gumbel.hip instead of living in the
+fused RQ kernel.  Every codebook row receives gradient here (the soft assignment touches all K codes)."""
+import torch
+from torch.autograd import Function
+
+from . import _C
+from .ops import L2NormFn
+from .tagpath import AddFn
 
 
-def _fail():
-    raise NotImplementedError("QuantizeForwardMode.GUMBEL_SOFTMAX in TRAINING mode is not built on the HIP path yet "
-                              "(STE, ROTATION_TRICK and every eval-mode call are); see DESIGN.md, 'out of scope this round'")
+class GumbelLevelFn(Function):
+    """(x [B,32], cb [K,32] effective codebook, U [B,K] uniform draws) -> (emb [B,32], ids [B], loss [B])."""
+
+    @staticmethod
+    def forward(ctx, x, cb, U, temperature, beta):
+        ctx.set_materialize_grads(False)
+        x, cb = x.contiguous(), cb.contiguous()
+        S = _C.gemm(_C.GEMM_NT, x, cb, split_k=0)           # x cb^T
+        cc = _C.codebook_prepare([cb], [False])[1][0]       # |c_k|^2
+        ids = _C.gumbel_rows_fwd(S, x, cc, U.contiguous(), temperature)  # S -> P
+        emb = _C.gemm(_C.GEMM_NN, S, cb, split_k=0)          # P cb
+        loss = _C.gumbel_loss(x, emb, beta)
+        ctx.save_for_backward(x, cb, S, emb)
+        ctx.cfg = (temperature, beta)
+        ctx.mark_non_differentiable(ids)
+        return emb, ids, loss
+
+    @staticmethod
+    def backward(ctx, g_out, _g_ids, g_l):
+        x, cb, P, emb = ctx.saved_tensors
+        temperature, beta = ctx.cfg
+        if g_out is None and g_l is None:
+            return None, None, None, None, None
+        g_emb = _C.gumbel_gemb(g_out.contiguous() if g_out is not None else None, g_l, x, emb)
+        gP = _C.gemm(_C.GEMM_NT, g_emb, cb, split_k=0)        # [B,K]
+        g_cb = _C.gemm(_C.GEMM_TN, P, g_emb, split_k=0)       # P^T g_emb
+        g_xx = _C.gumbel_rows_bwd(P, gP, temperature)         # gP -> g_S
+        g_x = _C.gemm(_C.GEMM_NN, gP, cb, split_k=0)          # g_S cb
+        _C.gemm(_C.GEMM_TN, gP, x, out=g_cb, split_k=0, accumulate=True)  # + g_S^T x
+        _C.gumbel_finish(g_x, x, emb, g_xx, g_l, beta, g_cb, cb, _C.colsum(gP))
+        return g_x, g_cb, None, None, None
 
 
-def gumbel_level(layer, x, temperature):
-    _fail()
+class SubFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return _C.binary(2, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        g = g.contiguous()
+        return g, _C.binary(2, torch.zeros_like(g), g)
+
+
+def _effective(layer):
+    cb = layer.table()
+    if layer.codebook_normalize:
+        cb = L2NormFn.apply(cb.contiguous(), 1e-12)
+    return cb
+
+
+def gumbel_level(layer, x, temperature, rand=None):
+    from .rand import DeviceRand
+    rand = rand or DeviceRand()
+    U = rand.gumbel_u((x.shape[0], layer.n_embed), x.device)
+    return GumbelLevelFn.apply(x, _effective(layer), U, float(temperature), layer.quantize_loss.commitment_weight)
 
 
 def gumbel_all_levels(model, y, normalize_input):
-    _fail()
+    """-> z, ids [B,L], emb_cat [B,L*D], emb_sum [B,D], qloss [B], res_cat [B,L*D]   (same tuple as ops.RQFn)"""
+    rand = model._rand()
+    z = L2NormFn.apply(y.contiguous(), 1e-12) if normalize_input else y
+    res, embs, ids, ress = z, [], [], []
+    qloss = esum = None
+    t = getattr(model, "_gumbel_t", 1.0)
+    for layer in model.layers:
+        ress.append(res)
+        emb, idl, loss = gumbel_level(layer, res, t, rand)
+        embs.append(emb)
+        ids.append(idl)
+        qloss = loss if qloss is None else AddFn.apply(qloss.unsqueeze(1), loss.unsqueeze(1)).squeeze(1)
+        esum = emb if esum is None else AddFn.apply(esum, emb)
+        res = SubFn.apply(res, emb)
+    # (assembling the side-by-side buffers is device plumbing; this branch is not on any config's path)
+    return z, torch.stack(ids, dim=1), torch.cat(embs, dim=1), esum, qloss, torch.cat([r.detach() for r in ress], dim=1)

@@ -182,7 +182,8 @@ int hidvae_adamw_step(float *const *p_dev, const float *const *g_host, float *co
  * act = HIDVAE_EPI_{NONE,RELU,GELU,SIGMOID,SILU}; ref = forward OUTPUT for RELU/SIGMOID, pre-activation for GELU/SILU. */
 int hidvae_act_bwd(const float *g, const float *ref, int64_t numel, int act, const float *mask, float mask_scale,
                    float *out, void *stream);
-/* out = a * b (op 0: TagPredictor gate, h_rqvae.py:208) or a + b (op 1: residual add, :219), row strides in elements */
+/* out = a * b (op 0: TagPredictor gate, h_rqvae.py:208), a + b (op 1: residual add, :219) or a - b (op 2: residual update
+ * of the Gumbel branch, h_rqvae.py:300), row strides in elements */
 int hidvae_binary(int op, const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M, int64_t N, float *out,
                   int64_t ldo, void *stream);
 /* dst[M,N] = sum_s src_s[:, :width_s] zero-extended: gradient of the column-prefix views concat_emb = cat(embs[:i+1])
@@ -241,6 +242,22 @@ int hidvae_tag_loss_bwd(const float *dmix, const float *dkl, const int64_t *targ
  * shift_scratch: K floats. */
 int hidvae_kmeans_iter(const float *x, int64_t N, const float *centroids, int64_t K, int32_t *assign,
                        const int64_t *reseed_idx, float *new_centroids, float *shift_scratch, float *shift, void *stream);
+
+/* ---- a6: GUMBEL_SOFTMAX training branch of one level (quantize.py:125-130, distributions/gumbel.py:8-18); row kernels
+ * around the GEMMs (S = x cb^T, emb = P cb and their gradients run on hidvae_gemm_f32).  D = 32.
+ * rows_fwd : S [B,K] in -> P = softmax((-(|x|^2+cc-2S) + G)/T) in place, G from the uniform draws U [B,K]; ids = argmin dist.
+ * loss     : loss[b] = (1+beta)|x-emb|^2.        gemb: g_emb = g_out + g_l[b*stride]*2(emb-x).
+ * rows_bwd : gP [B,K] (= g_emb cb^T) -> g_S in place, g_xx[b] = d/d|x_b|^2.
+ * finish   : g_x += 2 x g_xx + g_l 2 beta (x-emb);  g_cb += 2 cb * (-colsum(g_S)/2). */
+int hidvae_gumbel_rows_fwd(float *S, const float *x, const float *cc, const float *U, int64_t B, int64_t K,
+                           float temperature, int64_t *ids, void *stream);
+int hidvae_gumbel_loss(const float *x, const float *emb, int64_t B, float beta, float *loss, void *stream);
+int hidvae_gumbel_gemb(const float *g_out, const float *g_l, int64_t gl_stride, const float *x, const float *emb, int64_t B,
+                       float *g_emb, void *stream);
+int hidvae_gumbel_rows_bwd(const float *P, float *gP, int64_t B, int64_t K, float temperature, float *g_xx, void *stream);
+int hidvae_gumbel_finish(float *g_x, const float *x, const float *emb, const float *g_xx, const float *g_l,
+                         int64_t gl_stride, float beta, int64_t B, float *g_cb, const float *cb, const float *gS_colsum,
+                         int64_t K, void *stream);
 
 #ifdef __cplusplus
 }
