@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--pool", type=int, default=8, help="resident synthetic batches cycled through")
+    ap.add_argument("--kernels", type=int, default=1, help="time the dominant kernels for the roofline object (0 = skip, for profiling runs)")
     ap.add_argument("--also-tagged", type=int, default=1, help="also time the tagged step (reported as `tagged_step`)")
     return ap.parse_args()
 
@@ -322,6 +323,9 @@ def main():
                             workload="same shapes + tag heads (projector, InfoNCE, predictor, focal+mixup), amazon gin hyper-parameters")
 
     if rank == 0:
+        if not args.kernels:  # profiling run of the step only (rocprofv3 timelines): no roofline object
+            print(json.dumps({"value": args.batch * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "note": "--kernels 0"}))
+            return
         ks = kernel_rooflines(args, m, device)
         # dominant kernel: rocprof (profiles/) puts ~70 % of the step in gemm_direct_kernel, and the encoder's first layer is
         # its single largest launch

@@ -23,6 +23,7 @@ _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_floa
 
 _SIGNATURES = {
     "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _i, _vp, _i, _vp],
+    "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
@@ -54,6 +55,8 @@ _SIGNATURES = {
     "hidvae_gumbel_gemb": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp],
     "hidvae_gumbel_rows_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
     "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _vp],
+    "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
 }
@@ -152,6 +155,21 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
                                  epilogue, _p(aux), ldaux, _p(mask), ldmask, float(mask_scale), split_k, _p(ws),
                                  int(accumulate), _stream()), "hidvae_gemm_f32")
     return out
+
+
+def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None):
+    """backward of y = x W^T in one launch -> (dW [n_out,n_in], dX [B,n_in] or None); dX = epilogue(g W) with a D* code + aux."""
+    _f32(g, "g"), _f32(x, "x")
+    B, n_out = g.shape
+    n_in = x.shape[1]
+    if x.shape[0] != B or (need_dx and tuple(w.shape) != (n_out, n_in)):
+        raise RuntimeError(f"linear_bwd: shapes g {tuple(g.shape)} x {tuple(x.shape)} W {tuple(w.shape)}")
+    dW = torch.empty((n_out, n_in), device=g.device, dtype=torch.float32)
+    dX = torch.empty((B, n_in), device=g.device, dtype=torch.float32) if need_dx else None
+    _check(lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
+                                   _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, _p(dX), n_in, int(epilogue),
+                                   _p(aux), _row_stride(aux, "aux") if aux is not None else 0, _stream()), "hidvae_linear_bwd")
+    return dW, dX
 
 
 def colsum(X, out=None, accumulate=False):
@@ -260,12 +278,20 @@ def l2norm_bwd(g, out, norms, eps=1e-12, gx=None, accumulate=False):
     return gx
 
 
+_ID_SCRATCH = {}
+
+
 def id_stats(emb_cat, ids, want_norms=True):
     B, L = ids.shape
     dev = ids.device
+    key = (dev.index, B)
+    scratch = _ID_SCRATCH.get(key)
+    if scratch is None:  # zero-filled once; the kernel keeps it consistent between calls (include/hidvae.h)
+        if len(_ID_SCRATCH) > 64:
+            _ID_SCRATCH.clear()
+        scratch = _ID_SCRATCH[key] = torch.zeros((4 * B + 3,), device=dev, dtype=torch.int64)
     norms = torch.empty((B, L), device=dev, dtype=torch.float32) if want_norms else None
     pu = torch.empty((), device=dev, dtype=torch.float32)
-    scratch = torch.empty((4 * B,), device=dev, dtype=torch.int64)
     ld = _row_stride(emb_cat, "emb_cat") if emb_cat is not None else 0
     _check(lib().hidvae_id_stats(_p(emb_cat if want_norms else None), ld, _p(ids), B, L, _p(norms), _p(pu), _p(scratch), _stream()),
            "hidvae_id_stats")
@@ -314,6 +340,37 @@ def total_loss_bwd(g_loss, B, L, w_a, w_p, w_u, g_rows, want_gz):
     _check(lib().hidvae_total_loss_bwd(_p(g_loss), B, L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(scal), _p(g_z), _stream()),
            "hidvae_total_loss_bwd")
     return scal, g_z
+
+
+def loss_fwd(y, x, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want_grad):
+    """decoder tail + total loss -> (loss, recon, uniq, g_rows, tagstats)"""
+    _f32(y, "y"), _f32(x, "x")
+    if y.shape != x.shape or not y.is_contiguous() or not x.is_contiguous():
+        raise RuntimeError(f"loss: shapes differ or not contiguous ({tuple(y.shape)} vs {tuple(x.shape)})")
+    dev = y.device
+    B, N = y.shape
+    recon = torch.empty((B,), device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    uniq = torch.empty((), device=dev, dtype=torch.float32)
+    L = ids.shape[1] if ids is not None else 0
+    n_tag = len(aligns)
+    g_rows = torch.empty((L, EMBED_DIM), device=dev, dtype=torch.float32) if (want_grad and ids is not None) else None
+    tagstats = torch.empty((3 + 3 * n_tag,), device=dev, dtype=torch.float32) if n_tag else None
+    arr = lambda ts: _host_ptr_array(ts) if ts else None
+    _check(lib().hidvae_loss_fwd(_p(y), _p(x), B, N, _p(qloss), arr(aligns), arr(preds), arr(accs), n_tag, float(tag_div), _p(ids), _p(z), L,
+                                 float(uniq_weight), float(uniq_margin), float(w_a), float(w_p), float(w_u), _p(recon), _p(loss), _p(uniq),
+                                 _p(g_rows), _p(tagstats), _stream()), "hidvae_loss_fwd")
+    return loss, recon, uniq, g_rows, tagstats
+
+
+def loss_bwd(g_loss, y, x, L, w_a, w_p, w_u, g_rows, want_gz):
+    B, N = y.shape
+    scal = torch.empty((3,), device=y.device, dtype=torch.float32)
+    g_y = torch.empty_like(y)
+    g_z = torch.empty((B, EMBED_DIM), device=y.device, dtype=torch.float32) if want_gz else None
+    _check(lib().hidvae_loss_bwd(_p(g_loss), _p(y), _p(x), B, N, L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(g_y), _p(scal), _p(g_z),
+                                 _stream()), "hidvae_loss_bwd")
+    return g_y, scal, g_z
 
 
 # ------------------------------------------------------------------------------------------------ tag path

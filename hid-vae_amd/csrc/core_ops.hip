@@ -12,14 +12,12 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 constexpr int MAXV = 4;  // N <= 64 lanes * 4 floats * MAXV = 1024 on the vector path
 
+// one wave, one row: x_hat = y/max(|y|,eps), recon = |x_hat - x|^2, g_y = gscale * d recon / d y   (each output optional)
 template <bool VEC>
-__global__ __launch_bounds__(256) void recon_kernel(const float *y, const float *x, int64_t B, int64_t N, float gscale_all,
-                                                    const float *gscale_items, int64_t gs_stride, float *x_hat, float *recon, float *g_y) {
+__device__ __forceinline__ void recon_row(const float *y, const float *x, int64_t row, int64_t N, float gscale, float *x_hat,
+                                          float *recon, float *g_y) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B) return;
     const float *yr = y + row * N, *xr = x + row * N;
-    const float gscale = gscale_items != nullptr ? gscale_all * gscale_items[row * gs_stride] : gscale_all;
     if (VEC) {
         const int nv = (int)(N / 4);
         float4 yv[MAXV], xv[MAXV];
@@ -88,6 +86,15 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *y, const float 
             }
         }
     }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void recon_kernel(const float *y, const float *x, int64_t B, int64_t N, float gscale_all,
+                                                    const float *gscale_items, int64_t gs_stride, float *x_hat, float *recon, float *g_y) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float gscale = gscale_items != nullptr ? gscale_all * gscale_items[row * gs_stride] : gscale_all;
+    recon_row<VEC>(y, x, row, N, gscale, x_hat, recon, g_y);
 }
 
 // generic row L2 normalise: out = x / max(|x|, eps); saves |x| for the backward.  One wave per row.
@@ -181,11 +188,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // id statistics
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void id_stats_init_kernel(const float *emb_cat, int64_t ld_cat, int64_t B, int L,
-                                                            float *embs_norm, int64_t *table, int64_t tsize) {
+// One launch: embs_norm, and a census of the distinct id tuples in an open-addressing table that is never cleared.
+// scratch = tsize slots + {distinct<<32 | tickets, unused, call counter}; zero-filled ONCE by its owner.  A slot holds
+// (generation << 40) | item; slots of older generations count as empty, so the table needs no per-call initialisation.  The
+// workgroup that takes the last ticket publishes p_unique, resets the counters and moves to the next generation (and wipes
+// the table when the 24-bit generation wraps).
+constexpr unsigned long long GEN_MOD = 0xFFFFFEull;
+__global__ __launch_bounds__(256) void id_stats_kernel(const float *emb_cat, int64_t ld_cat, const int64_t *ids, int64_t B, int L,
+                                                       float *embs_norm, unsigned long long *table, int64_t tsize, float *p_unique) {
+    __shared__ int s_new;
+    __shared__ int s_last;
+    unsigned long long *ctrl = table + tsize;
+    const unsigned long long calls = ctrl[2];
+    const unsigned long long gen = calls % GEN_MOD + 1ull;
+    if (threadIdx.x == 0) s_new = 0;
+    __syncthreads();
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx < tsize) table[idx] = -1;
-    if (idx == 0) table[tsize] = 0;  // distinct counter
     if (embs_norm != nullptr && idx < B * L) {
         const int64_t b = idx / L;
         const int i = (int)(idx - b * L);
@@ -198,35 +216,53 @@ __global__ __launch_bounds__(256) void id_stats_init_kernel(const float *emb_cat
         }
         embs_norm[idx] = sqrtf(s);
     }
-}
-
-__global__ __launch_bounds__(256) void id_stats_insert_kernel(const int64_t *ids, int64_t B, int L, int64_t *table,
-                                                              int64_t tsize) {
-    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
-    unsigned long long h = 0x9E3779B97F4A7C15ull;
-    for (int i = 0; i < L; i++) {
-        h ^= (unsigned long long)ids[b * L + i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        h *= 0xBF58476D1CE4E5B9ull;
-        h ^= h >> 29;
-    }
-    int64_t slot = (int64_t)(h % (unsigned long long)tsize);
-    for (int64_t probe = 0; probe < tsize; probe++) {
-        const long long prev = (long long)atomicCAS(reinterpret_cast<unsigned long long *>(table + slot),
-                                                    (unsigned long long)-1ll, (unsigned long long)b);
-        if (prev == -1ll) {  // first item with this tuple
-            atomicAdd(reinterpret_cast<unsigned long long *>(table + tsize), 1ull);
-            return;
+    if (idx < B) {
+        const int64_t b = idx;
+        unsigned long long h = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < L; i++) {
+            h ^= (unsigned long long)ids[b * L + i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 29;
         }
-        bool same = true;
-        for (int i = 0; i < L; i++) same = same && (ids[prev * L + i] == ids[b * L + i]);
-        if (same) return;  // duplicate of an already counted tuple
-        slot = slot + 1 == tsize ? 0 : slot + 1;
+        const unsigned long long mine = (gen << 40) | (unsigned long long)b;
+        int64_t slot = (int64_t)(h % (unsigned long long)tsize);
+        for (int64_t probe = 0; probe < tsize;) {
+            unsigned long long cur = __atomic_load_n(table + slot, __ATOMIC_RELAXED);
+            if ((cur >> 40) != gen) {
+                const unsigned long long prev = atomicCAS(table + slot, cur, mine);
+                if (prev == cur) {  // first item with this tuple
+                    atomicAdd(&s_new, 1);
+                    break;
+                }
+                cur = prev;
+                if ((cur >> 40) != gen) continue;  // lost a race against a stale view of the slot: look again
+            }
+            const int64_t other = (int64_t)(cur & ((1ull << 40) - 1ull));
+            bool same = true;
+            for (int i = 0; i < L; i++) same = same && (ids[other * L + i] == ids[b * L + i]);
+            if (same) break;  // duplicate of an already counted tuple
+            slot = slot + 1 == tsize ? 0 : slot + 1;
+            probe++;
+        }
     }
-}
-
-__global__ void id_stats_final_kernel(const int64_t *table, int64_t tsize, int64_t B, float *p_unique) {
-    *p_unique = (float)table[tsize] / (float)B;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // ONE atomic per workgroup: tickets in the low half, distinct tuples in the high half, so the workgroup that draws the
+        // last ticket learns the final count from the value its own add returns (no fence, no second counter)
+        const unsigned long long old = atomicAdd(ctrl, ((unsigned long long)s_new << 32) + 1ull);
+        s_last = (old & 0xFFFFFFFFull) == (unsigned long long)gridDim.x - 1ull;
+        s_new += (int)(old >> 32);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        *p_unique = (float)s_new / (float)B;
+        ctrl[0] = 0ull;
+        ctrl[1] = 0ull;
+        ctrl[2] = calls + 1ull;
+    }
+    if ((calls + 1ull) % GEN_MOD == 0ull)
+        for (int64_t i = threadIdx.x; i < tsize; i += 256) table[i] = 0ull;
 }
 
 }  // namespace
@@ -281,15 +317,11 @@ extern "C" int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64
                                float *p_unique, int64_t *scratch, void *stream) {
     HV_REQUIRE(ids && p_unique && scratch && B >= 1 && L >= 1 && L <= HIDVAE_MAX_LEVELS, "id_stats: bad arguments");
     HV_REQUIRE(embs_norm == nullptr || (emb_cat != nullptr && ld_cat >= (int64_t)L * 32 && ld_cat % 4 == 0), "id_stats: emb_cat/ld_cat");
-    const int64_t tsize = 4 * B - 1;  // scratch holds tsize slots + 1 counter
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t n0 = tsize > B * L ? tsize : B * L;
-    hipLaunchKernelGGL(id_stats_init_kernel, dim3((unsigned)hv_cdiv(n0, 256)), dim3(256), 0, s, emb_cat, ld_cat, B, L, embs_norm, scratch, tsize);
-    HV_LAUNCH_CHECK("id_stats init");
-    hipLaunchKernelGGL(id_stats_insert_kernel, dim3((unsigned)hv_cdiv(B, 256)), dim3(256), 0, s, ids, B, L, scratch, tsize);
-    HV_LAUNCH_CHECK("id_stats insert");
-    hipLaunchKernelGGL(id_stats_final_kernel, dim3(1), dim3(1), 0, s, scratch, tsize, B, p_unique);
-    HV_LAUNCH_CHECK("id_stats final");
+    const int64_t tsize = 4 * B;  // + 3 control words
+    const int64_t n0 = B * (embs_norm != nullptr && L > 1 ? L : 1);
+    hipLaunchKernelGGL(id_stats_kernel, dim3((unsigned)hv_cdiv(n0, 256)), dim3(256), 0, (hipStream_t)stream, emb_cat, ld_cat, ids, B, L,
+                       embs_norm, reinterpret_cast<unsigned long long *>(scratch), tsize, p_unique);
+    HV_LAUNCH_CHECK("id_stats");
     return HIDVAE_OK;
 }
 
@@ -382,7 +414,8 @@ struct TotalArgs {
     float *loss, *uniq, *g_rows;
 };
 
-__global__ __launch_bounds__(256) void total_loss_kernel(TotalArgs a) {
+// executed by one whole 256-thread workgroup
+__device__ __forceinline__ void total_loss_body(const TotalArgs &a) {
     __shared__ float red[2][4];
     __shared__ float uq;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -418,6 +451,27 @@ __global__ __launch_bounds__(256) void total_loss_kernel(TotalArgs a) {
         *a.loss = t;
         if (a.uniq != nullptr) *a.uniq = uq;
     }
+}
+
+__global__ __launch_bounds__(256) void total_loss_kernel(TotalArgs a) { total_loss_body(a); }
+
+// backward of the same pair in ONE launch: g_y = (g/B) d recon/d y per row; scal / g_z as total_loss_bwd_kernel
+template <bool VEC>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L,
+                                                       float w_a, float w_p, float w_u, const float *g_rows, float *g_y, float *scal,
+                                                       float *g_z) {
+    const float g = *g_loss;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal[0] = g / (float)B;
+        scal[1] = g * w_a;
+        scal[2] = g * w_p;
+    }
+    if (g_z != nullptr && threadIdx.x < 128) {  // this workgroup's 4 rows of g_z
+        const int64_t idx = (int64_t)blockIdx.x * 128 + threadIdx.x;
+        if (idx < B * 32) g_z[idx] = (g_rows != nullptr && idx < (int64_t)L * 32) ? (g * w_u) * g_rows[idx] : 0.0f;
+    }
+    if (row < B) recon_row<VEC>(y, x, row, N, 1.0f * (g / (float)B), nullptr, nullptr, g_y);
 }
 
 // scal[0] = g/B, scal[1] = g*w_a, scal[2] = g*w_p ; g_z [B,32] = g*w_u*g_rows on the first L rows, 0 elsewhere
@@ -462,6 +516,58 @@ extern "C" int hidvae_total_loss(const float *recon, const float *qloss, int64_t
     a.w_a = w_a; a.w_p = w_p; a.w_u = w_u; a.loss = loss; a.uniq = uniq; a.g_rows = g_rows;
     hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     HV_LAUNCH_CHECK("total_loss");
+    return HIDVAE_OK;
+}
+
+static bool recon_vec_ok(int64_t N, const void *a, const void *b, const void *c, const void *d) {
+    return (N % 4 == 0) && N <= 256 * MAXV &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
+
+extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, const float *qloss,
+                               const float *const *align_host, const float *const *pred_host, const float *const *acc_host, int n_tag,
+                               float tag_div, const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
+                               float w_p, float w_u, float *recon, float *loss, float *uniq, float *g_rows, float *tagstats,
+                               void *stream) {
+    HV_REQUIRE(y && x && qloss && recon && loss && B >= 1 && N >= 1, "loss_fwd: bad arguments");
+    HV_REQUIRE(ids == nullptr || (z != nullptr && L >= 1 && L <= HIDVAE_MAX_LEVELS),
+               "loss_fwd: uniqueness term needs z and 1 <= n_layers <= %d (L=%d)", HIDVAE_MAX_LEVELS, L);
+    HV_REQUIRE(n_tag >= 0 && n_tag <= HIDVAE_MAX_LEVELS && (n_tag == 0 || (align_host && pred_host && acc_host && tag_div > 0.0f)),
+               "loss_fwd: tag terms");
+    TotalArgs a{};
+    a.recon = recon; a.qloss = qloss; a.B = B; a.n_tag = n_tag; a.tag_div = tag_div; a.tagstats = tagstats;
+    for (int i = 0; i < n_tag; i++) {
+        HV_REQUIRE(align_host[i] && pred_host[i] && acc_host[i], "loss_fwd: null tag scalar at level %d", i);
+        a.align[i] = align_host[i]; a.pred[i] = pred_host[i]; a.acc[i] = acc_host[i];
+    }
+    a.ids = ids; a.z = z; a.L = L; a.uniq_weight = uniq_weight; a.uniq_margin = uniq_margin;
+    a.w_a = w_a; a.w_p = w_p; a.w_u = w_u; a.loss = loss; a.uniq = uniq; a.g_rows = g_rows;
+    // two launches: a grid-wide hand-off inside one launch needs an agent-scope release per workgroup, and on 8 XCDs that
+    // L2 write-back costs several times the second launch (measured 25 us fused vs 5 + 6.6 us)
+    const unsigned grid = (unsigned)hv_cdiv(B, 4);
+    if (recon_vec_ok(N, y, x, nullptr, nullptr))
+        hipLaunchKernelGGL(recon_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, 0.0f, (const float *)nullptr,
+                           (int64_t)0, (float *)nullptr, recon, (float *)nullptr);
+    else
+        hipLaunchKernelGGL(recon_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, 0.0f, (const float *)nullptr,
+                           (int64_t)0, (float *)nullptr, recon, (float *)nullptr);
+    HV_LAUNCH_CHECK("loss_fwd recon");
+    hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("loss_fwd");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L, float w_a, float w_p,
+                               float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, void *stream) {
+    HV_REQUIRE(g_loss && y && x && g_y && scal && B >= 1 && N >= 1, "loss_bwd: bad arguments");
+    const unsigned grid = (unsigned)hv_cdiv(B, 4);
+    if (recon_vec_ok(N, y, x, g_y, nullptr))
+        hipLaunchKernelGGL(loss_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_loss, y, x, B, N, L, w_a, w_p, w_u, g_rows,
+                           g_y, scal, g_z);
+    else
+        hipLaunchKernelGGL(loss_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_loss, y, x, B, N, L, w_a, w_p, w_u, g_rows,
+                           g_y, scal, g_z);
+    HV_LAUNCH_CHECK("loss_bwd");
     return HIDVAE_OK;
 }
 

@@ -400,6 +400,98 @@ void launch_direct16(int layout, const GemmArgs &g, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_direct16_kernel<HIDVAE_GEMM_TN, SPLIT, NS>), grid, block, 0, s, g);
 }
 
+// ---- two independent 16x16-tile problems in ONE launch (the dW / dX pair of a Linear layer's backward) ------------------
+// Same arithmetic as gemm_direct16_kernel with the split taken at run time: wave w < split owns blocks [nfull*w/split,
+// nfull*(w+1)/split) and the partials are added in ascending wave order, so a pair launch is bit-identical to the two
+// separate launches it replaces.  The workgroup has max(split0, split1) waves; the surplus waves of the narrower problem
+// only keep the barrier company.
+template <int LAYOUT, int NS>
+__device__ __forceinline__ void direct16_body(const GemmArgs &g, int split, int64_t tile0, int64_t ntiles, int nbx, float *part) {
+    constexpr bool A_KC = (LAYOUT != HIDVAE_GEMM_TN);
+    constexpr bool B_KC = (LAYOUT == HIDVAE_GEMM_NT);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the workgroup's waves form groups of `split`; group t works on tile tile0 + t, wave w of the group on its K share
+    const int tw = wv / split, w = wv - tw * split;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int64_t tile = tile0 + tw;
+    if (tile < ntiles) {
+        const int64_t m0 = (tile / nbx) * 16, n0 = (tile % nbx) * 16;
+        const int64_t ra = (m0 + i16 < g.M) ? m0 + i16 : g.M - 1;
+        const int64_t rb = (n0 + i16 < g.N) ? n0 + i16 : g.N - 1;
+        const int va = 4 * (A_KC ? (int)(ra * g.lda) + 4 * q : (int)(4 * q * g.lda + ra));
+        const int vb = 4 * (B_KC ? (int)(rb * g.ldb) + 4 * q : (int)(4 * q * g.ldb + rb));
+        const int lda4 = (int)g.lda * 4, ldb4 = (int)g.ldb * 4, Ki = (int)g.K;
+        const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(g.A), 0, (int)(4 * (A_KC ? (g.M - 1) * g.lda + g.K : (g.K - 1) * g.lda + g.M)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(g.B), 0, (int)(4 * (B_KC ? (g.N - 1) * g.ldb + g.K : (g.K - 1) * g.ldb + g.N)), 0x00020000);
+        const int nfull = Ki / 16;
+        const int b_lo = nfull * w / split, b_hi = nfull * (w + 1) / split;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float ra_[NS][4], rb_[NS][4];
+        auto load = [&](float (&av)[4], float (&bv)[4], int blk) {
+            const bool in = blk < b_hi;
+            load_block16<A_KC>(ra_rsrc, lda4, in ? va : HV_OOB, blk * 16, av);
+            load_block16<B_KC>(rb_rsrc, ldb4, in ? vb : HV_OOB, blk * 16, bv);
+        };
+#pragma unroll
+        for (int st = 0; st < NS - 1; st++) load(ra_[st], rb_[st], b_lo + st);
+        for (int blk = b_lo; blk < b_hi; blk += NS) {
+#pragma unroll
+            for (int st = 0; st < NS; st++) {
+                load(ra_[(st + NS - 1) % NS], rb_[(st + NS - 1) % NS], blk + st + NS - 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra_[st][s4], rb_[st][s4], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (w == split - 1 && nfull * 16 < Ki) {
+            load_tail16<A_KC>(ra_rsrc, lda4, va, nfull * 16, Ki, q, ra_[0]);
+            load_tail16<B_KC>(rb_rsrc, ldb4, vb, nfull * 16, Ki, q, rb_[0]);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra_[0][s4], rb_[0][s4], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[wv * 256 + (4 * q + r) * 16 + i16] = acc[r];
+    }
+    __syncthreads();
+    const float *mk = g.mask;
+    const int groups = (int)(blockDim.x >> 6) / split;
+    for (int e = threadIdx.x; e < groups * 256; e += blockDim.x) {
+        const int t = e >> 8, ee = e & 255;
+        const int64_t tl = tile0 + t;
+        if (tl >= ntiles) break;
+        float v = part[(t * split) * 256 + ee];
+        for (int sidx = 1; sidx < split; sidx++) v += part[(t * split + sidx) * 256 + ee];  // fixed order: bit-reproducible
+        const int64_t row = (tl / nbx) * 16 + (ee >> 4), col = (tl % nbx) * 16 + (ee & 15);
+        if (row >= g.M || col >= g.N) continue;
+        v += g.bias != nullptr ? g.bias[col] : 0.0f;
+        if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+        if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+        float *dst = g.C + row * g.ldc + col;
+        *dst = g.accumulate ? *dst + v : v;
+    }
+}
+
+struct PairArgs {
+    GemmArgs g0, g1;       // g0: TN (dW = g^T x), g1: NN (dX = g W)
+    int split0, split1;    // waves per tile
+    int nbx0, nbx1;        // column tiles
+    int64_t nt0, nt1;      // tiles
+    int nb0;               // workgroups of problem 0 (each takes waves/split tiles)
+};
+
+__global__ __launch_bounds__(1024) void gemm_pair16_kernel(PairArgs p) {
+    __shared__ float part[16 * 256];
+    const int bid = blockIdx.x;
+    const int waves = (int)(blockDim.x >> 6);
+    if (bid < p.nb0) direct16_body<HIDVAE_GEMM_TN, 3>(p.g0, p.split0, (int64_t)bid * (waves / p.split0), p.nt0, p.nbx0, part);
+    else direct16_body<HIDVAE_GEMM_NN, 3>(p.g1, p.split1, (int64_t)(bid - p.nb0) * (waves / p.split1), p.nt1, p.nbx1, part);
+}
+
 // NWN > 1 (only with SPLIT == 1): the workgroup's NWN waves take NWN neighbouring column tiles of the SAME row tile, so the
 // A rows they all read are fetched into the CU's L1 once instead of NWN times.
 template <int LAYOUT, int SPLIT, int NS, int NWN = 1>
@@ -515,6 +607,25 @@ void launch_tile(int layout, const GemmArgs &g, int splits, hipStream_t s) {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// dispatch rules shared by hidvae_gemm_f32 and the pair launch (so both choose the same split and give the same bits)
+inline bool fits32bit(int layout, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    const int64_t a_rows = (layout == HIDVAE_GEMM_TN) ? K : M, b_rows = (layout == HIDVAE_GEMM_NT) ? N : K;
+    return a_rows * lda < (1ll << 29) && b_rows * ldb < (1ll << 29);  // the direct kernels use 32-bit BYTE offsets
+}
+inline bool use_direct16(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles32 = hv_cdiv(M, 32) * hv_cdiv(N, 32);
+    return tiles32 <= 256 || (tiles32 <= 512 && K <= 256);
+}
+inline int pick_split16(int64_t M, int64_t N, int64_t K, int split_k) {
+    const int64_t tiles16 = hv_cdiv(M, 16) * hv_cdiv(N, 16);
+    int sp16 = 1;
+    if (split_k != 1) {
+        const int cap = split_k == 0 ? 16 : split_k;
+        while (sp16 < cap && sp16 < 16 && tiles16 * sp16 < 4096 && K / (sp16 * 2) >= 32) sp16 *= 2;
+    }
+    return sp16;
+}
+
 }  // namespace
 
 extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
@@ -538,21 +649,15 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
     g.mask = mask; g.ldmask = ldmask; g.mask_scale = mask_scale;
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles32 = hv_cdiv(M, 32) * hv_cdiv(N, 32);
-    const int64_t a_rows = (layout == HIDVAE_GEMM_TN) ? K : M, b_rows = (layout == HIDVAE_GEMM_NT) ? N : K;
-    const bool fits32 = a_rows * lda < (1ll << 29) && b_rows * ldb < (1ll << 29);  // the direct kernel uses 32-bit BYTE offsets
+    const bool fits32 = fits32bit(layout, M, N, K, lda, ldb);
     const bool big = (tiles32 >= 4096 && K >= 64) || !fits32;  // enough tiles that LDS sharing beats per-wave operand loads
     if (!big || split_k == 1) {
         if (!big) {
             // direct path.  split_k == 1: one wave per tile, sequential (ORDER-G) chain; otherwise spread K over up to 16
             // waves of the workgroup until the chip has ~2 waves per SIMD or the chunks get shorter than 32
             // few tiles: 16x16 tiles (4x the waves, shorter dependent MFMA chains) -- the latency-optimised form
-            if (tiles32 <= 256 || (tiles32 <= 512 && K <= 256)) {
-                const int64_t tiles16 = hv_cdiv(M, 16) * hv_cdiv(N, 16);
-                int sp16 = 1;
-                if (split_k != 1) {
-                    const int cap = split_k == 0 ? 16 : split_k;
-                    while (sp16 < cap && sp16 < 16 && tiles16 * sp16 < 4096 && K / (sp16 * 2) >= 32) sp16 *= 2;
-                }
+            if (use_direct16(M, N, K)) {
+                const int sp16 = pick_split16(M, N, K, split_k);
                 const bool deep16 = K / (16 * sp16) >= 12;
                 switch (sp16) {
                     case 1: if (deep16) launch_direct16<1, 6>(layout, g, s); else launch_direct16<1, 3>(layout, g, s); break;
@@ -595,6 +700,45 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)hv_cdiv(M * N, 256)), dim3(256), 0, s, g, splits);
         HV_LAUNCH_CHECK("splitk_reduce");
     }
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
+                                 int64_t n_out, int64_t n_in, float *dW, int64_t lddw, float *dX, int64_t lddx, int dx_epilogue,
+                                 float *aux, int64_t ldaux, void *stream) {
+    HV_REQUIRE(g && x && dW && B >= 1 && n_out >= 1 && n_in >= 1, "linear_bwd: bad arguments");
+    HV_REQUIRE(ldg >= n_out && ldx >= n_in && lddw >= n_in, "linear_bwd: leading dimension too small");
+    HV_REQUIRE(dX == nullptr || (W != nullptr && ldw >= n_in && lddx >= n_in), "linear_bwd: dX needs W");
+    HV_REQUIRE(dX == nullptr || dx_epilogue == HIDVAE_EPI_NONE || (dx_epilogue >= HIDVAE_EPI_DSILU && aux != nullptr && ldaux >= n_in),
+               "linear_bwd: dX epilogue %d", dx_epilogue);
+    // dW [n_out, n_in] = g^T x : TN with M = n_out, N = n_in, K = B;   dX [B, n_in] = g W : NN with M = B, N = n_in, K = n_out
+    const bool pair = dX != nullptr && use_direct16(n_out, n_in, B) && use_direct16(B, n_in, n_out) &&
+                      fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw) &&
+                      hv_cdiv(n_out, 32) * hv_cdiv(n_in, 32) < 4096 && hv_cdiv(B, 32) * hv_cdiv(n_in, 32) < 4096;
+    if (!pair) {
+        int rc = hidvae_gemm_f32(HIDVAE_GEMM_TN, n_out, n_in, B, g, ldg, x, ldx, nullptr, dW, lddw, HIDVAE_EPI_NONE, nullptr, 0, nullptr, 0,
+                                 1.0f, 0, nullptr, 0, stream);
+        if (rc != HIDVAE_OK || dX == nullptr) return rc;
+        return hidvae_gemm_f32(HIDVAE_GEMM_NN, B, n_in, n_out, g, ldg, W, ldw, nullptr, dX, lddx, dx_epilogue, aux, ldaux, nullptr, 0, 1.0f, 0,
+                               nullptr, 0, stream);
+    }
+    PairArgs p{};
+    p.g0.M = n_out; p.g0.N = n_in; p.g0.K = B; p.g0.A = g; p.g0.lda = ldg; p.g0.B = x; p.g0.ldb = ldx; p.g0.C = dW; p.g0.ldc = lddw;
+    p.g0.epilogue = HIDVAE_EPI_NONE; p.g0.mask_scale = 1.0f;
+    p.g1.M = B; p.g1.N = n_in; p.g1.K = n_out; p.g1.A = g; p.g1.lda = ldg; p.g1.B = W; p.g1.ldb = ldw; p.g1.C = dX; p.g1.ldc = lddx;
+    p.g1.epilogue = dx_epilogue; p.g1.aux = aux; p.g1.ldaux = aux ? ldaux : 0; p.g1.mask_scale = 1.0f;
+    p.split0 = pick_split16(n_out, n_in, B, 0);
+    p.split1 = pick_split16(B, n_in, n_out, 0);
+    p.nbx0 = (int)hv_cdiv(n_in, 16);
+    p.nt0 = (int64_t)p.nbx0 * hv_cdiv(n_out, 16);
+    p.nbx1 = (int)hv_cdiv(n_in, 16);
+    p.nt1 = (int64_t)p.nbx1 * hv_cdiv(B, 16);
+    int waves = p.split0 > p.split1 ? p.split0 : p.split1;  // both splits are powers of two <= 16
+    if (waves < 4) waves = 4;
+    p.nb0 = (int)hv_cdiv(p.nt0, waves / p.split0);
+    const int nb1 = (int)hv_cdiv(p.nt1, waves / p.split1);
+    hipLaunchKernelGGL(gemm_pair16_kernel, dim3((unsigned)(p.nb0 + nb1)), dim3(64 * waves), 0, (hipStream_t)stream, p);
+    HV_LAUNCH_CHECK("linear_bwd pair");
     return HIDVAE_OK;
 }
 

@@ -432,23 +432,37 @@ __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a)
     const int d = lane & 31;
     int *list = hits[wave];
     float acc = 0.0f;
+    // operands of the epilogue are fetched first so that their latency hides behind the scan
+    const bool nrm = a.normalize[lvl] != 0;
+    const float ev = nrm ? a.E[lvl][k * D + d] : 0.0f;
+    const float cv = nrm ? a.cb_eff[row * D + d] : 0.0f;
     for (int64_t c0 = 0; c0 < a.B; c0 += 1024) {
         int n = 0;
-#pragma unroll 4
-        for (int j = 0; j < 16; j++) {
+        int64_t idv[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {  // 16 independent loads in flight
             const int64_t b = c0 + j * 64 + lane;
-            const bool hit = b < a.B && a.ids[b * a.L + lvl] == k;
+            idv[j] = b < a.B ? a.ids[b * a.L + lvl] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const bool hit = idv[j] == k;
             const unsigned long long m = __ballot(hit);
             if (hit) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (int)(j * 64 + lane);
             n += __popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
-        for (int e = 0; e < n; e++) acc += a.dE_rows[(c0 + list[e]) * ((int64_t)a.L * D) + lvl * D + d];
+        for (int e0 = 0; e0 < n; e0 += 8) {  // rows fetched eight at a time, added in ascending item order
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = e0 + j < n ? a.dE_rows[(c0 + list[e0 + j]) * ((int64_t)a.L * D) + lvl * D + d] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (e0 + j < n) acc += r[j];
+        }
         __builtin_amdgcn_wave_barrier();
     }
-    if (a.normalize[lvl]) {  // c = E / max(|E|, eps)  =>  gE = (g - c (c.g)) / max(|E|, eps)
-        const float ev = a.E[lvl][k * D + d];
-        const float cv = a.cb_eff[row * D + d];
+    if (nrm) {  // c = E / max(|E|, eps)  =>  gE = (g - c (c.g)) / max(|E|, eps)
         float n2 = ev * ev, cg = cv * acc;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) {

@@ -14,7 +14,7 @@ from torch import Tensor, nn
 
 from .. import _C
 from ..data.schemas import HRqVaeComputedLosses, HRqVaeOutput
-from ..ops import RQFn, TotalLossFn
+from ..ops import RQFn, StepLossFn, TotalLossFn  # noqa: F401
 from .encoder import MLP
 from .loss import QuantizeLoss, ReconstructionLoss, TagAlignmentLoss, TagPredictionLoss  # noqa: F401
 from .quantize import Quantize, QuantizeForwardMode
@@ -305,13 +305,13 @@ class HRqVae(nn.Module, _HubMixin):
             t.record_stream(main)
         for t in (emb_cat, ids):
             t.record_stream(side)
-        recon = ReconstructionLoss.fused(self.decoder.body(emb_sum), x)  # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0)
+        # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0) and the total loss in one launch
         # the alignment / uniqueness weights enter once inside their loss modules and once more here
         n_tag = len(tag_scalars) // 3
-        loss, uniq, stats = TotalLossFn.apply(recon, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
-                                              self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight,
-                                              self.tag_prediction_weight, self.sem_id_uniqueness_weight, n_tag, float(self.n_layers),
-                                              *tag_scalars)
+        loss, recon, uniq, stats = StepLossFn.apply(self.decoder.body(emb_sum), x, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
+                                                    self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight,
+                                                    self.tag_prediction_weight, self.sem_id_uniqueness_weight, n_tag,
+                                                    float(self.n_layers), *tag_scalars)
         main.wait_stream(side)  # the statistics above were computed beside the decoder
         zero = self._zero_scalar(x.device)
         if tagged:

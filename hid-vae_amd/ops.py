@@ -67,28 +67,16 @@ def mlp_body_forward(x, weights, keep_for_backward):
 
 
 def mlp_body_backward(saved, weights, g_y, need_input_grad):
-    """Input-gradient chain on the current stream; every weight gradient dW_j = g_j^T h_{j-1} on the side stream."""
+    """One launch per layer: dW_j = g_j^T h_{j-1} and g_{j-1} = (g_j W_j) * silu'(pre_{j-1}) share a grid (hidvae_linear_bwd)."""
     grads = [None] * len(weights)
-    main, side = torch.cuda.current_stream(), side_stream()
-    keep = []  # g_j must outlive the side-stream GEMM that reads it
     g = g_y
     for j in range(len(weights) - 1, -1, -1):
         inp, _ = saved[j]
-        w = weights[j]
-        keep.append(g)
-        keep.append(inp)  # saved activations die with the autograd node: the helper stream must be done with them first
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            grads[j] = _C.gemm(_C.GEMM_TN, g, inp, split_k=0)
-            grads[j].record_stream(main)
         if j > 0:
-            g = _C.gemm(_C.GEMM_NN, g, w, epilogue=_C.EPI_DSILU, aux=saved[j - 1][1], split_k=0)
-        elif need_input_grad:
-            g = _C.gemm(_C.GEMM_NN, g, w, split_k=0)
+            grads[j], g = _C.linear_bwd(g, inp, weights[j], True, _C.EPI_DSILU, saved[j - 1][1])
         else:
-            g = None
-    _join_after_backward()
-    return g, grads, keep
+            grads[j], g = _C.linear_bwd(g, inp, weights[j], need_input_grad)
+    return g, grads, []
 
 
 class MLPBodyFn(Function):
@@ -235,10 +223,44 @@ class TotalLossFn(Function):
         return (per_item, per_item, g_z, None, None, None, None, None, None, None, None) + tags
 
 
+class StepLossFn(Function):
+    """ReconFn + TotalLossFn as HRqVae.forward pairs them, one launch each way (hidvae_loss_fwd / hidvae_loss_bwd).
+    Inputs: decoder body output y, the batch x, then as TotalLossFn.  Returns (loss, recon, uniq, tagstats); only `loss`
+    is differentiable (the reconstruction term's gradient travels inside it)."""
+
+    @staticmethod
+    def forward(ctx, y, x, qloss, z, ids, uniq_weight, uniq_margin, w_a, w_p, w_u, n_tag, tag_div, *tag_scalars):
+        ctx.set_materialize_grads(False)
+        want = z is not None and ctx.needs_input_grad[3]
+        aligns, preds, accs = list(tag_scalars[:n_tag]), list(tag_scalars[n_tag:2 * n_tag]), list(tag_scalars[2 * n_tag:3 * n_tag])
+        loss, recon, uniq, g_rows, tagstats = _C.loss_fwd(y, x, qloss.detach(), [t.detach() for t in aligns], [t.detach() for t in preds],
+                                                          [t.detach() for t in accs], tag_div, ids, z, uniq_weight, uniq_margin, w_a,
+                                                          w_p, w_u, want)
+        ctx.meta = (y.shape[0], ids.shape[1] if ids is not None else 0, w_a, w_p, w_u, n_tag, tag_div, z is not None)
+        ctx.g_rows = g_rows
+        ctx.save_for_backward(y, x)
+        if tagstats is None:
+            tagstats = torch.empty(0, device=loss.device)
+        ctx.mark_non_differentiable(recon, uniq, tagstats)
+        return loss, recon, uniq, tagstats
+
+    @staticmethod
+    def backward(ctx, g, _g_recon, _g_uniq, _g_stats):
+        B, L, w_a, w_p, w_u, n_tag, tag_div, has_z = ctx.meta
+        if g is None:
+            return (None,) * (12 + 3 * n_tag)
+        y, x = ctx.saved_tensors
+        g_y, scal, g_z = _C.loss_bwd(g.contiguous(), y, x, L, w_a / tag_div, w_p / tag_div, w_u, ctx.g_rows,
+                                     want_gz=has_z and ctx.g_rows is not None)
+        per_item = scal[0].expand(B)  # stride-0 view: the kernels downstream read one device scalar
+        tags = (scal[1],) * n_tag + (scal[2],) * n_tag + (None,) * n_tag
+        return (g_y, None, per_item, g_z, None, None, None, None, None, None, None, None) + tags
+
+
 class LinearFn(Function):
     """y = act(x W^T + b) [* keep_mask * keep_scale]  -- nn.Linear with the activation (and dropout) fused into the GEMM
     epilogue.  act is an _C.EPI_* forward code.  Backward: g_pre = g * act'(.) through the elementwise kernel, then the
-    input gradient (NN GEMM), weight gradient (TN GEMM, split-K) and bias gradient (column sums)."""
+    input gradient (NN GEMM) and weight gradient (TN GEMM, split-K) in one paired launch, bias gradient (column sums)."""
 
     @staticmethod
     def forward(ctx, x, w, b, act, keep_mask=None, keep_scale=1.0):
@@ -262,16 +284,6 @@ class LinearFn(Function):
         g = g.contiguous()
         if ctx.act != _C.EPI_NONE or keep_mask is not None:
             g = _C.act_bwd(g, ref, ctx.act, keep_mask, ctx.keep_scale)
-        main, side = torch.cuda.current_stream(), side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):  # parameter gradients beside the input-gradient chain
-            gw = _C.gemm(_C.GEMM_TN, g, x, split_k=0)
-            gb = _C.colsum(g) if ctx.has_bias else None
-        gw.record_stream(main)
-        if gb is not None:
-            gb.record_stream(main)
-        g.record_stream(side)
-        x.record_stream(side)  # a saved tensor that may be freed as soon as this node returns
-        _join_after_backward()
-        gx = _C.gemm(_C.GEMM_NN, g, w, split_k=0) if ctx.need_x else None
+        gw, gx = _C.linear_bwd(g, x, w, ctx.need_x)  # weight and input gradients share one launch
+        gb = _C.colsum(g) if ctx.has_bias else None
         return gx, gw, gb, None, None, None

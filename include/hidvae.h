@@ -71,6 +71,18 @@ int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K,
                     const float *mask, int64_t ldmask, float mask_scale,
                     int split_k, float *workspace, int accumulate, void *stream);
 
+/* Backward of y = x W^T (nn.Linear without bias; encoder.py:27-31 as autograd differentiates it) in ONE launch:
+ *   dW [n_out, n_in] = g^T x          (g [B, n_out], x [B, n_in])
+ *   dX [B, n_in]     = epi(g W)       (W [n_out, n_in]; dx_epilogue = HIDVAE_EPI_NONE or a backward code D* whose `aux`
+ *                                      [B, n_in] is the previous layer's saved tensor, i.e. the activation derivative of the
+ *                                      layer below is applied on the way out; dX == NULL: weight gradient only)
+ * Both products are independent, so small problems share one grid (the dW tiles first, then the dX tiles) instead of paying
+ * two launches; the arithmetic, split and summation order are those of hidvae_gemm_f32(split_k = 0) on each product, so
+ * the results are bit-identical to the two separate calls.  Shapes outside the small-problem regime fall back to them. */
+int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
+                      int64_t n_out, int64_t n_in, float *dW, int64_t lddw, float *dX, int64_t lddx, int dx_epilogue,
+                      float *aux, int64_t ldaux, void *stream);
+
 /* out[n] (+)= sum_m X[m,n]   (bias gradients; fixed-order two-pass, bit-reproducible).
  * workspace: >= ceil(M/64)*N floats. */
 int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate,
@@ -156,9 +168,23 @@ int hidvae_total_loss(const float *recon, const float *qloss, int64_t B,
 int hidvae_total_loss_bwd(const float *g_loss, int64_t B, int L, float w_a, float w_p, float w_u, const float *g_rows,
                           float *scal, float *g_z, void *stream);
 
+/* The step's own pairing of the two above with the decoder tail (a3 + a14 + a1): one call forward, ONE launch backward.
+ * loss_fwd: recon[b] = |normalize(y[b]) - x[b]|^2 (encoder.py:32, loss.py:11-12) for every row, then the total loss as
+ *   hidvae_total_loss.
+ * loss_bwd: g_y = (g_loss/B) d recon/d y;  scal / g_z exactly as hidvae_total_loss_bwd. */
+int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, const float *qloss,
+                    const float *const *align_host, const float *const *pred_host, const float *const *acc_host, int n_tag,
+                    float tag_div, const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
+                    float w_p, float w_u, float *recon, float *loss, float *uniq, float *g_rows, float *tagstats,
+                    void *stream);
+int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L, float w_a, float w_p,
+                    float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, void *stream);
+
 /* ---- a13: debug statistics (h_rqvae.py:643-648) ----------------------------------------------------
  * embs_norm[b,i] = |emb_cat[b, i*32:(i+1)*32]|; *p_unique = (#distinct id tuples)/B computed by a
- * sort-free hash census (== the reference's O(B^2 L) triu expression).  scratch: >= 4*B int64. */
+ * sort-free hash census (== the reference's O(B^2 L) triu expression), one launch.
+ * scratch: 4*B + 3 int64 that the caller zero-fills ONCE when it allocates them and then leaves alone: the table is
+ * generation-tagged and the kernel resets its own counters, so consecutive calls (same B, one at a time) share it. */
 int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, int64_t B, int L,
                     float *embs_norm, float *p_unique, int64_t *scratch, void *stream);
 

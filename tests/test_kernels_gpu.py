@@ -196,6 +196,10 @@ def test_id_stats(C):
     assert abs(float(pu) - float(O.p_unique_fast(ids.cpu()))) < 1e-7
     assert abs(float(O.p_unique(ids.cpu()[:600])) - float(C.id_stats(emb[:600], ids[:600])[1])) < 1e-7
     assert H.rel_err(norms.cpu().numpy(), emb.cpu().reshape(5000, 3, 32).norm(dim=-1).numpy()) < 1e-6
+    # the census table is shared by consecutive calls of one batch size (generation-tagged, never cleared)
+    for seed, hi in ((52, 4), (53, 200), (54, 2), (55, 12), (56, 1)):
+        ids = torch.from_numpy(fill.ints((5000, 3), seed, hi)).cuda()
+        assert abs(float(C.id_stats(emb, ids)[1]) - float(O.p_unique_fast(ids.cpu()))) < 1e-7, (seed, hi)
 
 
 @pytest.mark.parametrize("name", H.case_names("kmeans"))
@@ -217,3 +221,20 @@ def test_kmeans_matches_reference_golden(C, name):
     nxt, sc, sh = torch.empty_like(c), torch.empty(desc["K"], device="cuda"), torch.empty((), device="cuda")
     C.kmeans_iter(x, c, a2, torch.zeros(desc["K"], dtype=torch.int64, device="cuda"), nxt, sc, sh)
     assert float(sh) == 0.0
+
+
+@pytest.mark.parametrize("B,n_out,n_in", [(1024, 256, 128), (1024, 32, 128), (1024, 128, 32), (96, 40, 24), (1000, 512, 256),
+                                          (1024, 768, 512), (17, 5, 3)])
+def test_linear_bwd_pair_is_bit_identical_to_two_gemms(C, B, n_out, n_in):
+    g = dev(fill.gauss((B, n_out), 70))
+    x = dev(fill.gauss((B, n_in), 71))
+    w = dev(fill.gauss((n_out, n_in), 72))
+    pre = dev(fill.gauss((B, n_in), 73))
+    for epi, aux in ((C.EPI_NONE, None), (C.EPI_DSILU, pre)):
+        dW, dX = C.linear_bwd(g, x, w, True, epi, aux)
+        assert torch.equal(dW, C.gemm(C.GEMM_TN, g, x, split_k=0))
+        assert torch.equal(dX, C.gemm(C.GEMM_NN, g, w, epilogue=epi, aux=aux, split_k=0))
+    dW, dX = C.linear_bwd(g, x, w, False)
+    assert dX is None and torch.equal(dW, C.gemm(C.GEMM_TN, g, x, split_k=0))
+    # and against fp32 torch (loose: different summation order)
+    assert H.rel_err(dW.cpu().numpy(), (g.cpu().double().T @ x.cpu().double()).float().numpy()) < 1e-5
