@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--pool", type=int, default=8, help="resident synthetic batches cycled through")
+    ap.add_argument("--dist", type=int, default=0, help="take the multi-rank code path (process group, flat gradient buffer, "
+                    "all-reduce between the two graphs) even with one rank: a rehearsal of the N>1 path on a one-GPU box")
     ap.add_argument("--kernels", type=int, default=1, help="time the dominant kernels for the roofline object (0 = skip, for profiling runs)")
     ap.add_argument("--also-tagged", type=int, default=1, help="also time the tagged step (reported as `tagged_step`)")
     return ap.parse_args()
@@ -183,9 +185,9 @@ def _cpu_steps(args, budget_s, threads):
 def cpu_baseline(args, budget_s):
     """The oracle's torch-CPU restatement of the SAME step (fwd + bwd + torch AdamW, reference op sequence incl. the
     O(B^2) p_unique_ids), timed on this host.  This is the checker being timed as a baseline, never the product.
-    Small-op PyTorch does not scale with cores, so three thread counts share the budget and the best one is reported."""
+    Small-op PyTorch does not scale with cores, so two thread counts share the budget and the best one is reported."""
     ncpu = os.cpu_count() or 8
-    tries = sorted({min(8, ncpu), min(32, ncpu), ncpu})
+    tries = sorted({min(8, ncpu), min(32, ncpu)})  # (all cores of a 100+-core host is slower still: one step took 20 s)
     best, notes = None, []
     for th in tries:
         steps, dt = _cpu_steps(args, budget_s / len(tries), th)
@@ -203,11 +205,13 @@ def run_workload(args, device, rank, world, dist):
     """Build the model + optimizer, capture one full train step in a HIP graph, time K replays.  -> (seconds, model, info)"""
     from hidvae_amd.optim import HidvaeAdamW
     m = build_model(args, device)
-    opt = HidvaeAdamW(param_groups(m, tagged=bool(args.tagged)), cosine=(400000, 7e-8), flat_grads=world > 1).prepare()
+    multi = dist is not None  # the data-parallel path (also taken with one rank under --dist 1)
+    opt = HidvaeAdamW(param_groups(m, tagged=bool(args.tagged)), cosine=(400000, 7e-8), flat_grads=multi).prepare()
     dp = None
-    if world > 1:
+    if multi:
         from hidvae_amd.parallel import DataParallel
         dp = DataParallel(m, opt.grad_buffer)
+        dp.always = bool(args.dist)
         dp.broadcast_parameters(0)  # replicas start identical (DDP semantics)
     pool_x, pool_te, pool_ti = synth_pool(args, device, rank)
     batch = types.SimpleNamespace(x=torch.empty_like(pool_x[0]))
@@ -228,11 +232,13 @@ def run_workload(args, device, rank, world, dist):
         opt.zero_grad()
         out = m(batch, gumbel_t=0.2)
         out.loss.backward(gradient=one)
+        if multi:
+            opt.grad_buffer.seal()  # inside the captured region: slots no kernel wrote in place are filled here
         last["loss"] = out.loss.detach()
 
     def step_eager():
         fwd_bwd()
-        if world > 1:
+        if multi:
             opt.grad_scale, _ = dp.allreduce()  # ONE RCCL all-reduce of the flat gradient buffer; 1/world folded into AdamW
         opt.step()
 
@@ -248,7 +254,7 @@ def run_workload(args, device, rank, world, dist):
     torch.cuda.synchronize()
     if use_graph:
         try:
-            if world > 1:  # collectives stay outside the graphs: [fwd+bwd] -> all-reduce -> [AdamW]
+            if multi:  # collectives stay outside the graphs: [fwd+bwd] -> all-reduce -> [AdamW]
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
                     fwd_bwd()
@@ -281,17 +287,17 @@ def run_workload(args, device, rank, world, dist):
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -308,8 +314,10 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist:
         import torch.distributed as dist
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     dt, m, info = run_workload(args, device, rank, world, dist)
@@ -325,6 +333,8 @@ def main():
     if rank == 0:
         if not args.kernels:  # profiling run of the step only (rocprofv3 timelines): no roofline object
             print(json.dumps({"value": args.batch * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "note": "--kernels 0"}))
+            if dist is not None:
+                dist.destroy_process_group()
             return
         ks = kernel_rooflines(args, m, device)
         # dominant kernel: rocprof (profiles/) puts ~70 % of the step in gemm_direct_kernel, and the encoder's first layer is
@@ -347,7 +357,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(line))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

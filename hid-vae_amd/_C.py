@@ -23,7 +23,7 @@ _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_floa
 
 _SIGNATURES = {
     "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _i, _vp, _i, _vp],
-    "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp],
+    "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
@@ -157,18 +157,22 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
     return out
 
 
-def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None):
+def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accumulate=False):
     """backward of y = x W^T in one launch -> (dW [n_out,n_in], dX [B,n_in] or None); dX = epilogue(g W) with a D* code + aux."""
     _f32(g, "g"), _f32(x, "x")
     B, n_out = g.shape
     n_in = x.shape[1]
     if x.shape[0] != B or (need_dx and tuple(w.shape) != (n_out, n_in)):
         raise RuntimeError(f"linear_bwd: shapes g {tuple(g.shape)} x {tuple(x.shape)} W {tuple(w.shape)}")
-    dW = torch.empty((n_out, n_in), device=g.device, dtype=torch.float32)
+    if dW is None:
+        dW = torch.empty((n_out, n_in), device=g.device, dtype=torch.float32)
+        accumulate = False
+    elif tuple(dW.shape) != (n_out, n_in) or not dW.is_contiguous():
+        raise RuntimeError(f"linear_bwd: dW slot has shape {tuple(dW.shape)}, expected {(n_out, n_in)} contiguous")
     dX = torch.empty((B, n_in), device=g.device, dtype=torch.float32) if need_dx else None
     _check(lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
-                                   _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, _p(dX), n_in, int(epilogue),
-                                   _p(aux), _row_stride(aux, "aux") if aux is not None else 0, _stream()), "hidvae_linear_bwd")
+                                   _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, int(bool(accumulate)), _p(dX), n_in,
+                                   int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, _stream()), "hidvae_linear_bwd")
     return dW, dX
 
 

@@ -704,8 +704,8 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
 }
 
 extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
-                                 int64_t n_out, int64_t n_in, float *dW, int64_t lddw, float *dX, int64_t lddx, int dx_epilogue,
-                                 float *aux, int64_t ldaux, void *stream) {
+                                 int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
+                                 int dx_epilogue, float *aux, int64_t ldaux, void *stream) {
     HV_REQUIRE(g && x && dW && B >= 1 && n_out >= 1 && n_in >= 1, "linear_bwd: bad arguments");
     HV_REQUIRE(ldg >= n_out && ldx >= n_in && lddw >= n_in, "linear_bwd: leading dimension too small");
     HV_REQUIRE(dX == nullptr || (W != nullptr && ldw >= n_in && lddx >= n_in), "linear_bwd: dX needs W");
@@ -717,14 +717,14 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
                       hv_cdiv(n_out, 32) * hv_cdiv(n_in, 32) < 4096 && hv_cdiv(B, 32) * hv_cdiv(n_in, 32) < 4096;
     if (!pair) {
         int rc = hidvae_gemm_f32(HIDVAE_GEMM_TN, n_out, n_in, B, g, ldg, x, ldx, nullptr, dW, lddw, HIDVAE_EPI_NONE, nullptr, 0, nullptr, 0,
-                                 1.0f, 0, nullptr, 0, stream);
+                                 1.0f, 0, nullptr, accumulate_dw, stream);
         if (rc != HIDVAE_OK || dX == nullptr) return rc;
         return hidvae_gemm_f32(HIDVAE_GEMM_NN, B, n_in, n_out, g, ldg, W, ldw, nullptr, dX, lddx, dx_epilogue, aux, ldaux, nullptr, 0, 1.0f, 0,
                                nullptr, 0, stream);
     }
     PairArgs p{};
     p.g0.M = n_out; p.g0.N = n_in; p.g0.K = B; p.g0.A = g; p.g0.lda = ldg; p.g0.B = x; p.g0.ldb = ldx; p.g0.C = dW; p.g0.ldc = lddw;
-    p.g0.epilogue = HIDVAE_EPI_NONE; p.g0.mask_scale = 1.0f;
+    p.g0.epilogue = HIDVAE_EPI_NONE; p.g0.mask_scale = 1.0f; p.g0.accumulate = accumulate_dw;
     p.g1.M = B; p.g1.N = n_in; p.g1.K = n_out; p.g1.A = g; p.g1.lda = ldg; p.g1.B = W; p.g1.ldb = ldw; p.g1.C = dX; p.g1.ldc = lddx;
     p.g1.epilogue = dx_epilogue; p.g1.aux = aux; p.g1.ldaux = aux ? ldaux : 0; p.g1.mask_scale = 1.0f;
     p.split0 = pick_split16(n_out, n_in, B, 0);

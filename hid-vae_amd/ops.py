@@ -48,6 +48,17 @@ def _join_after_backward():
     Variable._execution_engine.queue_callback(join_side)
 
 
+def grad_sink(p):
+    """-> (dst, accumulate).  dst is parameter p's slot in a flat gradient buffer (parallel.FlatGradBuffer) that the calling
+    backward may write in place from its own launch, or None when p has no slot (then the gradient goes back to autograd)."""
+    v = getattr(p, "_hv_view", None)
+    if v is None or not torch.is_tensor(v):
+        return None, False
+    acc = bool(p._hv_written)
+    p._hv_written = True
+    return v, acc
+
+
 def mlp_body_forward(x, weights, keep_for_backward):
     """x W0^T -> SiLU -> ... -> W_last^T  (modules/encoder.py:23-31 of the reference, no biases).
     Returns y and, for the backward, the per-layer (input, pre-activation) tensors."""
@@ -72,10 +83,12 @@ def mlp_body_backward(saved, weights, g_y, need_input_grad):
     g = g_y
     for j in range(len(weights) - 1, -1, -1):
         inp, _ = saved[j]
+        dst, acc = grad_sink(weights[j])
         if j > 0:
-            grads[j], g = _C.linear_bwd(g, inp, weights[j], True, _C.EPI_DSILU, saved[j - 1][1])
+            gw, g = _C.linear_bwd(g, inp, weights[j], True, _C.EPI_DSILU, saved[j - 1][1], dW=dst, accumulate=acc)
         else:
-            grads[j], g = _C.linear_bwd(g, inp, weights[j], need_input_grad)
+            gw, g = _C.linear_bwd(g, inp, weights[j], need_input_grad, dW=dst, accumulate=acc)
+        grads[j] = None if dst is not None else gw  # written in place: autograd has nothing to add
     return g, grads, []
 
 
@@ -160,11 +173,19 @@ class RQFn(Function):
         main, side = torch.cuda.current_stream(), side_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):  # the per-code gather runs beside the encoder's backward
-            gE = _C.codebook_grad(ids, dE, [t.detach() for t in ctx.tables], cb, flags)
+            sinks = [getattr(t, "_hv_view", None) for t in ctx.tables]
+            states = {bool(getattr(t, "_hv_written", False)) for t in ctx.tables}
+            if all(torch.is_tensor(v) for v in sinks) and len(states) == 1:  # every table owns a flat-gradient slot
+                acc = [grad_sink(t)[1] for t in ctx.tables][0]
+                _C.codebook_grad(ids, dE, [t.detach() for t in ctx.tables], cb, flags, grads=sinks, accumulate=acc)
+                gE = [None] * len(sinks)
+            else:
+                gE = _C.codebook_grad(ids, dE, [t.detach() for t in ctx.tables], cb, flags)
         for t in (dE, ids, cb):
             t.record_stream(side)
         for t in gE:
-            t.record_stream(main)
+            if t is not None:
+                t.record_stream(main)
         _join_after_backward()
         ctx.stash = None
         return (g_y, None, None, None, None, None, None, None) + tuple(gE)
@@ -272,6 +293,7 @@ class LinearFn(Function):
         y = _C.gemm(_C.GEMM_NT, x, w, bias=b, epilogue=act, aux=pre, mask=keep_mask, mask_scale=keep_scale, split_k=0)
         ctx.act, ctx.keep_scale = act, keep_scale
         ctx.has_bias = b is not None
+        ctx.w_param, ctx.b_param = w, b  # (the objects themselves: a flat-gradient slot hangs off the Parameter)
         ctx.need_x = ctx.needs_input_grad[0]
         ctx.save_for_backward(x, w, pre if pre is not None else y, keep_mask)
         return y
@@ -284,6 +306,14 @@ class LinearFn(Function):
         g = g.contiguous()
         if ctx.act != _C.EPI_NONE or keep_mask is not None:
             g = _C.act_bwd(g, ref, ctx.act, keep_mask, ctx.keep_scale)
-        gw, gx = _C.linear_bwd(g, x, w, ctx.need_x)  # weight and input gradients share one launch
-        gb = _C.colsum(g) if ctx.has_bias else None
+        dst, acc = grad_sink(ctx.w_param)
+        gw, gx = _C.linear_bwd(g, x, w, ctx.need_x, dW=dst, accumulate=acc)  # weight and input gradients share one launch
+        if dst is not None:
+            gw = None
+        gb = None
+        if ctx.has_bias:
+            bdst, bacc = grad_sink(ctx.b_param)
+            gb = _C.colsum(g, out=bdst, accumulate=bacc)
+            if bdst is not None:
+                gb = None
         return gx, gw, gb, None, None, None

@@ -98,6 +98,8 @@ class HidvaeAdamW(torch.optim.Optimizer):
         if not self._prepared:
             self._prepare_step_async()
         join_side()  # weight gradients and the step scalars may still be in flight on the helper stream
+        if self.flat_grads:
+            self.grad_buffer.seal()
         ptrs = []
         for p in self._params:
             g = p.grad

@@ -14,8 +14,15 @@ import torch.distributed as dist
 
 
 class FlatGradBuffer:
-    """One contiguous gradient buffer; every parameter's .grad is a view of it, so autograd accumulates in place and the
-    whole gradient is exchanged in a single collective (4.6 MB for the core model, 29 MB with the tag heads)."""
+    """One contiguous gradient buffer exchanged in a single collective (4.6 MB for the core model, 29 MB with the tag heads).
+
+    Protocol per optimizer step:  zero() -> backward (one or more) -> seal() -> all-reduce / optimizer.
+      * zero() launches nothing: it drops every .grad and marks every slot unwritten;
+      * operators that know the protocol (ops.grad_sink: the Linear / codebook backward kernels) write a parameter's slot IN
+        PLACE from their own launch (first write overwrites, later writes accumulate) and hand autograd no gradient;
+      * seal() makes the buffer complete: slots nobody wrote are filled from the .grad autograd produced (one copy each) or
+        zeroed, and every .grad becomes its slot, which is what the optimizer and the collective read.
+    So the usual cost of a flat buffer (a memset plus one accumulate-add launch per parameter) is not paid."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -25,26 +32,39 @@ class FlatGradBuffer:
         self.views, off = [], 0
         for p in self.params:
             n = p.numel()
-            self.views.append(self.flat[off:off + n].view_as(p))
+            v = self.flat[off:off + n].view_as(p)
+            self.views.append(v)
+            p._hv_view = v
+            p._hv_written = False
             off += n
-        self.bind()
-
-    def bind(self):
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        self._sealed = False
+        self.zero()
 
     def zero(self):
-        self.flat.zero_()
-        self.bind()
+        for p in self.params:
+            p.grad = None
+            p._hv_written = False
+        self._sealed = False
 
-    def fold_in_stray_grads(self):
-        """If someone replaced .grad (zero_grad(set_to_none=True) followed by backward), copy it back into the buffer."""
+    @torch.no_grad()
+    def seal(self):
+        if self._sealed:
+            return
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
+            if p._hv_written:
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                    v.add_(p.grad)  # a second, protocol-unaware producer of the same parameter
+            elif p.grad is None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
             p.grad = v
+            p._hv_written = True  # a further backward before the next zero() accumulates
+        self._sealed = True
+
+    def unseal(self):
+        """call before another backward of the same optimizer step (gradient accumulation)"""
+        self._sealed = False
 
 
 class DataParallel:
@@ -55,6 +75,7 @@ class DataParallel:
         self.module, self.buf, self.group = module, grad_buffer, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.always = False  # rehearsal switch: issue the collective even in a one-rank group (bench.py --dist 1)
 
     def broadcast_parameters(self, src=0):
         """DDP-style start: every replica takes rank `src`'s parameters and buffers."""
@@ -71,7 +92,8 @@ class DataParallel:
             dist.broadcast(t.data, src, group=self.group)
 
     def allreduce(self, async_op=False):
-        if self.world == 1:
+        self.buf.seal()
+        if self.world == 1 and not self.always:
             return 1.0, None
         work = dist.all_reduce(self.buf.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return 1.0 / self.world, work

@@ -78,10 +78,11 @@ int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K,
  *                                      layer below is applied on the way out; dX == NULL: weight gradient only)
  * Both products are independent, so small problems share one grid (the dW tiles first, then the dX tiles) instead of paying
  * two launches; the arithmetic, split and summation order are those of hidvae_gemm_f32(split_k = 0) on each product, so
- * the results are bit-identical to the two separate calls.  Shapes outside the small-problem regime fall back to them. */
+ * the results are bit-identical to the two separate calls.  Shapes outside the small-problem regime fall back to them.
+ * accumulate_dw: dW += g^T x (gradient accumulation straight into a flat gradient buffer's slot). */
 int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
-                      int64_t n_out, int64_t n_in, float *dW, int64_t lddw, float *dX, int64_t lddx, int dx_epilogue,
-                      float *aux, int64_t ldaux, void *stream);
+                      int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
+                      int dx_epilogue, float *aux, int64_t ldaux, void *stream);
 
 /* out[n] (+)= sum_m X[m,n]   (bias gradients; fixed-order two-pass, bit-reproducible).
  * workspace: >= ceil(M/64)*N floats. */

@@ -175,3 +175,35 @@ def test_train_steps_track_the_oracle():
         d = (sd[k].cpu() - Pc[k]).abs()
         assert float(d.max()) <= 0.5 * 2.8e-4 * steps, k        # never more than a fraction of the possible travel
         assert float(d.median()) <= 1e-6 * float(Pc[k].abs().max()) + 1e-9, k  # and the bulk agrees tightly
+
+
+def test_flat_gradient_buffer_matches_per_tensor_gradients():
+    """DP layout: the Linear / codebook backward kernels write their parameters' slots of the flat buffer in place (first write
+    overwrites, a second backward accumulates); everything else is folded in by seal().  Must equal plain autograd .grad."""
+    from hidvae_amd.parallel import FlatGradBuffer
+    fx, desc = H.load("rot_train_tag_b128")
+    cfg, P, x, te, ti = H.inputs_of(desc)
+    from hidvae_amd.rand import InjectedRand
+
+    def run(flat, passes):
+        m = build_model(cfg, P).train()
+        buf = FlatGradBuffer(list(m.parameters())) if flat else None
+        for _ in range(passes):
+            m.rand = InjectedRand(O.FormulaRand(**desc["rand"]))
+            if buf is not None:
+                buf.unseal()
+            m(make_batch(x, te, ti), gumbel_t=0.2).loss.backward()
+            if buf is not None:
+                buf.seal()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, buf
+
+    ref1, _ = run(False, 1)
+    got1, buf = run(True, 1)
+    assert set(ref1) == set(got1)
+    for k in ref1:
+        assert torch.equal(ref1[k], got1[k]), k
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(buf.params, buf.views))
+    ref2, _ = run(False, 2)   # autograd accumulates: grad = g + g
+    got2, _ = run(True, 2)
+    for k in ref2:
+        assert H.close(got2[k].cpu().numpy(), ref2[k].cpu().numpy(), 1e-6, 1e-9), k

@@ -13,8 +13,9 @@ from tests.test_model_gpu import build_model, make_batch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("flat", [False, True], ids=["per-tensor-grads", "flat-grad-buffer"])
 @pytest.mark.parametrize("name", H.case_names("train"))
-def test_three_iterations_match_the_reference_run(name):
+def test_three_iterations_match_the_reference_run(name, flat):
     """grad accumulation (2 forwards, one backward), 8 AdamW param groups with layer-specific lr / wd, cosine schedule:
     losses per iteration, final codebooks and BatchNorm buffers vs the reference's own run (train_hidvae.py:533-563,698-766)."""
     from hidvae_amd.optim import HidvaeAdamW
@@ -30,7 +31,8 @@ def test_three_iterations_match_the_reference_run(name):
     for i in range(cfg.n_layers):
         groups.append({"params": list(m.tag_predictors[i].parameters()), "lr": lr * (1 + 0.1 * i), "weight_decay": pwd / (1 + 0.2 * i)})
         groups.append({"params": list(m.tag_projectors[i].parameters()), "lr": lr * (1 + 0.1 * i), "weight_decay": pwd / (1 + 0.2 * i)})
-    opt = HidvaeAdamW(groups, cosine=(desc["T_max"], desc["eta_min"]))
+    # flat=True: the data-parallel layout (one gradient buffer; kernels write their slots in place, parallel.FlatGradBuffer)
+    opt = HidvaeAdamW(groups, cosine=(desc["T_max"], desc["eta_min"]), flat_grads=flat)
     losses = []
     for it in range(desc["iters"]):
         opt.zero_grad()
