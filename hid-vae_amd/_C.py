@@ -23,7 +23,7 @@ _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_floa
 
 _SIGNATURES = {
     "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _i, _vp, _i, _vp],
-    "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp],
+    "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _i, _vp, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
@@ -43,8 +43,9 @@ _SIGNATURES = {
     "hidvae_layernorm_fwd": [_vp, _i64, _i64, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp],
     "hidvae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp],
     "hidvae_layernorm_param_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _i, _vp, _vp],
-    "hidvae_batchnorm_fwd": [_vp, _i64, _i64, _i64, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp],
-    "hidvae_batchnorm_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp],
+    "hidvae_layernorm_bwd_all": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp],
+    "hidvae_batchnorm_fwd": [_vp, _i64, _i64, _i64, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp],
+    "hidvae_batchnorm_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp],
     "hidvae_infonce_rows": [_vp, _i64, _f, _f, _vp, _vp, _vp],
     "hidvae_infonce_dlogits": [_vp, _i64, _f, _f, _vp, _vp],
     "hidvae_tag_loss_fwd": [_vp, _i64, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -157,7 +158,7 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
     return out
 
 
-def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accumulate=False):
+def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accumulate=False, bias=False, db=None, accumulate_db=False):
     """backward of y = x W^T in one launch -> (dW [n_out,n_in], dX [B,n_in] or None); dX = epilogue(g W) with a D* code + aux."""
     _f32(g, "g"), _f32(x, "x")
     B, n_out = g.shape
@@ -170,9 +171,18 @@ def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accu
     elif tuple(dW.shape) != (n_out, n_in) or not dW.is_contiguous():
         raise RuntimeError(f"linear_bwd: dW slot has shape {tuple(dW.shape)}, expected {(n_out, n_in)} contiguous")
     dX = torch.empty((B, n_in), device=g.device, dtype=torch.float32) if need_dx else None
+    ws = None
+    if bias:
+        if db is None:
+            db = torch.empty((n_out,), device=g.device, dtype=torch.float32)
+            accumulate_db = False
+        ws = torch.empty(((B + 63) // 64 * n_out,), device=g.device, dtype=torch.float32)
     _check(lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
                                    _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, int(bool(accumulate)), _p(dX), n_in,
-                                   int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, _stream()), "hidvae_linear_bwd")
+                                   int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, _p(db if bias else None),
+                                   int(bool(accumulate_db)), _p(ws), _stream()), "hidvae_linear_bwd")
+    if bias:
+        return dW, dX, db
     return dW, dX
 
 
@@ -434,14 +444,30 @@ def layernorm_param_grad(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale)
     return gg, gb
 
 
+def layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, need_gx=True, gg=None, gb=None, accumulate=False):
+    """input + affine gradients from one pass -> (gx or None, ggamma, gbeta); gg/gb: optional destination slots"""
+    M, N = x.shape
+    gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if need_gx else None
+    if gg is None or gb is None:
+        gg = torch.empty((N,), device=x.device, dtype=torch.float32)
+        gb = torch.empty((N,), device=x.device, dtype=torch.float32)
+        accumulate = False
+    ws = torch.empty((2 * ((M + 3) // 4) * N,), device=x.device, dtype=torch.float32)
+    _check(lib().hidvae_layernorm_bwd_all(_p(gy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), M, N, int(relu), _p(mask),
+                                          float(mask_scale), _p(gx), _p(gg), _p(gb), int(bool(accumulate)), _p(ws), _stream()),
+           "hidvae_layernorm_bwd_all")
+    return gx, gg, gb
+
+
 def batchnorm_fwd(x, gamma, beta, eps, momentum, training, running_mean, running_var, relu, mask, mask_scale, num_batches=None):
     M, N = x.shape
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
     sm = torch.empty((N,), device=x.device, dtype=torch.float32) if training else None
     sr = torch.empty((N,), device=x.device, dtype=torch.float32) if training else None
+    ws = torch.empty((3 * ((M + 63) // 64) * N,), device=x.device, dtype=torch.float32) if training else None
     _check(lib().hidvae_batchnorm_fwd(_p(x), _row_stride(x, "x"), M, N, _p(gamma), _p(beta), float(eps), float(momentum), int(training),
                                       _p(running_mean), _p(running_var), _p(num_batches), _p(y), _p(sm), _p(sr), int(relu), _p(mask),
-                                      float(mask_scale), _stream()), "hidvae_batchnorm_fwd")
+                                      float(mask_scale), _p(ws), _stream()), "hidvae_batchnorm_fwd")
     return y, sm, sr
 
 
@@ -450,8 +476,9 @@ def batchnorm_bwd(gy, x, gamma, beta, save_mean, save_rstd, relu, mask, mask_sca
     gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if need_gx else None
     gg = torch.empty((N,), device=x.device, dtype=torch.float32)
     gb = torch.empty((N,), device=x.device, dtype=torch.float32)
+    ws = torch.empty((2 * ((M + 63) // 64) * N,), device=x.device, dtype=torch.float32)
     _check(lib().hidvae_batchnorm_bwd(_p(gy), _p(x), _row_stride(x, "x"), _p(gamma), _p(beta), _p(save_mean), _p(save_rstd), M, N,
-                                      int(relu), _p(mask), float(mask_scale), _p(gx), _p(gg), _p(gb), 0, _stream()), "hidvae_batchnorm_bwd")
+                                      int(relu), _p(mask), float(mask_scale), _p(gx), _p(gg), _p(gb), 0, _p(ws), _stream()), "hidvae_batchnorm_bwd")
     return gx, gg, gb
 
 

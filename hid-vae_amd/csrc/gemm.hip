@@ -241,6 +241,24 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *partial,
 }
 
 
+// one launch for the batches of a training step (M <= 16384): 32 columns x 32 row groups per workgroup, group r adds rows
+// r, r+32, ... in ascending order, the groups are combined in ascending order
+__global__ __launch_bounds__(1024) void colsum_one_kernel(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate) {
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int64_t n = (int64_t)blockIdx.x * 32 + c;
+    float s = 0.0f;
+    if (n < N)
+        for (int64_t m = rg; m < M; m += 32) s += X[m * ldx + n];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float v = red[0][c];
+        for (int j = 1; j < 32; j++) v += red[j][c];
+        out[n] = accumulate ? out[n] + v : v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // "direct" kernel for the small, L2-resident GEMMs of this model (M = batch ~ 1e3, K,N <= 768): one wave per
 // 32x32 output tile, operands loaded from global memory STRAIGHT into the MFMA operand registers (no LDS, no
@@ -482,14 +500,37 @@ struct PairArgs {
     int nbx0, nbx1;        // column tiles
     int64_t nt0, nt1;      // tiles
     int nb0;               // workgroups of problem 0 (each takes waves/split tiles)
+    int nb1;               // workgroups of problem 1; the rest of the grid sums columns of g (bias gradient), 32 per workgroup
+    const float *cs_x;     // g [rows, cols]
+    int64_t cs_ld, cs_rows, cs_cols;
+    float *cs_out;         // db [cols] (nullptr: no bias)
+    int cs_accumulate;
 };
+
+// bias gradient db[c] = sum_b g[b, c]: 32 columns per workgroup, blockDim/32 row groups, partials added in ascending group order
+__device__ __forceinline__ void colsum32_body(const PairArgs &p, int64_t c0, float *part) {
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5, nrg = (int)(blockDim.x >> 5);
+    const int64_t c = c0 + col;
+    float acc = 0.0f;
+    if (c < p.cs_cols)
+        for (int64_t r = rg; r < p.cs_rows; r += nrg) acc += p.cs_x[r * p.cs_ld + c];
+    part[rg * 32 + col] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < p.cs_cols) {
+        float v = part[col];
+        for (int j = 1; j < nrg; j++) v += part[j * 32 + col];
+        p.cs_out[c] = p.cs_accumulate ? p.cs_out[c] + v : v;
+    }
+}
 
 __global__ __launch_bounds__(1024) void gemm_pair16_kernel(PairArgs p) {
     __shared__ float part[16 * 256];
     const int bid = blockIdx.x;
     const int waves = (int)(blockDim.x >> 6);
     if (bid < p.nb0) direct16_body<HIDVAE_GEMM_TN, 3>(p.g0, p.split0, (int64_t)bid * (waves / p.split0), p.nt0, p.nbx0, part);
-    else direct16_body<HIDVAE_GEMM_NN, 3>(p.g1, p.split1, (int64_t)(bid - p.nb0) * (waves / p.split1), p.nt1, p.nbx1, part);
+    else if (bid < p.nb0 + p.nb1)
+        direct16_body<HIDVAE_GEMM_NN, 3>(p.g1, p.split1, (int64_t)(bid - p.nb0) * (waves / p.split1), p.nt1, p.nbx1, part);
+    else colsum32_body(p, (int64_t)(bid - p.nb0 - p.nb1) * 32, part);
 }
 
 // NWN > 1 (only with SPLIT == 1): the workgroup's NWN waves take NWN neighbouring column tiles of the SAME row tile, so the
@@ -703,9 +744,12 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
     return HIDVAE_OK;
 }
 
+extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate, float *workspace, void *stream);
+
 extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
                                  int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
-                                 int dx_epilogue, float *aux, int64_t ldaux, void *stream) {
+                                 int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
+                                 void *stream) {
     HV_REQUIRE(g && x && dW && B >= 1 && n_out >= 1 && n_in >= 1, "linear_bwd: bad arguments");
     HV_REQUIRE(ldg >= n_out && ldx >= n_in && lddw >= n_in, "linear_bwd: leading dimension too small");
     HV_REQUIRE(dX == nullptr || (W != nullptr && ldw >= n_in && lddx >= n_in), "linear_bwd: dX needs W");
@@ -715,9 +759,11 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
     const bool pair = dX != nullptr && use_direct16(n_out, n_in, B) && use_direct16(B, n_in, n_out) &&
                       fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw) &&
                       hv_cdiv(n_out, 32) * hv_cdiv(n_in, 32) < 4096 && hv_cdiv(B, 32) * hv_cdiv(n_in, 32) < 4096;
+    HV_REQUIRE(db == nullptr || pair || workspace != nullptr || B <= 16384, "linear_bwd: the unpaired bias gradient needs the colsum workspace");
     if (!pair) {
         int rc = hidvae_gemm_f32(HIDVAE_GEMM_TN, n_out, n_in, B, g, ldg, x, ldx, nullptr, dW, lddw, HIDVAE_EPI_NONE, nullptr, 0, nullptr, 0,
                                  1.0f, 0, nullptr, accumulate_dw, stream);
+        if (rc == HIDVAE_OK && db != nullptr) rc = hidvae_colsum(g, B, n_out, ldg, db, accumulate_db, workspace, stream);
         if (rc != HIDVAE_OK || dX == nullptr) return rc;
         return hidvae_gemm_f32(HIDVAE_GEMM_NN, B, n_in, n_out, g, ldg, W, ldw, nullptr, dX, lddx, dx_epilogue, aux, ldaux, nullptr, 0, 1.0f, 0,
                                nullptr, 0, stream);
@@ -736,17 +782,25 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
     int waves = p.split0 > p.split1 ? p.split0 : p.split1;  // both splits are powers of two <= 16
     if (waves < 4) waves = 4;
     p.nb0 = (int)hv_cdiv(p.nt0, waves / p.split0);
-    const int nb1 = (int)hv_cdiv(p.nt1, waves / p.split1);
-    hipLaunchKernelGGL(gemm_pair16_kernel, dim3((unsigned)(p.nb0 + nb1)), dim3(64 * waves), 0, (hipStream_t)stream, p);
+    p.nb1 = (int)hv_cdiv(p.nt1, waves / p.split1);
+    p.cs_x = g; p.cs_ld = ldg; p.cs_rows = B; p.cs_cols = n_out; p.cs_out = db; p.cs_accumulate = accumulate_db;
+    const int nbc = db != nullptr ? (int)hv_cdiv(n_out, 32) : 0;
+    hipLaunchKernelGGL(gemm_pair16_kernel, dim3((unsigned)(p.nb0 + p.nb1 + nbc)), dim3(64 * waves), 0, (hipStream_t)stream, p);
     HV_LAUNCH_CHECK("linear_bwd pair");
     return HIDVAE_OK;
 }
 
 extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate,
                              float *workspace, void *stream) {
-    HV_REQUIRE(X && out && workspace && M >= 1 && N >= 1 && ldx >= N, "colsum: bad arguments");
-    const int64_t chunks = hv_cdiv(M, 64);
+    HV_REQUIRE(X && out && M >= 1 && N >= 1 && ldx >= N, "colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (M <= 16384) {
+        hipLaunchKernelGGL(colsum_one_kernel, dim3((unsigned)hv_cdiv(N, 32)), dim3(1024), 0, s, X, M, N, ldx, out, accumulate);
+        HV_LAUNCH_CHECK("colsum_one");
+        return HIDVAE_OK;
+    }
+    HV_REQUIRE(workspace != nullptr, "colsum: M > 16384 needs the workspace");
+    const int64_t chunks = hv_cdiv(M, 64);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)hv_cdiv(N, 64), (unsigned)chunks), dim3(256), 0, s, X, M, N,
                        ldx, workspace);
     HV_LAUNCH_CHECK("colsum_partial");

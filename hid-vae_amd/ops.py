@@ -307,13 +307,14 @@ class LinearFn(Function):
         if ctx.act != _C.EPI_NONE or keep_mask is not None:
             g = _C.act_bwd(g, ref, ctx.act, keep_mask, ctx.keep_scale)
         dst, acc = grad_sink(ctx.w_param)
-        gw, gx = _C.linear_bwd(g, x, w, ctx.need_x, dW=dst, accumulate=acc)  # weight and input gradients share one launch
-        if dst is not None:
-            gw = None
-        gb = None
-        if ctx.has_bias:
+        if ctx.has_bias:  # weight, input and bias gradients share one launch
             bdst, bacc = grad_sink(ctx.b_param)
-            gb = _C.colsum(g, out=bdst, accumulate=bacc)
+            gw, gx, gb = _C.linear_bwd(g, x, w, ctx.need_x, dW=dst, accumulate=acc, bias=True, db=bdst, accumulate_db=bacc)
             if bdst is not None:
                 gb = None
+        else:
+            gw, gx = _C.linear_bwd(g, x, w, ctx.need_x, dW=dst, accumulate=acc)
+            gb = None
+        if dst is not None:
+            gw = None
         return gx, gw, gb, None, None, None

@@ -73,6 +73,7 @@ class LayerNormFn(Function):
         y, mean, rstd = _C.layernorm_fwd(x, gamma, beta, eps, relu, mask, mask_scale, residual)
         ctx.save_for_backward(x, gamma, beta, mean, rstd, mask)
         ctx.cfg = (relu, mask_scale, residual is not None)
+        ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
 
     @staticmethod
@@ -82,17 +83,15 @@ class LayerNormFn(Function):
         x, gamma, beta, mean, rstd, mask = ctx.saved_tensors
         relu, mask_scale, has_res = ctx.cfg
         gy = gy.contiguous()
-        main, side = torch.cuda.current_stream(), side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):  # the affine gradients are off the critical path
-            gg, gb = _C.layernorm_param_grad(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale)
-        for t in (gg, gb):
-            t.record_stream(main)
-        for t in (gy, x, mean, rstd, mask):  # read by the helper stream; saved tensors die when this node returns
-            if t is not None:
-                t.record_stream(side)
-        _join_after_backward()
-        gx = _C.layernorm_bwd(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale) if ctx.needs_input_grad[0] else None
+        from .ops import grad_sink
+        gdst, gacc = grad_sink(ctx.gamma_param)
+        bdst, bacc = grad_sink(ctx.beta_param)
+        if gdst is None or bdst is None or gacc != bacc:
+            gdst = bdst = None
+        gx, gg, gb = _C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, need_gx=ctx.needs_input_grad[0],
+                                          gg=gdst, gb=bdst, accumulate=gacc)
+        if gdst is not None:
+            gg = gb = None
         return gx, gg, gb, None, None, None, None, (gy if has_res else None)
 
 

@@ -79,13 +79,16 @@ int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K,
  * Both products are independent, so small problems share one grid (the dW tiles first, then the dX tiles) instead of paying
  * two launches; the arithmetic, split and summation order are those of hidvae_gemm_f32(split_k = 0) on each product, so
  * the results are bit-identical to the two separate calls.  Shapes outside the small-problem regime fall back to them.
- * accumulate_dw: dW += g^T x (gradient accumulation straight into a flat gradient buffer's slot). */
+ * accumulate_dw: dW += g^T x (gradient accumulation straight into a flat gradient buffer's slot).
+ * db (optional): the bias gradient db[n_out] = column sums of g, from the same launch (fixed summation order; the fallback
+ * uses hidvae_colsum and needs its workspace of ceil(B/64)*n_out floats). */
 int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
                       int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
-                      int dx_epilogue, float *aux, int64_t ldaux, void *stream);
+                      int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
+                      void *stream);
 
-/* out[n] (+)= sum_m X[m,n]   (bias gradients; fixed-order two-pass, bit-reproducible).
- * workspace: >= ceil(M/64)*N floats. */
+/* out[n] (+)= sum_m X[m,n]   (bias gradients; fixed summation order, bit-reproducible).  One launch for M <= 16384 (no
+ * workspace needed, may be NULL); above that two fixed-order passes through workspace >= ceil(M/64)*N floats. */
 int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate,
                   float *workspace, void *stream);
 
@@ -231,17 +234,24 @@ int hidvae_layernorm_param_grad(const float *gy, const float *x, const float *ga
                                 const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask,
                                 float keep_scale, float *ggamma, float *gbeta, int accumulate, float *workspace,
                                 void *stream);
+/* both of the above from one pass over (gy, x) + the fixed-order finish: gx (optional), ggamma, gbeta.
+ * workspace: 2 * ceil(M/4) * N floats (2 * ceil(M/128) * N suffices when N > 1024, where the separate kernels run). */
+int hidvae_layernorm_bwd_all(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
+                             const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask, float keep_scale,
+                             float *gx, float *ggamma, float *gbeta, int accumulate, float *workspace, void *stream);
 /* BatchNorm1d (h_rqvae.py:325): y = dropout(relu?(BN(x))).  training != 0: batch statistics (biased variance for the
  * normalisation, unbiased for the running update with `momentum`), saved mean / rstd for the backward;
- * training == 0: running statistics.  num_batches_tracked (optional int64 device scalar) is incremented in training. */
+ * training == 0: running statistics.  num_batches_tracked (optional int64 device scalar) is incremented in training.
+ * workspace (3*ceil(M/64)*N floats forward, 2*ceil(M/64)*N backward): selects the row-parallel form (per-chunk statistics merged
+ * with Chan's update in ascending chunk order, then a row-parallel apply launch); NULL: one workgroup per 32 columns. */
 int hidvae_batchnorm_fwd(const float *x, int64_t ldx, int64_t M, int64_t N, const float *gamma, const float *beta, float eps,
                          float momentum, int training, float *running_mean, float *running_var,
                          int64_t *num_batches_tracked, float *y, float *save_mean, float *save_rstd, int relu,
-                         const float *keep_mask, float keep_scale, void *stream);
+                         const float *keep_mask, float keep_scale, float *workspace, void *stream);
 int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx, const float *gamma, const float *beta,
                          const float *save_mean, const float *save_rstd, int64_t M, int64_t N, int relu,
                          const float *keep_mask, float keep_scale, float *gx, float *ggamma, float *gbeta, int accumulate,
-                         void *stream);
+                         float *workspace, void *stream);
 /* InfoNCE (loss.py:54-85) on the similarity matrix S = normalize(c) normalize(t)^T [B,B] produced by hidvae_gemm_f32:
  * rows: loss = scale * mean_b( logsumexp_j(S_bj/tau) - S_bb/tau ), S overwritten by softmax(S/tau);
  * dlogits: P <- (g*scale/(B*tau)) (P - I) in place, g a device scalar -- feed it to two GEMMs for d c / d t. */

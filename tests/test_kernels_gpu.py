@@ -236,5 +236,11 @@ def test_linear_bwd_pair_is_bit_identical_to_two_gemms(C, B, n_out, n_in):
         assert torch.equal(dX, C.gemm(C.GEMM_NN, g, w, epilogue=epi, aux=aux, split_k=0))
     dW, dX = C.linear_bwd(g, x, w, False)
     assert dX is None and torch.equal(dW, C.gemm(C.GEMM_TN, g, x, split_k=0))
+    dW2, dX2, db = C.linear_bwd(g, x, w, True, bias=True)  # bias gradient from the same launch
+    assert torch.equal(dW2, dW) and torch.equal(dX2, C.gemm(C.GEMM_NN, g, w, split_k=0))
+    assert H.close(db.cpu().numpy(), g.cpu().double().sum(0).float().numpy(), 1e-5, 1e-5)
+    slot = torch.ones(n_out, device="cuda")
+    C.linear_bwd(g, x, w, True, bias=True, db=slot, accumulate_db=True)
+    assert H.close(slot.cpu().numpy(), 1.0 + g.cpu().double().sum(0).float().numpy(), 1e-5, 1e-5)
     # and against fp32 torch (loose: different summation order)
     assert H.rel_err(dW.cpu().numpy(), (g.cpu().double().T @ x.cpu().double()).float().numpy()) < 1e-5
