@@ -285,6 +285,10 @@ class HRqVae(nn.Module, _HubMixin):
         tagged = tags_emb is not None and tags_indices is not None
         self._gumbel_t = gumbel_t
 
+        if self.training and tagged:
+            r = self._rand()
+            if hasattr(r, "begin_step"):
+                r.begin_step(x.device)  # all dropout keep-masks of the step from one launch (rand.DeviceRand)
         self._prepared = self._prepare_codebooks_async()  # effective codebooks + |c|^2 on the helper stream, beside the encoder
         y = self.encoder.body(x)  # the encoder's l2norm (codebook_normalize) happens in the RQ prologue
         z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)

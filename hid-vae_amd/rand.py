@@ -8,31 +8,84 @@ import torch
 
 
 class DeviceRand:
-    """Production provider: everything is drawn on the device with no host synchronisation (graph-capturable)."""
+    """Production provider: everything is drawn on the device with no host synchronisation (graph-capturable).
+
+    A training step asks for ~25 dropout masks of fixed shapes and rates and one mixup pairing per level; drawn one by one that
+    is ~70 tiny launches, each at the ~5 us launch floor.  So the provider learns the step's request list once (begin_step()
+    .. the requests that follow) and from then on draws ALL keep-masks with ONE torch.bernoulli over a cached per-element
+    keep-probability vector and hands out views; the pairings of all levels are computed together (mixup_all)."""
 
     def __init__(self, mixup_alpha=0.2):
         self.mixup_alpha = mixup_alpha
         self._beta = None
+        self._plan = None      # [(numel, shape, p)] learned from the first step
+        self._probs = None     # per-element keep probability of the arena
+        self._record = None    # requests seen since begin_step() while learning
+        self._arena = None
+        self._cursor = 0
+        self._mix = None       # per-level (partner, inverse, lam) of the current step
+
+    # ---- step protocol (optional: without begin_step() every request is an individual draw)
+    def begin_step(self, device):
+        self._mix = None
+        if self._record is not None and self._record:  # the previous step was the learning step
+            self._plan = self._record
+            self._probs = torch.cat([torch.full((n,), 1.0 - p, device=device, dtype=torch.float32) for n, _, p in self._plan])
+        self._record = [] if self._plan is None else None
+        if self._plan is not None:
+            self._arena = torch.bernoulli(self._probs)  # one launch for every keep-mask of the step
+            self._cursor, self._offset = 0, 0
+        return self
 
     def dropout_keep(self, shape, p, device):
-        return torch.empty(tuple(shape), device=device, dtype=torch.float32).bernoulli_(1.0 - p)
+        shape = tuple(int(d) for d in shape)
+        n = 1
+        for d in shape:
+            n *= d
+        if self._record is not None:
+            self._record.append((n, shape, float(p)))
+        elif self._plan is not None and self._arena is not None and self._cursor < len(self._plan) \
+                and self._plan[self._cursor] == (n, shape, float(p)):
+            view = self._arena[self._offset:self._offset + n].view(shape)
+            self._cursor += 1
+            self._offset += n
+            return view
+        elif self._plan is not None:  # the step changed shape (another batch size, eval in between): learn again
+            self._plan, self._arena, self._record = None, None, None
+        return torch.empty(shape, device=device, dtype=torch.float32).bernoulli_(1.0 - p)
 
-    def mixup_partner(self, target, device):
-        """Random pairing of the VALID rows (target >= 0) among themselves, as loss.py:144 does on the compacted rows:
-        partner[b] = row mixed into b, inverse[partner[b]] = b, -1 on invalid rows; lam ~ Beta(alpha, alpha) (device)."""
-        B = target.shape[0]
-        valid = target >= 0
-        keys = torch.rand(B, device=device)
-        keys = torch.where(valid, keys, torch.full_like(keys, 2.0))
-        order = torch.argsort(keys)  # valid rows first, in random order
-        rank = torch.cumsum(valid.to(torch.int64), 0) - 1  # position of each valid row among the valid rows
-        partner = torch.where(valid, order[rank.clamp(min=0)], torch.full_like(rank, -1))
-        inv_ext = torch.full((B + 1,), -1, dtype=torch.int64, device=device)
-        inv_ext.scatter_(0, torch.where(valid, partner, torch.full_like(partner, B)), torch.arange(B, device=device))
+    def _lam(self, device, n):
         if self._beta is None:  # built once (a host->device scalar copy is not allowed inside a graph capture)
             a = torch.tensor(self.mixup_alpha, device=device)
             self._beta = torch.distributions.Beta(a, a)
-        return partner, inv_ext[:B].contiguous(), self._beta.sample().to(torch.float32)
+        return self._beta.sample((n,)).to(torch.float32)
+
+    def mixup_all(self, targets, device):
+        """targets [B, L] -> per level (partner, inverse, lam), every op batched over the levels.
+        Random pairing of the VALID rows (target >= 0) among themselves, as loss.py:144 does on the compacted rows:
+        partner[b] = row mixed into b, inverse[partner[b]] = b, -1 on invalid rows; lam ~ Beta(alpha, alpha) (device)."""
+        t = targets.t()  # [L, B]
+        L, B = t.shape
+        valid = t >= 0
+        keys = torch.rand((L, B), device=device)
+        keys = torch.where(valid, keys, torch.full_like(keys, 2.0))
+        order = torch.argsort(keys, dim=1)  # valid rows first, in random order
+        rank = torch.cumsum(valid.to(torch.int64), 1) - 1  # position of each valid row among the valid rows
+        partner = torch.where(valid, torch.gather(order, 1, rank.clamp(min=0)), torch.full_like(rank, -1))
+        inv_ext = torch.full((L, B + 1), -1, dtype=torch.int64, device=device)
+        inv_ext.scatter_(1, torch.where(valid, partner, torch.full_like(partner, B)), torch.arange(B, device=device).expand(L, B))
+        inverse = inv_ext[:, :B].contiguous()
+        partner = partner.contiguous()
+        lam = self._lam(device, L)
+        return [(partner[i], inverse[i], lam[i]) for i in range(L)]
+
+    def prepare_mixup(self, targets, device):
+        self._mix = self.mixup_all(targets, device)
+
+    def mixup_partner(self, target, device, level=None):
+        if level is not None and self._mix is not None:
+            return self._mix[level]
+        return self.mixup_all(target.unsqueeze(1), device)[0]
 
     def gumbel_u(self, shape, device):
         return torch.rand(tuple(shape), device=device, dtype=torch.float32)
@@ -48,7 +101,7 @@ class InjectedRand:
     def dropout_keep(self, shape, p, device):
         return self.source.dropout_keep(shape, p).to(device)
 
-    def mixup_partner(self, target, device):
+    def mixup_partner(self, target, device, level=None):
         t = target.cpu().numpy()
         vidx = np.nonzero(t >= 0)[0]
         if len(vidx) <= 1:  # the reference draws nothing then (loss.py:123-125, :139)

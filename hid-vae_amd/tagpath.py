@@ -230,7 +230,7 @@ def tag_predictor_forward(pred, x, x_gate=None, rand=None):
     return _lin(c, cl[7])
 
 
-def tag_prediction_loss(loss_mod, logits, target, layer_idx=0, rand=None):
+def tag_prediction_loss(loss_mod, logits, target, layer_idx=0, rand=None, level=None):
     """TagPredictionLoss.forward of the reference (loss.py:107-228); layer_idx only selects focal_params keys."""
     from .rand import DeviceRand
     rand = rand or loss_mod.rand or DeviceRand(loss_mod.mixup_alpha)
@@ -244,7 +244,7 @@ def tag_prediction_loss(loss_mod, logits, target, layer_idx=0, rand=None):
         smooth = min(0.25, loss_mod.label_smoothing_alpha + gamma * 0.015 + min(0.3, 0.05 * (C / 100)))
     partner = inverse = lam = None
     if loss_mod.use_mixup and grad_mode and logits.shape[0] > 1:  # loss.py:139-147
-        partner, inverse, lam = rand.mixup_partner(target, logits.device)
+        partner, inverse, lam = rand.mixup_partner(target, logits.device, level)
     ce_ls = min(0.25, 0.05 + layer_idx * 0.06)
     return TagPredLossFn.apply(logits.contiguous(), target.contiguous(), partner, inverse, lam, bool(loss_mod.use_focal_loss),
                                float(gamma), float(alpha), float(smooth), float(ce_ls))
@@ -260,12 +260,15 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
     te = tags_emb.reshape(B, -1)  # [B, L_tags*768]: level i is the column block i (a strided view, no copy)
     E = model.tag_embed_dim
     aligns, preds, accs = [], [], []
+    lm = model.tag_prediction_loss
+    if training and torch.is_grad_enabled() and lm.use_mixup and B > 1 and hasattr(rand, "prepare_mixup"):
+        rand.prepare_mixup(tags_indices[:, :L], emb_cat.device)  # the pairings of all levels from one batched set of launches
     for i in range(L):
         c_nce, c_att, c_gate = views[3 * i], views[3 * i + 1], views[3 * i + 2]
         proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
         aligns.append(model.tag_alignment_loss(c_nce, proj, i))
         logits = tag_predictor_forward(model.tag_predictors[i], c_att, c_gate, rand)
-        loss, acc = tag_prediction_loss(model.tag_prediction_loss, logits, tags_indices[:, i].contiguous(), 0, rand)
+        loss, acc = tag_prediction_loss(model.tag_prediction_loss, logits, tags_indices[:, i].contiguous(), 0, rand, level=i)
         preds.append(loss)
         accs.append(acc)
     return tuple(aligns) + tuple(preds) + tuple(accs)

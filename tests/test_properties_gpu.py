@@ -113,3 +113,43 @@ def test_training_step_is_bitwise_reproducible():
     assert torch.equal(outs[0][0], outs[1][0])
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_device_rand_provider_properties():
+    """The production randomness provider (no golden can pin a device RNG stream): the mixup pairing is a permutation of the
+    valid rows among themselves with a consistent inverse, lam lies in (0,1), keep-masks are 0/1 with the requested rate, and the
+    one-launch mask arena hands out exactly the shapes the learning step saw (and falls back when the request list changes)."""
+    from hidvae_amd.rand import DeviceRand
+    dev = torch.device("cuda")
+    r = DeviceRand(0.2)
+    g = torch.Generator().manual_seed(5)
+    tg = torch.randint(0, 7, (500, 3), generator=g)
+    tg[torch.rand(500, generator=g) < 0.3, 1] = -1
+    tg[:, 2] = -1
+    tg[7, 2] = 3  # a level with a single valid row
+    tgd = tg.to(dev)
+    for level, (partner, inverse, lam) in enumerate(r.mixup_all(tgd, dev)):
+        p, inv, t = partner.cpu(), inverse.cpu(), tg[:, level]
+        valid = t >= 0
+        assert (p[~valid] == -1).all() and (inv[~valid] == -1).all()
+        assert sorted(p[valid].tolist()) == sorted(torch.nonzero(valid).flatten().tolist())  # a permutation of the valid rows
+        assert (inv[p[valid]] == torch.nonzero(valid).flatten()).all()
+        assert 0.0 <= float(lam) <= 1.0
+    r.prepare_mixup(tgd, dev)
+    assert r.mixup_partner(tgd[:, 1], dev, level=1)[0].shape == (500,)
+    single = r.mixup_partner(tgd[:, 0], dev)
+    assert sorted(single[0].cpu().tolist()) == list(range(500))
+
+    reqs = [((256, 512), 0.1), ((256, 128), 0.3), ((256, 64), 0.05)]
+    for step in range(4):
+        r.begin_step(dev)
+        masks = [r.dropout_keep(s, p, dev) for s, p in reqs]
+        for (s, p), m in zip(reqs, masks):
+            assert tuple(m.shape) == s and m.is_contiguous()
+            assert set(torch.unique(m).cpu().tolist()) <= {0.0, 1.0}
+            assert abs(float(m.mean()) - (1 - p)) < 0.02
+        if step >= 2:  # learnt in step 0, arena from step 1 on: the views tile one buffer
+            assert masks[1].data_ptr() == masks[0].data_ptr() + 4 * masks[0].numel()
+    r.begin_step(dev)
+    odd = r.dropout_keep((100, 512), 0.1, dev)  # a different request list: individual draw, plan dropped
+    assert tuple(odd.shape) == (100, 512) and r._plan is None
