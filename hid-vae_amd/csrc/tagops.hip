@@ -261,23 +261,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *g
     }
 }
 
-// 64 columns x 4 chunk groups per workgroup: group q adds chunks q, q+4, ... in ascending order, then (g0+g1)+(g2+g3)
-__global__ __launch_bounds__(256) void layernorm_param_final_kernel(const float *part, int64_t chunks, int64_t N, float *ggamma,
-                                                                    float *gbeta, int accumulate) {
-    __shared__ float red[2][4][64];
-    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+// 32 columns x 32 chunk groups per workgroup: group q adds chunks q, q+32, ... in ascending order, then the groups are added
+// in ascending order (the fused backward leaves one partial per 4 rows, so depth matters more than work here)
+__global__ __launch_bounds__(1024) void layernorm_param_final_kernel(const float *part, int64_t chunks, int64_t N, float *ggamma,
+                                                                     float *gbeta, int accumulate) {
+    __shared__ float red[2][32][33];
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int64_t n = (int64_t)blockIdx.x * 32 + c;
     float a = 0.0f, b = 0.0f;
     if (n < N)
-        for (int64_t k = q; k < chunks; k += 4) { a += part[(k * 2 + 0) * N + n]; b += part[(k * 2 + 1) * N + n]; }
+        for (int64_t k = q; k < chunks; k += 32) { a += part[(k * 2 + 0) * N + n]; b += part[(k * 2 + 1) * N + n]; }
     red[0][q][c] = a;
     red[1][q][c] = b;
     __syncthreads();
-    if (q == 0 && n < N) {
-        a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-        b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
-        ggamma[n] = accumulate ? ggamma[n] + a : a;
-        gbeta[n] = accumulate ? gbeta[n] + b : b;
+    if (q < 2 && n < N) {  // wave 0: lanes 0-31 finish gamma, lanes 32-63 finish beta
+        float v = red[q][0][c];
+        for (int j = 1; j < 32; j++) v += red[q][j][c];
+        float *dst = q == 0 ? ggamma : gbeta;
+        dst[n] = accumulate ? dst[n] + v : v;
     }
 }
 
@@ -861,7 +862,7 @@ extern "C" int hidvae_layernorm_param_grad(const float *gy, const float *x, cons
     hipLaunchKernelGGL(layernorm_param_partial_kernel, dim3((unsigned)hv_cdiv(N, 64), (unsigned)chunks), dim3(256), 0, s, gy, x, gamma,
                        beta, mean, rstd, M, N, relu, keep_mask, keep_scale, workspace);
     HV_LAUNCH_CHECK("layernorm_param_partial");
-    hipLaunchKernelGGL(layernorm_param_final_kernel, dim3((unsigned)hv_cdiv(N, 64)), dim3(256), 0, s, workspace, chunks, N, ggamma,
+    hipLaunchKernelGGL(layernorm_param_final_kernel, dim3((unsigned)hv_cdiv(N, 32)), dim3(1024), 0, s, workspace, chunks, N, ggamma,
                        gbeta, accumulate);
     HV_LAUNCH_CHECK("layernorm_param_final");
     return HIDVAE_OK;
@@ -885,7 +886,7 @@ extern "C" int hidvae_layernorm_bwd_all(const float *gy, const float *x, const f
     hipLaunchKernelGGL(layernorm_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 0, s, gy, x, gamma, beta, mean, rstd, M, N, relu,
                        keep_mask, keep_scale, gx, workspace);
     HV_LAUNCH_CHECK("layernorm_bwd_fused");
-    hipLaunchKernelGGL(layernorm_param_final_kernel, dim3((unsigned)hv_cdiv(N, 64)), dim3(256), 0, s, workspace, chunks, N, ggamma,
+    hipLaunchKernelGGL(layernorm_param_final_kernel, dim3((unsigned)hv_cdiv(N, 32)), dim3(1024), 0, s, workspace, chunks, N, ggamma,
                        gbeta, accumulate);
     HV_LAUNCH_CHECK("layernorm_param_final");
     return HIDVAE_OK;
