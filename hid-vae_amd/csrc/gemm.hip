@@ -304,6 +304,20 @@ __device__ __forceinline__ void load_tail(__amdgpu_buffer_rsrc_t rsrc, int ld4, 
     }
 }
 
+// XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), and every XCD has its own
+// L2: with the identity mapping each XCD touches every row block and every column block, so each L2 pulls its own copy of both
+// operands (PMC, round 1: 26.6 MB fetched for 4.7 MB of operands on the encoder's first layer).  Remapping dispatch slot i to
+// tile (i % 8) * (T/8) + i / 8 gives XCD j the j-th contiguous eighth of the row-major tile list, i.e. a band of rows: its L2
+// then holds one eighth of A and all of B.  A bijection when T % 8 == 0, otherwise the identity is kept.
+__device__ __forceinline__ void xcd_tile(int nbx, int nby, int &bx, int &by) {
+    const int total = nbx * nby;
+    if ((total & 7) != 0) return;
+    const int id = by * nbx + bx;
+    const int t = (id & 7) * (total >> 3) + (id >> 3);
+    by = t / nbx;
+    bx = t - by * nbx;
+}
+
 // ---- 16x16 tiles (v_mfma_f32_16x16x4_f32): lane = (i = lane&15, q = lane>>4) supplies k = k0 + 4q + s at step s.
 // Four times as many waves as the 32x32 form for the same problem and a 40-cycle dependent chain per 4 k instead of 64 per
 // 2 k: this is the latency-optimised form the small-batch GEMMs of the step use.
@@ -335,7 +349,9 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_direct16_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63;
     const int w = SPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.y * 16, n0 = (int64_t)blockIdx.x * 16;
+    int bx = blockIdx.x, by = blockIdx.y;
+    xcd_tile(gridDim.x, gridDim.y, bx, by);
+    const int64_t m0 = (int64_t)by * 16, n0 = (int64_t)bx * 16;
     const int64_t ra = (m0 + i16 < g.M) ? m0 + i16 : g.M - 1;
     const int64_t rb = (n0 + i16 < g.N) ? n0 + i16 : g.N - 1;
     const int va = 4 * (A_KC ? (int)(ra * g.lda) + 4 * q : (int)(4 * q * g.lda + ra));
@@ -547,7 +563,9 @@ __global__ __launch_bounds__(64 * SPLIT * NWN) void gemm_direct_kernel(GemmArgs 
     const int w = SPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i32 = lane & 31, h = lane >> 5;
     const int wn = NWN == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = ((int64_t)blockIdx.x * NWN + wn) * 32;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (NWN == 1) xcd_tile(gridDim.x, gridDim.y, bx, by);
+    const int64_t m0 = (int64_t)by * 32, n0 = ((int64_t)bx * NWN + wn) * 32;
     if (NWN > 1 && n0 >= g.N) return;  // (no barrier follows in the unsplit kernel)
     const int64_t ra = (m0 + i32 < g.M) ? m0 + i32 : g.M - 1;
     const int64_t rb = (n0 + i32 < g.N) ? n0 + i32 : g.N - 1;
@@ -628,6 +646,90 @@ __global__ __launch_bounds__(64 * SPLIT * NWN) void gemm_direct_kernel(GemmArgs 
     }
 }
 
+// the 32x32-tile twin of direct16_body / gemm_pair16_kernel: same arithmetic as gemm_direct_kernel with a run-time split
+template <int LAYOUT, int NS>
+__device__ __forceinline__ void direct32_body(const GemmArgs &g, int split, int64_t tile0, int64_t ntiles, int nbx, float *part) {
+    constexpr bool A_KC = (LAYOUT != HIDVAE_GEMM_TN);
+    constexpr bool B_KC = (LAYOUT == HIDVAE_GEMM_NT);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tw = wv / split, w = wv - tw * split;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int64_t tile = tile0 + tw;
+    if (tile < ntiles) {
+        const int64_t m0 = (tile / nbx) * 32, n0 = (tile % nbx) * 32;
+        const int64_t ra = (m0 + i32 < g.M) ? m0 + i32 : g.M - 1;
+        const int64_t rb = (n0 + i32 < g.N) ? n0 + i32 : g.N - 1;
+        const int va = 4 * (A_KC ? (int)(ra * g.lda) + 4 * h : (int)(4 * h * g.lda + ra));
+        const int vb = 4 * (B_KC ? (int)(rb * g.ldb) + 4 * h : (int)(4 * h * g.ldb + rb));
+        const int lda4 = (int)g.lda * 4, ldb4 = (int)g.ldb * 4, Ki = (int)g.K;
+        const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(g.A), 0, (int)(4 * (A_KC ? (g.M - 1) * g.lda + g.K : (g.K - 1) * g.lda + g.M)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(g.B), 0, (int)(4 * (B_KC ? (g.N - 1) * g.ldb + g.K : (g.K - 1) * g.ldb + g.N)), 0x00020000);
+        const int nfull = Ki / 16;
+        const int b_lo = nfull * w / split, b_hi = nfull * (w + 1) / split;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        float ra_[NS][8], rb_[NS][8];
+        auto load = [&](float (&av)[8], float (&bv)[8], int blk) {
+            const bool in = blk < b_hi;
+            load_block<A_KC>(ra_rsrc, lda4, in ? va : HV_OOB, blk * 16, av);
+            load_block<B_KC>(rb_rsrc, ldb4, in ? vb : HV_OOB, blk * 16, bv);
+        };
+#pragma unroll
+        for (int st = 0; st < NS - 1; st++) load(ra_[st], rb_[st], b_lo + st);
+        for (int blk = b_lo; blk < b_hi; blk += NS) {
+#pragma unroll
+            for (int st = 0; st < NS; st++) {
+                load(ra_[(st + NS - 1) % NS], rb_[(st + NS - 1) % NS], blk + st + NS - 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[st][s8], rb_[st][s8], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (w == split - 1 && nfull * 16 < Ki) {
+            load_tail<A_KC>(ra_rsrc, lda4, va, nfull * 16, Ki, h, ra_[0]);
+            load_tail<B_KC>(rb_rsrc, ldb4, vb, nfull * 16, Ki, h, rb_[0]);
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[0][s8], rb_[0][s8], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) part[wv * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i32] = acc[r];
+    }
+    __syncthreads();
+    const float *mk = g.mask;
+    const int groups = (int)(blockDim.x >> 6) / split;
+    for (int e = threadIdx.x; e < groups * 1024; e += blockDim.x) {
+        const int t = e >> 10, ee = e & 1023;
+        const int64_t tl = tile0 + t;
+        if (tl >= ntiles) break;
+        float v = part[(t * split) * 1024 + ee];
+        for (int sidx = 1; sidx < split; sidx++) v += part[(t * split + sidx) * 1024 + ee];  // fixed order: bit-reproducible
+        const int64_t row = (tl / nbx) * 32 + (ee >> 5), col = (tl % nbx) * 32 + (ee & 31);
+        if (row >= g.M || col >= g.N) continue;
+        v += g.bias != nullptr ? g.bias[col] : 0.0f;
+        if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+        if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+        float *dst = g.C + row * g.ldc + col;
+        *dst = g.accumulate ? *dst + v : v;
+    }
+}
+
+template <int NS1>
+__global__ __launch_bounds__(512) void gemm_pair32_kernel(PairArgs p) {
+    __shared__ float part[8 * 1024];
+    const int bid = blockIdx.x;
+    const int waves = (int)(blockDim.x >> 6);
+    if (bid < p.nb0) direct32_body<HIDVAE_GEMM_TN, 3>(p.g0, p.split0, (int64_t)bid * (waves / p.split0), p.nt0, p.nbx0, part);
+    else if (bid < p.nb0 + p.nb1)
+        direct32_body<HIDVAE_GEMM_NN, NS1>(p.g1, p.split1, (int64_t)(bid - p.nb0) * (waves / p.split1), p.nt1, p.nbx1, part);
+    else colsum32_body(p, (int64_t)(bid - p.nb0 - p.nb1) * 32, part);
+}
+
 template <int SPLIT, int NS, int NWN = 1>
 void launch_direct(int layout, const GemmArgs &g, hipStream_t s) {
     dim3 grid((unsigned)hv_cdiv(hv_cdiv(g.N, 32), NWN), (unsigned)hv_cdiv(g.M, 32));
@@ -656,6 +758,15 @@ inline bool fits32bit(int layout, int64_t M, int64_t N, int64_t K, int64_t lda, 
 inline bool use_direct16(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles32 = hv_cdiv(M, 32) * hv_cdiv(N, 32);
     return tiles32 <= 256 || (tiles32 <= 512 && K <= 256);
+}
+inline int pick_split32(int64_t M, int64_t N, int64_t K, int split_k) {
+    const int64_t tiles32 = hv_cdiv(M, 32) * hv_cdiv(N, 32);
+    int sp = 1;
+    if (split_k != 1) {
+        const int cap = split_k == 0 ? 16 : split_k;
+        while (sp < cap && sp < 16 && tiles32 * sp < 2048 && K / (sp * 2) >= 32) sp *= 2;
+    }
+    return sp;
 }
 inline int pick_split16(int64_t M, int64_t N, int64_t K, int split_k) {
     const int64_t tiles16 = hv_cdiv(M, 16) * hv_cdiv(N, 16);
@@ -710,11 +821,7 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
                 HV_LAUNCH_CHECK("gemm_f32 direct16");
                 return HIDVAE_OK;
             }
-            int sp = 1;
-            if (split_k != 1) {
-                const int cap = split_k == 0 ? 16 : split_k;
-                while (sp < cap && sp < 16 && tiles32 * sp < 2048 && K / (sp * 2) >= 32) sp *= 2;
-            }
+            const int sp = pick_split32(M, N, K, split_k);
             const bool deep = K / (16 * sp) >= 12;  // long chains per wave: keep 5 blocks of loads in flight instead of 2
             switch (sp) {
                 case 1: if (deep) launch_direct<1, 6>(layout, g, s); else launch_direct<1, 3>(layout, g, s); break;
@@ -756,9 +863,12 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
     HV_REQUIRE(dX == nullptr || dx_epilogue == HIDVAE_EPI_NONE || (dx_epilogue >= HIDVAE_EPI_DSILU && aux != nullptr && ldaux >= n_in),
                "linear_bwd: dX epilogue %d", dx_epilogue);
     // dW [n_out, n_in] = g^T x : TN with M = n_out, N = n_in, K = B;   dX [B, n_in] = g W : NN with M = B, N = n_in, K = n_out
-    const bool pair = dX != nullptr && use_direct16(n_out, n_in, B) && use_direct16(B, n_in, n_out) &&
-                      fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw) &&
-                      hv_cdiv(n_out, 32) * hv_cdiv(n_in, 32) < 4096 && hv_cdiv(B, 32) * hv_cdiv(n_in, 32) < 4096;
+    const bool small = dX != nullptr && fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw) &&
+                       hv_cdiv(n_out, 32) * hv_cdiv(n_in, 32) < 4096 && hv_cdiv(B, 32) * hv_cdiv(n_in, 32) < 4096;
+    const bool pair16 = small && use_direct16(n_out, n_in, B) && use_direct16(B, n_in, n_out);
+    const int s32_0 = pick_split32(n_out, n_in, B, 0), s32_1 = pick_split32(B, n_in, n_out, 0);
+    const bool pair32 = small && !use_direct16(n_out, n_in, B) && !use_direct16(B, n_in, n_out) && s32_0 <= 8 && s32_1 <= 8;
+    const bool pair = pair16 || pair32;
     HV_REQUIRE(db == nullptr || pair || workspace != nullptr || B <= 16384, "linear_bwd: the unpaired bias gradient needs the colsum workspace");
     if (!pair) {
         int rc = hidvae_gemm_f32(HIDVAE_GEMM_TN, n_out, n_in, B, g, ldg, x, ldx, nullptr, dW, lddw, HIDVAE_EPI_NONE, nullptr, 0, nullptr, 0,
@@ -773,19 +883,23 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
     p.g0.epilogue = HIDVAE_EPI_NONE; p.g0.mask_scale = 1.0f; p.g0.accumulate = accumulate_dw;
     p.g1.M = B; p.g1.N = n_in; p.g1.K = n_out; p.g1.A = g; p.g1.lda = ldg; p.g1.B = W; p.g1.ldb = ldw; p.g1.C = dX; p.g1.ldc = lddx;
     p.g1.epilogue = dx_epilogue; p.g1.aux = aux; p.g1.ldaux = aux ? ldaux : 0; p.g1.mask_scale = 1.0f;
-    p.split0 = pick_split16(n_out, n_in, B, 0);
-    p.split1 = pick_split16(B, n_in, n_out, 0);
-    p.nbx0 = (int)hv_cdiv(n_in, 16);
-    p.nt0 = (int64_t)p.nbx0 * hv_cdiv(n_out, 16);
-    p.nbx1 = (int)hv_cdiv(n_in, 16);
-    p.nt1 = (int64_t)p.nbx1 * hv_cdiv(B, 16);
-    int waves = p.split0 > p.split1 ? p.split0 : p.split1;  // both splits are powers of two <= 16
+    const int T = pair16 ? 16 : 32;
+    p.split0 = pair16 ? pick_split16(n_out, n_in, B, 0) : s32_0;
+    p.split1 = pair16 ? pick_split16(B, n_in, n_out, 0) : s32_1;
+    p.nbx0 = (int)hv_cdiv(n_in, T);
+    p.nt0 = (int64_t)p.nbx0 * hv_cdiv(n_out, T);
+    p.nbx1 = (int)hv_cdiv(n_in, T);
+    p.nt1 = (int64_t)p.nbx1 * hv_cdiv(B, T);
+    int waves = p.split0 > p.split1 ? p.split0 : p.split1;  // both splits are powers of two (<= 16, <= 8 for 32x32 tiles)
     if (waves < 4) waves = 4;
     p.nb0 = (int)hv_cdiv(p.nt0, waves / p.split0);
     p.nb1 = (int)hv_cdiv(p.nt1, waves / p.split1);
     p.cs_x = g; p.cs_ld = ldg; p.cs_rows = B; p.cs_cols = n_out; p.cs_out = db; p.cs_accumulate = accumulate_db;
     const int nbc = db != nullptr ? (int)hv_cdiv(n_out, 32) : 0;
-    hipLaunchKernelGGL(gemm_pair16_kernel, dim3((unsigned)(p.nb0 + p.nb1 + nbc)), dim3(64 * waves), 0, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)(p.nb0 + p.nb1 + nbc)), block(64 * waves);
+    if (pair16) hipLaunchKernelGGL(gemm_pair16_kernel, grid, block, 0, (hipStream_t)stream, p);
+    else if (n_out / (16 * p.split1) >= 12) hipLaunchKernelGGL(gemm_pair32_kernel<6>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_pair32_kernel<3>, grid, block, 0, (hipStream_t)stream, p);
     HV_LAUNCH_CHECK("linear_bwd pair");
     return HIDVAE_OK;
 }

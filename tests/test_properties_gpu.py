@@ -91,6 +91,13 @@ def test_corpus_sized_launch_against_oracle_sample(C):
     # eval outputs are codebook rows: gathering them by id must reproduce emb_cat exactly
     for i in range(L):
         assert torch.equal(emb_cat[:, i * 32:(i + 1) * 32], cb[i][ids[:, i]])
+    # the training (rotation-trick) form of the same large-batch kernel variant (16 waves per workgroup), sampled likewise
+    M = 1 << 17
+    z, ids, emb_cat, emb_sum, _, qloss = C.rq_forward(y[:M], cb, cc, True, 3, True, 0.4)
+    pick = torch.arange(0, M, 331, device="cuda")
+    want = exact.rq_forward(y[pick].cpu().numpy(), [t.cpu().numpy() for t in tabs], True, True, 3, True, 0.4)
+    for got, key in ((ids, "ids"), (z, "z"), (emb_cat, "emb_cat"), (emb_sum, "emb_sum"), (qloss, "loss")):
+        assert np.array_equal(got[pick].cpu().numpy(), want[key]), key
 
 
 def test_training_step_is_bitwise_reproducible():
