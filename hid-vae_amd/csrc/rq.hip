@@ -261,8 +261,16 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
                 }
             }
             float e[8];
-            load8(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 8 * q, e);
-            const float cce = a.cc[(int64_t)i * a.K + bidx];
+            float cce;
+            if (RESIDENT) {  // the winning row is already in LDS (same floats as cb_eff): no dependent trip to L2
+                const float *Cl = lds + i * lvl_floats;
+#pragma unroll
+                for (int j = 0; j < 8; j++) e[j] = Cl[(8 * q + j) * LDK + bidx];
+                cce = Cl[32 * LDK + bidx];
+            } else {
+                load8(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 8 * q, e);
+                cce = a.cc[(int64_t)i * a.K + bidx];
+            }
             float o[8], u[8], qv[8], w[8];
             level_output<MODE, TRAIN>(r, e, xx, cce, o, u, qv, w);
             float df[8];
