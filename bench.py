@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--dist", type=int, default=0, help="take the multi-rank code path (process group, flat gradient buffer, "
                     "all-reduce between the two graphs) even with one rank: a rehearsal of the N>1 path on a one-GPU box")
     ap.add_argument("--kernels", type=int, default=1, help="time the dominant kernels for the roofline object (0 = skip, for profiling runs)")
+    ap.add_argument("--also-large", type=int, default=8192, help="also time the same step at this per-GPU batch (reported as "
+                    "`large_batch_step`; 0 = skip): shows the throughput-bound regime next to the latency-bound headline batch")
     ap.add_argument("--also-tagged", type=int, default=1, help="also time the tagged step (reported as `tagged_step`)")
     return ap.parse_args()
 
@@ -151,6 +153,24 @@ def kernel_rooflines(args, m, device):
     out.append(dict(kernel="rq_forward_kernel at 1,048,576 items (corpus-sized launch)", bound="hbm", achieved=algb / t * 1e-3,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=algb / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t, algorithmic_bytes=algb,
                     mfma_f32_frac=2.0 * big * L * K * 32 / t * 1e-6 / MFMA_F32_PEAK_TF, items_per_s=big / t * 1e6))
+    return out
+
+
+def pmc_traffic():
+    """{kernel-name prefix: bytes per launch} from profiles/*_pmc_hbm_traffic.csv (FETCH_SIZE doubled as the guide prescribes for
+    gfx950, + WRITE_SIZE; both in KB in the file).  The counters need their own rocprofv3 passes, so they cannot be taken live
+    here; absent file -> {} and `traffic` stays null."""
+    import csv
+    import glob
+    out = {}
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_hbm_traffic.csv")))
+    if not files:
+        return out
+    try:
+        for row in csv.DictReader(open(files[-1])):
+            out[row["bench_kernel_prefix"]] = (2.0 * float(row["FETCH_SIZE_KB"]) + float(row["WRITE_SIZE_KB"])) * 1024.0
+    except Exception:  # noqa: BLE001  a malformed evidence file must not break the bench
+        return {}
     return out
 
 
@@ -330,6 +350,13 @@ def main():
                             hip_graph=tinfo["hip_graph"],
                             workload="same shapes + tag heads (projector, InfoNCE, predictor, focal+mixup), amazon gin hyper-parameters")
 
+    large_extra = None
+    if world == 1 and dist is None and not args.tagged and args.also_large and args.kernels:
+        largs = argparse.Namespace(**{**vars(args), "batch": args.also_large, "steps": max(20, args.steps // 5), "warmup": 5, "pool": 2})
+        ldt, _, linfo = run_workload(largs, device, rank, world, dist)
+        large_extra = dict(batch=largs.batch, value=largs.batch * largs.steps / ldt, unit="items/s", ms_per_step=ldt / largs.steps * 1e3,
+                           steps=largs.steps, hip_graph=linfo["hip_graph"])
+
     if rank == 0:
         if not args.kernels:  # profiling run of the step only (rocprofv3 timelines): no roofline object
             print(json.dumps({"value": args.batch * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "note": "--kernels 0"}))
@@ -340,6 +367,11 @@ def main():
         # dominant kernel: rocprof (profiles/) puts ~70 % of the step in gemm_direct_kernel, and the encoder's first layer is
         # its single largest launch
         roof = ks[0]
+        pmc = pmc_traffic()
+        for k in ks:  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of exactly these launches (profiles/)
+            for key, val in pmc.items():
+                if k["kernel"].startswith(key):
+                    k["traffic"] = val
         line = {
             "metric": "item-embeddings/sec HiD-VAE train step, 768-d in, 3x256 codebooks",
             "value": args.batch * world * args.steps / dt, "unit": "items/s", "n_gpus": world, "steps": args.steps,
@@ -354,6 +386,8 @@ def main():
         }
         if tagged_extra is not None:
             line["tagged_step"] = tagged_extra
+        if large_extra is not None:
+            line["large_batch_step"] = large_extra
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(line))

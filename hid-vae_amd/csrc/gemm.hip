@@ -309,13 +309,20 @@ __device__ __forceinline__ void load_tail(__amdgpu_buffer_rsrc_t rsrc, int ld4, 
 // operands (PMC, round 1: 26.6 MB fetched for 4.7 MB of operands on the encoder's first layer).  Remapping dispatch slot i to
 // tile (i % 8) * (T/8) + i / 8 gives XCD j the j-th contiguous eighth of the row-major tile list, i.e. a band of rows: its L2
 // then holds one eighth of A and all of B.  A bijection when T % 8 == 0, otherwise the identity is kept.
-__device__ __forceinline__ void xcd_tile(int nbx, int nby, int &bx, int &by) {
+// The band runs along the LONGER output dimension (rows if M >= N, else columns), so the operand that is split eight ways is
+// the larger one and the replicated one the smaller.
+__device__ __forceinline__ void xcd_tile(int nbx, int nby, bool row_bands, int &bx, int &by) {
     const int total = nbx * nby;
     if ((total & 7) != 0) return;
     const int id = by * nbx + bx;
     const int t = (id & 7) * (total >> 3) + (id >> 3);
-    by = t / nbx;
-    bx = t - by * nbx;
+    if (row_bands) {
+        by = t / nbx;
+        bx = t - by * nbx;
+    } else {
+        bx = t / nby;
+        by = t - bx * nby;
+    }
 }
 
 // ---- 16x16 tiles (v_mfma_f32_16x16x4_f32): lane = (i = lane&15, q = lane>>4) supplies k = k0 + 4q + s at step s.
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_direct16_kernel(GemmArgs g) {
     const int w = SPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
     int bx = blockIdx.x, by = blockIdx.y;
-    xcd_tile(gridDim.x, gridDim.y, bx, by);
+    xcd_tile(gridDim.x, gridDim.y, g.M >= g.N, bx, by);
     const int64_t m0 = (int64_t)by * 16, n0 = (int64_t)bx * 16;
     const int64_t ra = (m0 + i16 < g.M) ? m0 + i16 : g.M - 1;
     const int64_t rb = (n0 + i16 < g.N) ? n0 + i16 : g.N - 1;
@@ -510,6 +517,11 @@ __device__ __forceinline__ void direct16_body(const GemmArgs &g, int split, int6
     }
 }
 
+// workgroup slot -> slot of the XCD's contiguous band (see xcd_tile); tiles are listed row-major, so bands are row bands
+__device__ __forceinline__ int xcd_slot(int slot, int nslots) {
+    return (nslots & 7) == 0 ? (slot & 7) * (nslots >> 3) + (slot >> 3) : slot;
+}
+
 struct PairArgs {
     GemmArgs g0, g1;       // g0: TN (dW = g^T x), g1: NN (dX = g W)
     int split0, split1;    // waves per tile
@@ -543,9 +555,9 @@ __global__ __launch_bounds__(1024) void gemm_pair16_kernel(PairArgs p) {
     __shared__ float part[16 * 256];
     const int bid = blockIdx.x;
     const int waves = (int)(blockDim.x >> 6);
-    if (bid < p.nb0) direct16_body<HIDVAE_GEMM_TN, 3>(p.g0, p.split0, (int64_t)bid * (waves / p.split0), p.nt0, p.nbx0, part);
+    if (bid < p.nb0) direct16_body<HIDVAE_GEMM_TN, 3>(p.g0, p.split0, (int64_t)xcd_slot(bid, p.nb0) * (waves / p.split0), p.nt0, p.nbx0, part);
     else if (bid < p.nb0 + p.nb1)
-        direct16_body<HIDVAE_GEMM_NN, 3>(p.g1, p.split1, (int64_t)(bid - p.nb0) * (waves / p.split1), p.nt1, p.nbx1, part);
+        direct16_body<HIDVAE_GEMM_NN, 3>(p.g1, p.split1, (int64_t)xcd_slot(bid - p.nb0, p.nb1) * (waves / p.split1), p.nt1, p.nbx1, part);
     else colsum32_body(p, (int64_t)(bid - p.nb0 - p.nb1) * 32, part);
 }
 
@@ -564,7 +576,7 @@ __global__ __launch_bounds__(64 * SPLIT * NWN) void gemm_direct_kernel(GemmArgs 
     const int i32 = lane & 31, h = lane >> 5;
     const int wn = NWN == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bx = blockIdx.x, by = blockIdx.y;
-    if (NWN == 1) xcd_tile(gridDim.x, gridDim.y, bx, by);
+    if (NWN == 1) xcd_tile(gridDim.x, gridDim.y, g.M >= g.N, bx, by);
     const int64_t m0 = (int64_t)by * 32, n0 = ((int64_t)bx * NWN + wn) * 32;
     if (NWN > 1 && n0 >= g.N) return;  // (no barrier follows in the unsplit kernel)
     const int64_t ra = (m0 + i32 < g.M) ? m0 + i32 : g.M - 1;
@@ -724,9 +736,9 @@ __global__ __launch_bounds__(512) void gemm_pair32_kernel(PairArgs p) {
     __shared__ float part[8 * 1024];
     const int bid = blockIdx.x;
     const int waves = (int)(blockDim.x >> 6);
-    if (bid < p.nb0) direct32_body<HIDVAE_GEMM_TN, 3>(p.g0, p.split0, (int64_t)bid * (waves / p.split0), p.nt0, p.nbx0, part);
+    if (bid < p.nb0) direct32_body<HIDVAE_GEMM_TN, 3>(p.g0, p.split0, (int64_t)xcd_slot(bid, p.nb0) * (waves / p.split0), p.nt0, p.nbx0, part);
     else if (bid < p.nb0 + p.nb1)
-        direct32_body<HIDVAE_GEMM_NN, NS1>(p.g1, p.split1, (int64_t)(bid - p.nb0) * (waves / p.split1), p.nt1, p.nbx1, part);
+        direct32_body<HIDVAE_GEMM_NN, NS1>(p.g1, p.split1, (int64_t)xcd_slot(bid - p.nb0, p.nb1) * (waves / p.split1), p.nt1, p.nbx1, part);
     else colsum32_body(p, (int64_t)(bid - p.nb0 - p.nb1) * 32, part);
 }
 

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) of
+tools/profile_kernels.py into the evidence file bench.py reads:
+    python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> > profiles/rNN_quoted_kernels_pmc_hbm_traffic.csv
+Values are RAW counter averages per launch in KB (on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads;
+bench.py doubles it, the file does not)."""
+import csv
+import glob
+import re
+import sys
+from collections import defaultdict
+
+# bench.py kernel-name prefix  <-  (substring of the profiled kernel name, grid size in work-items)
+QUOTED = [
+    ("gemm_direct_kernel<NT,1,6> encoder layer 0", "gemm_direct_kernel<0, 1, 6", None),
+    ("gemm_direct_kernel<TN,8,3> dW encoder layer 0", "gemm_direct_kernel<2, 8, 3", None),
+    ("rq_forward_kernel (fused L-level VQ, code-split variant)", "rq_forward_kernel<3, true, true, true", None),
+    ("rq_forward_kernel at 1,048,576 items", "rq_forward_kernel<3, true, true, false", None),
+]
+
+
+def averages(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        acc[(name, r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch, n = averages(sys.argv[1], "FETCH_SIZE")
+    write, _ = averages(sys.argv[2], "WRITE_SIZE")
+    w = csv.writer(sys.stdout)
+    w.writerow(["bench_kernel_prefix", "kernel", "grid_work_items", "launches", "FETCH_SIZE_KB", "WRITE_SIZE_KB"])
+    for prefix, sub, _ in QUOTED:
+        keys = [k for k in fetch if sub in k[0]]
+        if not keys:
+            continue
+        k = max(keys, key=lambda kk: int(kk[1]))  # the quoted launch is the largest grid of that instantiation
+        w.writerow([prefix, k[0], k[1], n[k], f"{fetch[k]:.1f}", f"{write.get(k, 0.0):.1f}"])
+
+
+if __name__ == "__main__":
+    main()

@@ -25,9 +25,13 @@ tabs = [(torch.rand(K, 32, device=dev) * 2 - 1) * (1.0 if i == 0 else 0.35 * 0.5
 cb, cc = _C.codebook_prepare(tabs, [i == 0 for i in range(L)])
 y_small = torch.randn(B, 32, device=dev)
 y_big = torch.randn(1 << 20, 32, device=dev)
+w1 = torch.randn(256, 512, device=dev) * 0.03
+pre = torch.randn(B, 512, device=dev)
+g1 = torch.randn(B, 256, device=dev)
 for _ in range(10):
     _C.gemm(_C.GEMM_NT, x, w0, out=o0, epilogue=_C.EPI_SILU, aux=a0)
     _C.gemm(_C.GEMM_TN, g, x, out=gw, split_k=0)
+    _C.linear_bwd(g1, o0, w1, True, _C.EPI_DSILU, pre)  # the paired dW + dX launch of encoder layer 1
     _C.rq_forward(y_small, cb, cc, True, 3, True, 0.4)
 for _ in range(5):
     _C.rq_forward(y_big, cb, cc, True, 3, True, 0.4)
