@@ -27,6 +27,8 @@ _SIGNATURES = {
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "hidvae_bottleneck_fwd": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp,
+                              _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _vp],
     "hidvae_uniq_loss": [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
     "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
@@ -230,6 +232,35 @@ def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=Fa
                                    float(beta), _p(z), _p(ids), _p(emb_cat), L * EMBED_DIM, _p(emb_sum), _p(res), _p(qloss),
                                    _stream()), "hidvae_rq_forward")
     return z if z is not None else y, ids, emb_cat, emb_sum, res, qloss
+
+
+def bottleneck_eligible(B, K2, N2, Nd0, Nd1, L, K):
+    """the fused middle-of-the-step launch: small batches, widths the kernel keeps in LDS, codebooks resident beside them"""
+    Kp = (K + 127) // 128 * 128
+    lds = L * (33 * Kp + 64) * 4 + (2 * 16 * 64 + 2 * 64) * 16
+    return (B <= 4096 and all(v % 16 == 0 and v >= 16 for v in (K2, N2, Nd0, Nd1)) and max(K2, N2, Nd0) <= 256 and Kp <= 1024
+            and lds <= 160 * 1024 - 1024)
+
+
+def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1):
+    """-> dict of every tensor the launch writes (see include/hidvae.h)"""
+    _f32(h1, "h1")
+    B, K2 = h1.shape
+    N2, Nd0, Nd1 = W2.shape[0], Wd0.shape[0], Wd1.shape[0]
+    L, K, _ = cb_eff.shape
+    dev = h1.device
+    f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    o = dict(pre2=f(B, N2), h2=f(B, N2), y=f(B, EMBED_DIM), z=f(B, EMBED_DIM), ids=torch.empty((B, L), device=dev, dtype=torch.int64),
+             emb_cat=f(B, L * EMBED_DIM), emb_sum=f(B, EMBED_DIM), qloss=f(B), pre_d0=f(B, Nd0), d0=f(B, Nd0), pre_d1=f(B, Nd1), d1=f(B, Nd1))
+    if not (h1.is_contiguous() and W2.is_contiguous() and W3.is_contiguous() and Wd0.is_contiguous() and Wd1.is_contiguous()):
+        raise RuntimeError("bottleneck_fwd: operands must be contiguous")
+    if tuple(W2.shape) != (N2, K2) or tuple(W3.shape) != (EMBED_DIM, N2) or tuple(Wd0.shape) != (Nd0, EMBED_DIM) or tuple(Wd1.shape) != (Nd1, Nd0):
+        raise RuntimeError("bottleneck_fwd: layer shapes do not chain")
+    _check(lib().hidvae_bottleneck_fwd(_p(h1), B, K2, N2, _p(W2), _p(W3), _p(o["pre2"]), _p(o["h2"]), _p(o["y"]), int(bool(normalize_input)),
+                                       _p(cb_eff), _p(cc), L, K, int(mode), float(beta), _p(o["z"]), _p(o["ids"]), _p(o["emb_cat"]),
+                                       L * EMBED_DIM, _p(o["emb_sum"]), _p(o["qloss"]), Nd0, Nd1, _p(Wd0), _p(Wd1), _p(o["pre_d0"]),
+                                       _p(o["d0"]), _p(o["pre_d1"]), _p(o["d1"]), _stream()), "hidvae_bottleneck_fwd")
+    return o
 
 
 def rq_backward(y, z, cb_eff, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z_in, gq, gq_items):

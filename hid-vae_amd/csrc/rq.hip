@@ -161,6 +161,111 @@ __device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl
 // the four (distance, index) candidates meet in LDS and are merged in ascending-quarter order (so equal distances still
 // resolve to the lowest index), then every wave carries on with the same residual.  4x more workgroups, 4x shorter
 // search per wave; results are bit-identical to the unsplit kernel.
+// The level loop for one 16-item tile held as r[8] per lane (see the geometry note at the top): argmin per level, output,
+// loss, residual update, stores of ids / emb_cat / res_cat.  r is consumed; esum and loss are returned in registers.
+template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT>
+__device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, float (*cand_d)[4][16], int (*cand_i)[4][16], int &phase,
+                                              int wave, int it, int q, int64_t item, bool valid, float (&r)[8], float (&esum)[8],
+                                              float &loss) {
+    const int LDK = a.KC + 2;
+    const int lvl_floats = 32 * LDK + a.KC;
+    loss = 0.0f;
+    for (int i = 0; i < a.L; i++) {
+        if (a.res_cat != nullptr && valid) store8(a.res_cat + item * (a.L * D) + i * D + 8 * q, r);
+        const float xx = dotQ(r, r);
+        float best = INFINITY;
+        int bidx = 0;
+        for (int c = 0; c < a.nchunks; c++) {
+            const float *Cs;
+            if (RESIDENT) {
+                Cs = lds + i * lvl_floats;
+            } else {
+                __syncthreads();  // previous chunk fully consumed
+                stage_codes(lds, a, i, c * a.KC);
+                __syncthreads();
+                Cs = lds;
+            }
+            const float *ccs = Cs + 32 * LDK;
+            const float *arow = Cs + (8 * q) * LDK + it;
+            const int cbase = c * a.KC + 4 * q;
+            // two 16-code tiles per iteration: two independent accumulator chains keep the MFMA pipe full
+            const int t_lo = CSPLIT ? wave * (a.KC / 4) : 0, t_hi = CSPLIT ? (wave + 1) * (a.KC / 4) : a.KC;
+            for (int t = t_lo; t < t_hi; t += 32) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float a0 = arow[j * LDK + t];
+                    const float a1 = arow[j * LDK + t + 16];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, r[j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, r[j], acc1, 0, 0, 0);
+                }
+                const float4 c0 = *reinterpret_cast<const float4 *>(ccs + t + 4 * q);
+                const float4 c1 = *reinterpret_cast<const float4 *>(ccs + t + 16 + 4 * q);
+                const float cc0[4] = {c0.x, c0.y, c0.z, c0.w};
+                const float cc1[4] = {c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                for (int g = 0; g < 4; g++) {  // ascending code index inside the lane: strict < keeps the first min
+                    const float d0 = fmaf(-2.0f, acc0[g], xx + cc0[g]);
+                    if (d0 < best) { best = d0; bidx = cbase + t + g; }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float d1 = fmaf(-2.0f, acc1[g], xx + cc1[g]);
+                    if (d1 < best) { best = d1; bidx = cbase + t + 16 + g; }
+                }
+            }
+        }
+        // combine the 4 quarter-lanes of the item; equal distances resolve to the lowest code index
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        }
+        if (CSPLIT) {  // merge the four code quarters (double-buffered by level parity: one barrier per level)
+            const int pb = phase & 1;
+            phase++;
+            if (q == 0) { cand_d[pb][wave][it] = best; cand_i[pb][wave][it] = bidx; }
+            __syncthreads();
+            best = cand_d[pb][0][it];
+            bidx = cand_i[pb][0][it];
+#pragma unroll
+            for (int ww = 1; ww < 4; ww++) {
+                const float ob = cand_d[pb][ww][it];
+                const int oi = cand_i[pb][ww][it];
+                if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            }
+        }
+        float e[8];
+        float cce;
+        if (RESIDENT) {  // the winning row is already in LDS (same floats as cb_eff): no dependent trip to L2
+            const float *Cl = lds + i * lvl_floats;
+#pragma unroll
+            for (int j = 0; j < 8; j++) e[j] = Cl[(8 * q + j) * LDK + bidx];
+            cce = Cl[32 * LDK + bidx];
+        } else {
+            load8(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 8 * q, e);
+            cce = a.cc[(int64_t)i * a.K + bidx];
+        }
+        float o[8], u[8], qv[8], w[8];
+        level_output<MODE, TRAIN>(r, e, xx, cce, o, u, qv, w);
+        float df[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) df[j] = r[j] - e[j];
+        const float l1 = dotQ(df, df);  // loss.py:41-44: both terms are numerically |r-e|^2
+        loss = loss + (l1 + a.beta * l1);
+        if (valid) {
+            if (q == 0) a.ids[item * a.L + i] = (int64_t)bidx;
+            if (a.emb_cat != nullptr) store8(a.emb_cat + item * a.ld_cat + i * D + 8 * q, o);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            esum[j] = (i == 0) ? o[j] : esum[j] + o[j];
+            r[j] = r[j] - o[j];
+        }
+    }
+}
+
 template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT, int NW>
 __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -192,107 +297,148 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
             for (int j = 0; j < 8; j++) r[j] = r[j] / den;
         }
         if (a.z != nullptr && valid) store8(a.z + item * D + 8 * q, r);
-        float loss = 0.0f;
+        float loss;
         float esum[8];
-        for (int i = 0; i < a.L; i++) {
-            if (a.res_cat != nullptr && valid) store8(a.res_cat + item * (a.L * D) + i * D + 8 * q, r);
-            const float xx = dotQ(r, r);
-            float best = INFINITY;
-            int bidx = 0;
-            for (int c = 0; c < a.nchunks; c++) {
-                const float *Cs;
-                if (RESIDENT) {
-                    Cs = lds + i * lvl_floats;
-                } else {
-                    __syncthreads();  // previous chunk fully consumed
-                    stage_codes(lds, a, i, c * a.KC);
-                    __syncthreads();
-                    Cs = lds;
-                }
-                const float *ccs = Cs + 32 * LDK;
-                const float *arow = Cs + (8 * q) * LDK + it;
-                const int cbase = c * a.KC + 4 * q;
-                // two 16-code tiles per iteration: two independent accumulator chains keep the MFMA pipe full
-                const int t_lo = CSPLIT ? wave * (a.KC / 4) : 0, t_hi = CSPLIT ? (wave + 1) * (a.KC / 4) : a.KC;
-                for (int t = t_lo; t < t_hi; t += 32) {
-                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const float a0 = arow[j * LDK + t];
-                        const float a1 = arow[j * LDK + t + 16];
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, r[j], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, r[j], acc1, 0, 0, 0);
-                    }
-                    const float4 c0 = *reinterpret_cast<const float4 *>(ccs + t + 4 * q);
-                    const float4 c1 = *reinterpret_cast<const float4 *>(ccs + t + 16 + 4 * q);
-                    const float cc0[4] = {c0.x, c0.y, c0.z, c0.w};
-                    const float cc1[4] = {c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {  // ascending code index inside the lane: strict < keeps the first min
-                        const float d0 = fmaf(-2.0f, acc0[g], xx + cc0[g]);
-                        if (d0 < best) { best = d0; bidx = cbase + t + g; }
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const float d1 = fmaf(-2.0f, acc1[g], xx + cc1[g]);
-                        if (d1 < best) { best = d1; bidx = cbase + t + 16 + g; }
-                    }
-                }
-            }
-            // combine the 4 quarter-lanes of the item; equal distances resolve to the lowest code index
-#pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
-                const float ob = __shfl_xor(best, o);
-                const int oi = __shfl_xor(bidx, o);
-                if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-            }
-            if (CSPLIT) {  // merge the four code quarters (double-buffered by level parity: one barrier per level)
-                const int pb = phase & 1;
-                phase++;
-                if (q == 0) { cand_d[pb][wave][it] = best; cand_i[pb][wave][it] = bidx; }
-                __syncthreads();
-                best = cand_d[pb][0][it];
-                bidx = cand_i[pb][0][it];
-#pragma unroll
-                for (int ww = 1; ww < 4; ww++) {
-                    const float ob = cand_d[pb][ww][it];
-                    const int oi = cand_i[pb][ww][it];
-                    if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-                }
-            }
-            float e[8];
-            float cce;
-            if (RESIDENT) {  // the winning row is already in LDS (same floats as cb_eff): no dependent trip to L2
-                const float *Cl = lds + i * lvl_floats;
-#pragma unroll
-                for (int j = 0; j < 8; j++) e[j] = Cl[(8 * q + j) * LDK + bidx];
-                cce = Cl[32 * LDK + bidx];
-            } else {
-                load8(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 8 * q, e);
-                cce = a.cc[(int64_t)i * a.K + bidx];
-            }
-            float o[8], u[8], qv[8], w[8];
-            level_output<MODE, TRAIN>(r, e, xx, cce, o, u, qv, w);
-            float df[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) df[j] = r[j] - e[j];
-            const float l1 = dotQ(df, df);  // loss.py:41-44: both terms are numerically |r-e|^2
-            loss = loss + (l1 + a.beta * l1);
-            if (valid) {
-                if (q == 0) a.ids[item * a.L + i] = (int64_t)bidx;
-                if (a.emb_cat != nullptr) store8(a.emb_cat + item * a.ld_cat + i * D + 8 * q, o);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                esum[j] = (i == 0) ? o[j] : esum[j] + o[j];
-                r[j] = r[j] - o[j];
-            }
-        }
+        rq_level_loop<MODE, TRAIN, RESIDENT, CSPLIT>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss);
         if (valid) {
             if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
             if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The narrow middle of the step in ONE launch (small batches): the encoder's last two layers, the L-level quantisation and the
+// decoder's first two layers are all row-local, 16 items wide here, and each is a ~5 us launch on its own:
+//     h2 = silu(h1 W2^T) -> y = h2 W3^T -> [z = normalize(y)] -> L levels -> d0 = silu(emb_sum Wd0^T) -> d1 = silu(d0 Wd1^T)
+// One workgroup (4 waves) per 16 items.  Every Linear runs on v_mfma_f32_16x16x4_f32 with the WEIGHT rows as the A operand
+// (straight from global memory, 16 bytes per lane per 16-wide k-block) and the 16 ITEMS as the B operand, which makes the
+// accumulator layout of one layer (lane = item + 16 q, register r  <->  feature 16 t + 4 q + r of output tile t) exactly the B
+// operand layout of k-block t of the next layer: activations pass from layer to layer as float4-per-lane images in LDS with no
+// re-layout, and the same image with q <-> 8-dims-per-lane bridges to the quantiser's geometry.  Each output is the same
+// ORDER-G16 fmaf chain as in gemm_direct16_kernel, so every tensor written here is bit-identical to the unfused launches.
+// Measured (B = 1024, 256->128->32 | 3x256 | 32->128->256): 28 us against 31 us for the five launches back to back in a
+// microbenchmark and ~37 us for them inside the step; a workgroup pulls 288 KB of weights + 96 KB of codebooks through one CU's
+// L2 port (~70 GB/s) and runs ~300 dependent-ish MFMAs per wave, so the launch is bound by that, not by launch overhead.  A
+// variant that fetched every weight fragment into ~300 VGPRs up front was 2 us slower.
+// ------------------------------------------------------------------------------------------------
+struct BneckArgs {
+    FwdArgs rq;           // rq.y is not read: y is produced here (and written to y_out)
+    const float *h1;      // [B, K2] input activations (silu already applied)
+    int K2, N2;           // enc layer a: [N2, K2]; enc layer b: [32, N2]
+    const float *W2, *W3;
+    float *pre2, *h2, *y_out;
+    int Nd0, Nd1;         // dec layer a: [Nd0, 32]; dec layer b: [Nd1, Nd0]
+    const float *Wd0, *Wd1;
+    float *pre_d0, *d0, *pre_d1, *d1;
+};
+
+constexpr int BN_HMAX = 256;  // widest activation kept in LDS (features per item)
+
+// One Linear layer for the workgroup's 16 items.  Hin: K/16 float4-per-lane k-block images; outputs: pre (before the activation,
+// optional), act (after it) to global [B, N] and act to Hout (optional).  Output tiles are dealt to the 4 waves round-robin, two
+// tiles in flight per wave.
+__device__ __forceinline__ void bneck_layer(const float *W, int N, int K, const float4 *Hin, bool silu, float *pre, float *act,
+                                            float4 *Hout, int64_t item, bool valid, int wave, int lane) {
+    const int i16 = lane & 15, q = lane >> 4;
+    const int ntile = N / 16, nkb = K / 16;
+    for (int t0 = wave; t0 < ntile; t0 += 8) {
+        const int t1 = t0 + 4;
+        const bool two = t1 < ntile;
+        const float *w0 = W + (int64_t)(16 * t0 + i16) * K + 4 * q;
+        const float *w1 = W + (int64_t)(16 * (two ? t1 : t0) + i16) * K + 4 * q;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int kb = 0; kb < nkb; kb++) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(w0 + 16 * kb);
+            const float4 a1 = *reinterpret_cast<const float4 *>(w1 + 16 * kb);
+            const float4 b = Hin[kb * 64 + lane];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+            if (which == 1 && !two) break;
+            const int t = which ? t1 : t0;
+            const f32x4 acc = which ? acc1 : acc0;
+            float4 v = make_float4(acc[0] + 0.0f, acc[1] + 0.0f, acc[2] + 0.0f, acc[3] + 0.0f);  // (+ bias 0: as the GEMM epilogue)
+            float4 o = v;
+            if (silu) o = make_float4(hv_silu(v.x), hv_silu(v.y), hv_silu(v.z), hv_silu(v.w));
+            if (valid) {
+                const int64_t off = item * N + 16 * t + 4 * q;
+                if (pre != nullptr) *reinterpret_cast<float4 *>(pre + off) = v;
+                if (act != nullptr) *reinterpret_cast<float4 *>(act + off) = o;
+            }
+            if (Hout != nullptr) Hout[t * 64 + lane] = o;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(WG_THREADS) void bottleneck_fwd_kernel(BneckArgs b) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float cand_d[2][4][16];
+    __shared__ int cand_i[2][4][16];
+    const FwdArgs &a = b.rq;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int it = lane & 15, q = lane >> 4;
+    const int LDK = a.KC + 2;
+    const int lvl_floats = 32 * LDK + a.KC;
+    float4 *HA = reinterpret_cast<float4 *>(lds + (size_t)a.L * lvl_floats);  // [BN_HMAX/16][64] float4 = 16 items x 256 features
+    float4 *HB = HA + (BN_HMAX / 16) * 64;
+    float4 *HY = HB + (BN_HMAX / 16) * 64;                                     // [2][64]: 16 items x 32 dims
+    const int64_t item = (int64_t)blockIdx.x * ITEMS_PER_WAVE + it;
+    const bool in_range = item < a.B;
+    const int64_t src = in_range ? item : a.B - 1;
+    // the items' input rows as k-block images (all four waves need all of them)
+    for (int idx = threadIdx.x; idx < (b.K2 / 16) * 64; idx += WG_THREADS) {
+        const int kb = idx >> 6, l = idx & 63;
+        const int64_t row = (int64_t)blockIdx.x * ITEMS_PER_WAVE + (l & 15);
+        HA[idx] = *reinterpret_cast<const float4 *>(b.h1 + (row < a.B ? row : a.B - 1) * b.K2 + 16 * kb + 4 * (l >> 4));
+    }
+    for (int i = 0; i < a.L; i++) stage_codes(lds + i * lvl_floats, a, i, 0);
+    __syncthreads();
+    bneck_layer(b.W2, b.N2, b.K2, HA, true, b.pre2, b.h2, HB, item, in_range, wave, lane);
+    __syncthreads();
+    bneck_layer(b.W3, D, b.N2, HB, false, nullptr, b.y_out, HY, item, in_range, wave, lane);
+    __syncthreads();
+    // quantiser geometry: lane (it, q) holds dims 8q .. 8q+7 = registers of (tile q>>1, quarter 2(q&1)) and (.., 2(q&1)+1)
+    float r[8];
+    {
+        const float4 lo = HY[(q >> 1) * 64 + (2 * (q & 1)) * 16 + it];
+        const float4 hi = HY[(q >> 1) * 64 + (2 * (q & 1) + 1) * 16 + it];
+        r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = hi.w;
+    }
+    const bool valid = in_range && wave == 0;
+    if (a.normalize_input) {
+        const float den = fmaxf(sqrtf(dotQ(r, r)), 1e-12f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = r[j] / den;
+    }
+    if (a.z != nullptr && valid) store8(a.z + item * D + 8 * q, r);
+    float loss;
+    float esum[8];
+    int phase = 0;
+    rq_level_loop<MODE, true, true, true>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss);
+    if (valid) {
+        if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
+        if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
+    }
+    __syncthreads();  // HY is free again (every wave has read its r)
+    if (wave == 0) {  // every wave carries the same esum: one of them writes the k-block images of the decoder's input
+        HY[(q >> 1) * 64 + (2 * (q & 1)) * 16 + it] = make_float4(esum[0], esum[1], esum[2], esum[3]);
+        HY[(q >> 1) * 64 + (2 * (q & 1) + 1) * 16 + it] = make_float4(esum[4], esum[5], esum[6], esum[7]);
+    }
+    __syncthreads();
+    bneck_layer(b.Wd0, b.Nd0, D, HY, true, b.pre_d0, b.d0, HA, item, in_range, wave, lane);
+    __syncthreads();
+    bneck_layer(b.Wd1, b.Nd1, b.Nd0, HA, true, b.pre_d1, b.d1, nullptr, item, in_range, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,6 +736,46 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     if (!training) return launch_fwd<HIDVAE_MODE_STE, false>(a, resident, csplit, nw, grid, lds, s);
     if (mode == HIDVAE_MODE_STE) return launch_fwd<HIDVAE_MODE_STE, true>(a, resident, csplit, nw, grid, lds, s);
     return launch_fwd<HIDVAE_MODE_ROTATION, true>(a, resident, csplit, nw, grid, lds, s);
+}
+
+extern "C" int hidvae_bottleneck_fwd(const float *h1, int64_t B, int K2, int N2, const float *W2, const float *W3, float *pre2, float *h2,
+                                     float *y, int normalize_input, const float *cb_eff, const float *cc, int L, int64_t K, int mode,
+                                     float beta, float *z, int64_t *ids, float *emb_cat, int64_t ld_cat, float *emb_sum, float *qloss,
+                                     int Nd0, int Nd1, const float *Wd0, const float *Wd1, float *pre_d0, float *d0, float *pre_d1,
+                                     float *d1, void *stream) {
+    HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS && B >= 1 && K >= 1, "bottleneck_fwd: bad sizes");
+    HV_REQUIRE(h1 && W2 && W3 && h2 && y && cb_eff && cc && ids && emb_sum && Wd0 && Wd1 && d0 && d1 && pre2 && pre_d0 && pre_d1,
+               "bottleneck_fwd: null pointer");
+    HV_REQUIRE(mode == HIDVAE_MODE_STE || mode == HIDVAE_MODE_ROTATION, "bottleneck_fwd: mode %d is not fused", mode);
+    HV_REQUIRE(K2 % 16 == 0 && N2 % 16 == 0 && Nd0 % 16 == 0 && Nd1 % 16 == 0 && K2 >= 16 && N2 >= 16 && Nd0 >= 16 && Nd1 >= 16 &&
+                   K2 <= BN_HMAX && N2 <= BN_HMAX && Nd0 <= BN_HMAX,
+               "bottleneck_fwd: layer widths must be multiples of 16 and at most %d (K2=%d N2=%d Nd0=%d Nd1=%d)", BN_HMAX, K2, N2, Nd0, Nd1);
+    HV_REQUIRE(emb_cat == nullptr || (ld_cat >= (int64_t)L * D && ld_cat % 4 == 0), "bottleneck_fwd: ld_cat=%lld", (long long)ld_cat);
+    BneckArgs b{};
+    FwdArgs &a = b.rq;
+    a.y = nullptr; a.B = B; a.normalize_input = normalize_input; a.cb_eff = cb_eff; a.cc = cc; a.L = L; a.K = K;
+    const int64_t Kp = hv_cdiv(K, 128) * 128;  // the four waves each scan a quarter, 32 codes at a time (padding: +inf)
+    a.KC = (int)Kp;
+    a.nchunks = 1;
+    a.beta = beta; a.z = z; a.ids = ids; a.emb_cat = emb_cat; a.ld_cat = ld_cat; a.emb_sum = emb_sum; a.res_cat = nullptr; a.qloss = qloss;
+    const size_t lds = level_lds_bytes(a.KC) * (size_t)L + (size_t)(2 * (BN_HMAX / 16) * 64 + 2 * 64) * sizeof(float4);
+    HV_REQUIRE(a.KC % 128 == 0 && a.KC <= MAX_KC && lds <= 160 * 1024 - 1024,
+               "bottleneck_fwd: the codebooks (L=%d, K=%lld) do not fit in LDS beside the activations", L, (long long)K);
+    b.h1 = h1; b.K2 = K2; b.N2 = N2; b.W2 = W2; b.W3 = W3; b.pre2 = pre2; b.h2 = h2; b.y_out = y;
+    b.Nd0 = Nd0; b.Nd1 = Nd1; b.Wd0 = Wd0; b.Wd1 = Wd1; b.pre_d0 = pre_d0; b.d0 = d0; b.pre_d1 = pre_d1; b.d1 = d1;
+    const int grid = (int)hv_cdiv(B, ITEMS_PER_WAVE);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == HIDVAE_MODE_STE) {
+        auto kern = bottleneck_fwd_kernel<HIDVAE_MODE_STE>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, b);
+    } else {
+        auto kern = bottleneck_fwd_kernel<HIDVAE_MODE_ROTATION>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, b);
+    }
+    HV_LAUNCH_CHECK("bottleneck_fwd");
+    return HIDVAE_OK;
 }
 
 extern "C" int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_input, const float *cb_eff,

@@ -242,6 +242,20 @@ class HRqVae(nn.Module, _HubMixin):
         cc.record_stream(main)
         return cb, cc
 
+    def _bottleneck_ok(self, x):
+        """may this training step use the fused middle launch? (see include/hidvae.h, hidvae_bottleneck_fwd)"""
+        if not (self.training and torch.is_grad_enabled() and getattr(self, "fuse_bottleneck", True)):
+            return False
+        if self.codebook_mode.value not in (QuantizeForwardMode.STE.value, QuantizeForwardMode.ROTATION_TRICK.value):
+            return False
+        if any(getattr(layer, "do_kmeans_init", False) and not getattr(layer, "kmeans_initted", True) for layer in self.layers):
+            return False  # the k-means start-up pass wants y on its own first
+        We, Wd = self.encoder.weights(), self.decoder.weights()
+        if len(We) < 3 or len(Wd) < 3 or x.dim() != 2:
+            return False
+        return _C.bottleneck_eligible(x.shape[0], We[-2].shape[1], We[-2].shape[0], Wd[0].shape[0], Wd[1].shape[0], self.n_layers,
+                                      self.codebook_size)
+
     def _fused_mode(self):
         m = self.codebook_mode.value
         return _C.MODE_STE if m == QuantizeForwardMode.GUMBEL_SOFTMAX.value else m
@@ -290,8 +304,20 @@ class HRqVae(nn.Module, _HubMixin):
             if hasattr(r, "begin_step"):
                 r.begin_step(x.device)  # all dropout keep-masks of the step from one launch (rand.DeviceRand)
         self._prepared = self._prepare_codebooks_async()  # effective codebooks + |c|^2 on the helper stream, beside the encoder
-        y = self.encoder.body(x)  # the encoder's l2norm (codebook_normalize) happens in the RQ prologue
-        z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)
+        y_dec = None
+        if self._bottleneck_ok(x):
+            # small batches: encoder[-2:] + the L levels + decoder[:2] are one launch (ops.BottleneckFn); the stacks either side
+            # hand over (pre-activation, activation) pairs so no elementwise launch appears at the cuts
+            from ..ops import BottleneckFn, MLPBackFn, MLPFrontFn
+            We, Wd = self.encoder.weights(), self.decoder.weights()
+            pre1, h1 = MLPFrontFn.apply(x, *We[:-2])
+            z, ids, emb_cat, emb_sum, qloss, pre_d1, d1 = BottleneckFn.apply(
+                pre1, h1, We[-2], We[-1], Wd[0], Wd[1], self.codebook_normalize, self._fused_mode(), self.commitment_weight,
+                self._normalize_flags(), self._prepared, *self._tables())
+            y_dec = MLPBackFn.apply(pre_d1, d1, *Wd[2:])
+        else:
+            y = self.encoder.body(x)  # the encoder's l2norm (codebook_normalize) happens in the RQ prologue
+            z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)
         self._prepared = None
 
         tag_scalars = ()
@@ -312,7 +338,7 @@ class HRqVae(nn.Module, _HubMixin):
         # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0) and the total loss in one launch
         # the alignment / uniqueness weights enter once inside their loss modules and once more here
         n_tag = len(tag_scalars) // 3
-        loss, recon, uniq, stats = StepLossFn.apply(self.decoder.body(emb_sum), x, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
+        loss, recon, uniq, stats = StepLossFn.apply(y_dec if y_dec is not None else self.decoder.body(emb_sum), x, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
                                                     self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight,
                                                     self.tag_prediction_weight, self.sem_id_uniqueness_weight, n_tag,
                                                     float(self.n_layers), *tag_scalars)

@@ -77,8 +77,9 @@ def mlp_body_forward(x, weights, keep_for_backward):
     return h, saved
 
 
-def mlp_body_backward(saved, weights, g_y, need_input_grad):
-    """One launch per layer: dW_j = g_j^T h_{j-1} and g_{j-1} = (g_j W_j) * silu'(pre_{j-1}) share a grid (hidvae_linear_bwd)."""
+def mlp_body_backward(saved, weights, g_y, need_input_grad, in_pre=None):
+    """One launch per layer: dW_j = g_j^T h_{j-1} and g_{j-1} = (g_j W_j) * silu'(pre_{j-1}) share a grid (hidvae_linear_bwd).
+    in_pre: the stack's input was silu(in_pre) and the gradient wanted is the one w.r.t. in_pre (MLPBackFn)."""
     grads = [None] * len(weights)
     g = g_y
     for j in range(len(weights) - 1, -1, -1):
@@ -86,6 +87,8 @@ def mlp_body_backward(saved, weights, g_y, need_input_grad):
         dst, acc = grad_sink(weights[j])
         if j > 0:
             gw, g = _C.linear_bwd(g, inp, weights[j], True, _C.EPI_DSILU, saved[j - 1][1], dW=dst, accumulate=acc)
+        elif in_pre is not None and need_input_grad:
+            gw, g = _C.linear_bwd(g, inp, weights[j], True, _C.EPI_DSILU, in_pre, dW=dst, accumulate=acc)
         else:
             gw, g = _C.linear_bwd(g, inp, weights[j], need_input_grad, dW=dst, accumulate=acc)
         grads[j] = None if dst is not None else gw  # written in place: autograd has nothing to add
@@ -111,6 +114,115 @@ class MLPBodyFn(Function):
             t.record_stream(side_stream())  # read by the helper stream after this frame is gone
         ctx.saved = None
         return (gx,) + tuple(gws)
+
+
+# ---- the step split around the fused middle launch (hidvae_bottleneck_fwd) ------------------------------------------------------
+# An activated tensor h = silu(pre) crosses the cut as the PAIR (pre, h): `pre` is the differentiable tensor, `h` a cache of its
+# activation, so the consumer's input-gradient GEMM can apply silu'(pre) in its epilogue exactly as inside one MLPBodyFn and no
+# extra elementwise launch appears at the cut.
+class MLPFrontFn(Function):
+    """Linear+SiLU stack whose LAST layer is activated too.  -> (pre_last [differentiable], silu(pre_last) [cache])"""
+
+    @staticmethod
+    def forward(ctx, x, *weights):
+        ctx.set_materialize_grads(False)
+        saved, h = [], x
+        for w in weights:
+            pre = torch.empty((h.shape[0], w.shape[0]), device=h.device, dtype=torch.float32)
+            out = _C.gemm(_C.GEMM_NT, h, w, epilogue=_C.EPI_SILU, aux=pre)
+            saved.append((h, pre))
+            h = out
+        ctx.saved, ctx.weights, ctx.need_x = saved, weights, ctx.needs_input_grad[0]
+        ctx.mark_non_differentiable(h)
+        return saved[-1][1], h
+
+    @staticmethod
+    def backward(ctx, g_pre, _g_h):
+        if g_pre is None:
+            return (None,) * (1 + len(ctx.weights))
+        gx, gws, _ = mlp_body_backward(ctx.saved, ctx.weights, g_pre.contiguous(), ctx.need_x)
+        ctx.saved = None
+        return (gx,) + tuple(gws)
+
+
+class MLPBackFn(Function):
+    """MLPBodyFn on an input given as (pre_in [differentiable], act_in = silu(pre_in) [cache])."""
+
+    @staticmethod
+    def forward(ctx, pre_in, act_in, *weights):
+        ctx.set_materialize_grads(False)
+        y, saved = mlp_body_forward(act_in, weights, any(ctx.needs_input_grad))
+        ctx.saved, ctx.weights, ctx.pre_in, ctx.need_x = saved, weights, pre_in, ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        if g_y is None:
+            return (None,) * (2 + len(ctx.weights))
+        gx, gws, _ = mlp_body_backward(ctx.saved, ctx.weights, g_y.contiguous(), ctx.need_x, in_pre=ctx.pre_in)
+        ctx.saved = None
+        return (gx, None) + tuple(gws)
+
+
+class BottleneckFn(Function):
+    """encoder[-2:] + all L quantisation levels + decoder[:2] in one launch (csrc/rq.hip bottleneck_fwd_kernel); the backward is
+    the same sequence of launches as the unfused path (paired Linear backward x4, rq_backward, codebook_grad).
+    inputs : pre1 / h1 (the cut pair), W2, W3, Wd0, Wd1, config, prepared codebooks or None, the L raw tables
+    outputs: z, ids, emb_cat, emb_sum (non-differentiable here: its gradient is produced inside), qloss, pre_d1 / d1 (cut pair)"""
+
+    @staticmethod
+    def forward(ctx, pre1, h1, W2, W3, Wd0, Wd1, normalize_input, mode, beta, normalize_flags, prepared, *tables):
+        ctx.set_materialize_grads(False)
+        if prepared is not None:
+            cb, cc = prepared
+            join_side()
+        else:
+            cb, cc = _C.codebook_prepare([t.detach() for t in tables], normalize_flags)
+        o = _C.bottleneck_fwd(h1, W2.detach(), W3.detach(), cb, cc, normalize_input, mode, beta, Wd0.detach(), Wd1.detach())
+        ctx.cfg = (normalize_input, mode, beta, tuple(normalize_flags))
+        ctx.params = (W2, W3, Wd0, Wd1)
+        ctx.tables = tables
+        ctx.stash = (pre1, h1, o["pre2"], o["h2"], o["y"], o["z"], o["ids"], o["emb_sum"], o["pre_d0"], o["d0"], cb, cc)
+        ctx.mark_non_differentiable(o["ids"], o["emb_sum"], o["d1"])
+        return o["z"], o["ids"], o["emb_cat"], o["emb_sum"], o["qloss"], o["pre_d1"], o["d1"]
+
+    @staticmethod
+    def backward(ctx, g_z, _g_ids, g_cat, _g_sum, g_q, g_pre_d1, _g_d1):
+        normalize_input, mode, beta, flags = ctx.cfg
+        W2, W3, Wd0, Wd1 = ctx.params
+        pre1, h1, pre2, h2, y, z, ids, emb_sum, pre_d0, d0, cb, cc = ctx.stash
+        g_sum = None
+        gWd0 = gWd1 = None
+        if g_pre_d1 is not None:
+            dst, acc = grad_sink(Wd1)
+            gWd1, g_pre_d0 = _C.linear_bwd(g_pre_d1.contiguous(), d0, Wd1, True, _C.EPI_DSILU, pre_d0, dW=dst, accumulate=acc)
+            if dst is not None:
+                gWd1 = None
+            dst, acc = grad_sink(Wd0)
+            gWd0, g_sum = _C.linear_bwd(g_pre_d0, emb_sum, Wd0, True, dW=dst, accumulate=acc)
+            if dst is not None:
+                gWd0 = None
+        g_cat = g_cat.contiguous() if g_cat is not None else None
+        g_z = g_z.contiguous() if g_z is not None else None
+        g_y, dE = _C.rq_backward(y, z, cb, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z, 1.0 if g_q is not None else 0.0, g_q)
+        sinks = [getattr(t, "_hv_view", None) for t in ctx.tables]
+        states = {bool(getattr(t, "_hv_written", False)) for t in ctx.tables}
+        if all(torch.is_tensor(v) for v in sinks) and len(states) == 1:
+            acc = [grad_sink(t)[1] for t in ctx.tables][0]
+            _C.codebook_grad(ids, dE, [t.detach() for t in ctx.tables], cb, flags, grads=sinks, accumulate=acc)
+            gE = [None] * len(sinks)
+        else:
+            gE = _C.codebook_grad(ids, dE, [t.detach() for t in ctx.tables], cb, flags)
+        dst, acc = grad_sink(W3)
+        gW3, g_pre2 = _C.linear_bwd(g_y, h2, W3, True, _C.EPI_DSILU, pre2, dW=dst, accumulate=acc)
+        if dst is not None:
+            gW3 = None
+        dst, acc = grad_sink(W2)
+        gW2, g_pre1 = _C.linear_bwd(g_pre2, h1, W2, ctx.needs_input_grad[0], _C.EPI_DSILU, pre1, dW=dst, accumulate=acc)
+        if dst is not None:
+            gW2 = None
+        ctx.stash = None
+        return (g_pre1, None, gW2, gW3, gWd0, gWd1, None, None, None, None, None) + tuple(gE)
 
 
 class L2NormFn(Function):

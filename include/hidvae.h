@@ -117,6 +117,20 @@ int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
                       float *z, int64_t *ids, float *emb_cat, int64_t ld_cat,
                       float *emb_sum, float *res_cat, float *qloss, void *stream);
 
+/* ---- a2 (last two layers) + a5-a7 + a3 (first two layers) in ONE launch, for small batches (B <= 4096; codebooks + 34 KB of
+ * activations must fit in LDS: L*(33*Kp+64)*4 bytes with Kp = K rounded up to 128, e.g. 3x256 or 2x512).  Training only.
+ *   h2 = silu(h1 W2^T)   [B,N2]   (W2 [N2,K2]; h1 [B,K2] contiguous, activation already applied)      encoder.py:27-31
+ *   y  = h2 W3^T         [B,32]   (W3 [32,N2])
+ *   z, ids, emb_cat, emb_sum, qloss = hidvae_rq_forward(y, ...)  (same arguments and results)
+ *   d0 = silu(emb_sum Wd0^T) [B,Nd0],  d1 = silu(d0 Wd1^T) [B,Nd1]
+ * pre2 / pre_d0 / pre_d1 receive the pre-activations (the backward's saved tensors).  All widths multiples of 16; K2, N2, Nd0
+ * <= 256.  Every output is bit-identical to the separate launches (hidvae_gemm_f32 split_k=1 + hidvae_rq_forward). */
+int hidvae_bottleneck_fwd(const float *h1, int64_t B, int K2, int N2, const float *W2, const float *W3, float *pre2, float *h2,
+                          float *y, int normalize_input, const float *cb_eff, const float *cc, int L, int64_t K, int mode,
+                          float beta, float *z, int64_t *ids, float *emb_cat, int64_t ld_cat, float *emb_sum, float *qloss,
+                          int Nd0, int Nd1, const float *Wd0, const float *Wd1, float *pre_d0, float *d0, float *pre_d1,
+                          float *d1, void *stream);
+
 /* ---- fused RQ backward (autograd of the above) --------------------------------
  *   g_cat [B, ld_gcat] grad wrt each o_i (NULL = 0); g_sum [B,32] grad wrt sum_i o_i (NULL = 0);
  *   g_z_in [g_z_rows,32] extra grad wrt the first g_z_rows rows of z (uniqueness loss; NULL = 0); gq: d(loss)/d(qloss[b]) (same for all b),

@@ -244,3 +244,27 @@ def test_linear_bwd_pair_is_bit_identical_to_two_gemms(C, B, n_out, n_in):
     assert H.close(slot.cpu().numpy(), 1.0 + g.cpu().double().sum(0).float().numpy(), 1e-5, 1e-5)
     # and against fp32 torch (loose: different summation order)
     assert H.rel_err(dW.cpu().numpy(), (g.cpu().double().T @ x.cpu().double()).float().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,mode,norm", [(1024, 3, True), (50, 3, True), (16, 2, False), (333, 3, False)])
+def test_bottleneck_launch_is_bit_identical_to_the_separate_launches(C, B, mode, norm):
+    """enc(256->128->32) + 3x256 RQ + dec(32->128->256) in one launch vs gemm / rq_forward one by one"""
+    K2, N2, Nd0, Nd1, L, K = 256, 128, 128, 256, 3, 256
+    assert C.bottleneck_eligible(B, K2, N2, Nd0, Nd1, L, K)
+    h1 = dev(fill.uniform((B, K2), 90, -1, 1))
+    W2, W3 = dev(fill.uniform((N2, K2), 91, -0.08, 0.08)), dev(fill.uniform((32, N2), 92, -0.1, 0.1))
+    Wd0, Wd1 = dev(fill.uniform((Nd0, 32), 93, -0.2, 0.2)), dev(fill.uniform((Nd1, Nd0), 94, -0.1, 0.1))
+    _, tables = _rq_inputs(B, L, K, 95)
+    cb, cc = C.codebook_prepare([dev(t) for t in tables], [norm and i == 0 for i in range(L)])
+    o = C.bottleneck_fwd(h1, W2, W3, cb, cc, norm, mode, 0.4, Wd0, Wd1)
+    pre2 = torch.empty(B, N2, device="cuda")
+    h2 = C.gemm(C.GEMM_NT, h1, W2, epilogue=C.EPI_SILU, aux=pre2)
+    y = C.gemm(C.GEMM_NT, h2, W3)
+    z, ids, emb_cat, emb_sum, _, qloss = C.rq_forward(y, cb, cc, norm, mode, True, 0.4)
+    pre_d0 = torch.empty(B, Nd0, device="cuda")
+    d0 = C.gemm(C.GEMM_NT, emb_sum, Wd0, epilogue=C.EPI_SILU, aux=pre_d0)
+    pre_d1 = torch.empty(B, Nd1, device="cuda")
+    d1 = C.gemm(C.GEMM_NT, d0, Wd1, epilogue=C.EPI_SILU, aux=pre_d1)
+    want = dict(pre2=pre2, h2=h2, y=y, z=z, ids=ids, emb_cat=emb_cat, emb_sum=emb_sum, qloss=qloss, pre_d0=pre_d0, d0=d0, pre_d1=pre_d1, d1=d1)
+    for k, v in want.items():
+        assert torch.equal(o[k], v), k

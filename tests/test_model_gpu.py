@@ -207,3 +207,29 @@ def test_flat_gradient_buffer_matches_per_tensor_gradients():
     got2, _ = run(True, 2)
     for k in ref2:
         assert H.close(got2[k].cpu().numpy(), ref2[k].cpu().numpy(), 1e-6, 1e-9), k
+
+
+@pytest.mark.parametrize("name", ["rot_train_tag_b128", "rot_train_untag_b1024", "ste_train_untag_b64", "rot_train_untag_simvq_b64"])
+def test_fused_middle_launch_equals_the_separate_launches(name):
+    """encoder[-2:] + L levels + decoder[:2] in one launch (hidvae_bottleneck_fwd) vs the unfused step: losses, ids and every
+    gradient bit for bit (same fmaf chains, same backward launches)."""
+    from hidvae_amd.rand import InjectedRand
+    fx, desc = H.load(name)
+    cfg, P, x, te, ti = H.inputs_of(desc)
+
+    def run(fuse):
+        m = build_model(cfg, P).train()
+        m.fuse_bottleneck = fuse
+        m.rand = InjectedRand(O.FormulaRand(**desc["rand"]))
+        assert m._bottleneck_ok(x.cuda()) == fuse
+        out = m(make_batch(x, te, ti), gumbel_t=0.2)
+        out.loss.backward()
+        return out, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    for k in ("loss", "reconstruction_loss", "rqvae_loss", "embs_norm", "p_unique_ids"):
+        assert torch.equal(getattr(o1, k).detach(), getattr(o0, k).detach()), k
+    assert set(g1) == set(g0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
