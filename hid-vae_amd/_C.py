@@ -60,7 +60,7 @@ _SIGNATURES = {
     "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _vp],
     "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
-    "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _vp, _vp],
+    "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
 }
 
@@ -343,9 +343,10 @@ def id_stats(emb_cat, ids, want_norms=True):
     return norms, pu
 
 
-def adamw_prepare(desc, step_dev, beta1, beta2, eta_min, T_max):
+def adamw_prepare(desc, step_dev, beta1, beta2, eta_min, T_max, step_size=0, gamma=1.0):
     _check(lib().hidvae_adamw_prepare(_p(step_dev), _p(desc["lr"]), _p(desc["wd"]), int(desc["n"]), float(beta1), float(beta2),
-                                      float(eta_min), int(T_max), _p(desc["hyper"]), _stream()), "hidvae_adamw_prepare")
+                                      float(eta_min), int(T_max), int(step_size), float(gamma), _p(desc["hyper"]), _stream()),
+           "hidvae_adamw_prepare")
 
 
 def adamw_step(desc, beta1, beta2, eps, grad_scale):

@@ -149,12 +149,14 @@ struct AdamArgs {
 // per-step scalars in double precision, once per tensor (torch computes them on the host in double), and the step
 // counter itself: one tiny launch that depends on nothing, so it runs on the helper stream beside forward/backward
 __global__ void adamw_prepare_kernel(int64_t *step, const float *base_lr, const float *wd, int n, float beta1, float beta2,
-                                     float eta_min, int64_t T_max, float *hyper) {
+                                     float eta_min, int64_t T_max, int64_t step_size, float gamma, float *hyper) {
     const int64_t t1 = *step + 1;  // torch counts the step being taken from 1
     for (int t = threadIdx.x; t < n; t += blockDim.x) {
         double lr = (double)base_lr[t];
         if (T_max > 0)  // CosineAnnealingLR after (t1 - 1) scheduler steps, closed form
             lr = (double)eta_min + (lr - (double)eta_min) * (1.0 + cos(M_PI * (double)(t1 - 1) / (double)T_max)) * 0.5;
+        else if (step_size > 0)  // StepLR after (t1 - 1) scheduler steps: base * gamma^floor((t1-1)/step_size)
+            lr = lr * pow((double)gamma, (double)((t1 - 1) / step_size));
         const double bc1 = 1.0 - pow((double)beta1, (double)t1);
         const double bc2 = 1.0 - pow((double)beta2, (double)t1);
         hyper[3 * t + 0] = (float)(1.0 - lr * (double)wd[t]);
@@ -281,10 +283,11 @@ extern "C" int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, i
 }
 
 extern "C" int hidvae_adamw_prepare(int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors, float beta1,
-                                    float beta2, float eta_min, int64_t T_max, float *hyper_dev, void *stream) {
+                                    float beta2, float eta_min, int64_t T_max, int64_t step_size, float gamma, float *hyper_dev,
+                                    void *stream) {
     HV_REQUIRE(step_dev && base_lr_dev && wd_dev && hyper_dev && n_tensors >= 1, "adamw_prepare: bad arguments");
     hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_dev, base_lr_dev, wd_dev, n_tensors,
-                       beta1, beta2, eta_min, T_max, hyper_dev);
+                       beta1, beta2, eta_min, T_max, step_size, gamma, hyper_dev);
     HV_LAUNCH_CHECK("adamw_prepare");
     return HIDVAE_OK;
 }

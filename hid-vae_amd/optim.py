@@ -11,14 +11,14 @@ from . import _C
 
 class HidvaeAdamW(torch.optim.Optimizer):
     """Same param-group interface as torch.optim.AdamW (lr, weight_decay, betas, eps per group).
-    cosine=(T_max, eta_min) enables CosineAnnealingLR stepped once per optimizer step (the reference calls
-    scheduler.step() right after optimizer.step()).
+    cosine=(T_max, eta_min) enables CosineAnnealingLR, step_lr=(step_size, gamma) StepLR, each stepped once per optimizer step
+    (the reference calls scheduler.step() right after optimizer.step()); both are evaluated on the device.
 
     flat_grads=True gives every parameter a view of ONE flat gradient buffer as its .grad (autograd then accumulates
     in place), which is what the data-parallel path all-reduces in a single RCCL collective."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, cosine=None, start_step=0,
-                 flat_grads=False):
+                 flat_grads=False, step_lr=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         b = {tuple(g["betas"]) for g in self.param_groups}
         e = {g["eps"] for g in self.param_groups}
@@ -26,6 +26,10 @@ class HidvaeAdamW(torch.optim.Optimizer):
             raise ValueError("one (betas, eps) pair for all groups (the reference uses torch defaults everywhere)")
         self.betas, self.eps = b.pop(), e.pop()
         self.T_max, self.eta_min = (cosine if cosine is not None else (0, 0.0))
+        # step_lr=(step_size, gamma): torch StepLR stepped once per optimizer step (reference train_hidvae.py:641-642)
+        self.step_size, self.gamma = (step_lr if step_lr is not None else (0, 1.0))
+        if cosine is not None and step_lr is not None:
+            raise ValueError("one schedule at a time: cosine or step_lr")
         self._desc = None
         self._start_step = start_step
         self.flat_grads = flat_grads
@@ -78,7 +82,7 @@ class HidvaeAdamW(torch.optim.Optimizer):
         main, side = torch.cuda.current_stream(), side_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            _C.adamw_prepare(self._desc, self.step_dev, self.betas[0], self.betas[1], self.eta_min, self.T_max)
+            _C.adamw_prepare(self._desc, self.step_dev, self.betas[0], self.betas[1], self.eta_min, self.T_max, self.step_size, self.gamma)
         self._prepared = True
 
     def zero_grad(self, set_to_none=True):
@@ -118,7 +122,7 @@ class HidvaeAdamW(torch.optim.Optimizer):
         self.prepare()
         return {"hidvae_m": self._m.detach().cpu(), "hidvae_v": self._v.detach().cpu(), "step": int(self.step_dev[0].item()),
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-                "cosine": (self.T_max, self.eta_min)}
+                "cosine": (self.T_max, self.eta_min), "step_lr": (self.step_size, self.gamma)}
 
     def load_flat_state(self, state):
         self.prepare()
@@ -130,5 +134,5 @@ class HidvaeAdamW(torch.optim.Optimizer):
         t = int(self.step_dev[0].item())
         base = self.param_groups[group]["lr"]
         if self.T_max <= 0:
-            return base
+            return base * self.gamma ** (t // self.step_size) if self.step_size > 0 else base
         return self.eta_min + (base - self.eta_min) * (1 + math.cos(math.pi * t / self.T_max)) / 2

@@ -179,10 +179,9 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
         model.load_pretrained(pretrained_hrqvae_path)
         state = torch.load(pretrained_hrqvae_path, map_location=device, weights_only=False)
         start_iter, opt_state = state["iter"] + 1, state.get("optimizer")
-    if lr_scheduler_type == "step" and use_lr_scheduler:
-        raise NotImplementedError("StepLR is not fused into the device-side optimizer yet (every reference config uses cosine)")
-    cosine = (lr_scheduler_T_max, lr_scheduler_eta_min) if use_lr_scheduler else None
-    opt = HidvaeAdamW(groups, cosine=cosine, start_step=start_iter, flat_grads=world > 1).prepare()
+    cosine = (lr_scheduler_T_max, lr_scheduler_eta_min) if (use_lr_scheduler and lr_scheduler_type == "cosine") else None
+    step_lr = (lr_scheduler_step_size, lr_scheduler_gamma) if (use_lr_scheduler and lr_scheduler_type == "step") else None
+    opt = HidvaeAdamW(groups, cosine=cosine, step_lr=step_lr, start_step=start_iter, flat_grads=world > 1).prepare()
     if opt_state is not None and "hidvae_m" in opt_state:
         opt.load_flat_state(opt_state)
     dp = DataParallel(model, opt.grad_buffer) if world > 1 else None

@@ -209,14 +209,16 @@ int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, in
 /* ---- a16: AdamW (torch.optim.AdamW defaults; train_hidvae.py:533-563,762-766) with the cosine schedule
  * evaluated ON DEVICE from a device step counter, so the whole step is graph-capturable.
  * hidvae_adamw_prepare: one tiny launch per optimizer step that depends on nothing (run it beside forward/backward):
- *   t = *step_dev + 1; lr_t = eta_min + (base_lr-eta_min)(1+cos(pi*(t-1)/T_max))/2 if T_max > 0 else base_lr;
+ *   t = *step_dev + 1; lr_t = eta_min + (base_lr-eta_min)(1+cos(pi*(t-1)/T_max))/2 if T_max > 0 (CosineAnnealingLR),
+ *   else base_lr * gamma^floor((t-1)/step_size) if step_size > 0 (StepLR, train_hidvae.py:641-642), else base_lr;
  *   hyper[i] = {1 - lr_t*wd_i, lr_t/(1-beta1^t), sqrt(1-beta2^t)} (double precision, as torch does on the host);
  *   *step_dev = t.
  * hidvae_adamw_step: one launch per <=128 tensors.  p/m/v/numel: DEVICE tables built once; g_host: HOST array of the
  *   n_tensors gradient device pointers (autograd hands out new buffers every step; they travel by value in the kernel
  *   arguments).  grad_scale multiplies g first (1/world_size after an all-reduce SUM). */
-int hidvae_adamw_prepare(int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
-                         float beta1, float beta2, float eta_min, int64_t T_max, float *hyper_dev, void *stream);
+int hidvae_adamw_prepare(int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n,
+                         float beta1, float beta2, float eta_min, int64_t T_max, int64_t step_size, float gamma,
+                         float *hyper_dev, void *stream);
 int hidvae_adamw_step(float *const *p_dev, const float *const *g_host, float *const *m_dev, float *const *v_dev,
                       const int64_t *numel_dev, const float *hyper_dev, int n_tensors, int64_t max_numel,
                       float beta1, float beta2, float eps, float grad_scale, void *stream);

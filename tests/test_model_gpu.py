@@ -145,6 +145,27 @@ def test_adamw_kernel_matches_torch_adamw_math():
     assert int(opt.step_dev[0]) == 5
 
 
+def test_adamw_step_lr_schedule_matches_torch_steplr():
+    """StepLR(step_size, gamma) evaluated on the device (reference train_hidvae.py:641-642) against torch's own optimizer +
+    scheduler on the CPU, stepping the scheduler after every optimizer step as the reference does."""
+    from hidvae_amd.optim import HidvaeAdamW
+    from oracle import fill
+    w = torch.from_numpy(fill.uniform((300, 7), 61, -1, 1))
+    p_dev = torch.nn.Parameter(w.clone().cuda())
+    p_cpu = torch.nn.Parameter(w.clone())
+    opt = HidvaeAdamW([{"params": [p_dev], "lr": 1e-3, "weight_decay": 0.01}], step_lr=(3, 0.5))
+    ref = torch.optim.AdamW([p_cpu], lr=1e-3, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.StepLR(ref, step_size=3, gamma=0.5)
+    for it in range(8):
+        g = torch.from_numpy(fill.gauss((300, 7), 80 + it)) * 0.1
+        p_dev.grad, p_cpu.grad = g.cuda(), g.clone()
+        opt.step()
+        ref.step()
+        sched.step()
+        assert abs(opt.current_lr() - sched.get_last_lr()[0]) < 1e-12
+    assert H.rel_err(p_dev.detach().cpu().numpy(), p_cpu.detach().numpy()) <= 2e-6
+
+
 def test_train_steps_track_the_oracle():
     """3 optimizer steps end to end (HIP fwd/bwd + fused AdamW): the loss sequence must follow the torch-CPU oracle.
     Parameters are compared with an Adam-aware tolerance: where |g| ~ eps (1e-8) the update lr*g/(|g|+eps) amplifies
