@@ -234,76 +234,30 @@ def run_workload(args, device, rank, world, dist):
         dp.always = bool(args.dist)
         dp.broadcast_parameters(0)  # replicas start identical (DDP semantics)
     pool_x, pool_te, pool_ti = synth_pool(args, device, rank)
-    batch = types.SimpleNamespace(x=torch.empty_like(pool_x[0]))
-    if args.tagged:
-        batch.tags_emb, batch.tags_indices = torch.empty_like(pool_te[0]), torch.empty_like(pool_ti[0])
 
-    def load(i):  # "next_batch": one resident batch -> the static step inputs
-        batch.x.copy_(pool_x[i % args.pool])
+    def pool_batch(i):  # "next_batch": one resident batch (the stepper copies it into its static step inputs)
+        b = types.SimpleNamespace(x=pool_x[i % args.pool])
         if args.tagged:
-            batch.tags_emb.copy_(pool_te[i % args.pool])
-            batch.tags_indices.copy_(pool_ti[i % args.pool])
+            b.tags_emb, b.tags_indices = pool_te[i % args.pool], pool_ti[i % args.pool]
+        return b
 
-    last = {}
-
-    one = torch.ones((), device=device)  # d loss / d loss, allocated once instead of a fill kernel per step
-
-    def fwd_bwd():
-        opt.zero_grad()
-        out = m(batch, gumbel_t=0.2)
-        out.loss.backward(gradient=one)
-        if multi:
-            opt.grad_buffer.seal()  # inside the captured region: slots no kernel wrote in place are filled here
-        last["loss"] = out.loss.detach()
-
-    def step_eager():
-        fwd_bwd()
-        if multi:
-            opt.grad_scale, _ = dp.allreduce()  # ONE RCCL all-reduce of the flat gradient buffer; 1/world folded into AdamW
-        opt.step()
-
+    # the product's own step object (hidvae_amd/step.py, what train_hidvae.train() runs): 3 eager calls, then capture + replay;
+    # under DP: graph[fwd+bwd] -> ONE RCCL all-reduce of the flat gradient buffer (1/world folded into AdamW) -> graph[AdamW]
+    from hidvae_amd.step import GraphedTrainStep
+    stepper = GraphedTrainStep(m, opt, [pool_batch(0)], dp=dp, gumbel_t=0.2, warmup=3, enabled=bool(args.graph))
     use_graph = bool(args.graph)
-    graphs = None
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for i in range(3):  # allocator / kernel-attribute warm-up outside any capture
-            load(i)
-            step_eager()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    if use_graph:
-        try:
-            if multi:  # collectives stay outside the graphs: [fwd+bwd] -> all-reduce -> [AdamW]
-                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
-                    fwd_bwd()
-                opt.grad_scale = 1.0 / world
-                with torch.cuda.graph(g2):
-                    opt.step()
-                graphs = (g1, g2)
-            else:
-                g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
-                    step_eager()
-                graphs = (g1,)
-        except Exception as e:  # noqa: BLE001  report and run eagerly rather than die
-            import traceback
-            print(f"[bench] graph capture failed ({type(e).__name__}); running eagerly\n" + "".join(traceback.format_exc().splitlines(True)[-14:]),
-                  file=sys.stderr)
-            graphs, use_graph = None, False
-            torch.cuda.synchronize()
+    try:
+        for i in range(4):  # 3 eager warm-up calls + the capturing call, outside the timed region
+            stepper([pool_batch(i)])
+    except Exception as e:  # noqa: BLE001  report and run eagerly rather than die
+        import traceback
+        print(f"[bench] graph capture failed ({type(e).__name__}); running eagerly\n" + "".join(traceback.format_exc().splitlines(True)[-14:]),
+              file=sys.stderr)
+        stepper.enabled, stepper.graphs, use_graph = False, None, False
+        torch.cuda.synchronize()
 
     def step(i):
-        load(i)
-        if graphs is None:
-            step_eager()
-        elif len(graphs) == 1:
-            graphs[0].replay()
-        else:
-            graphs[0].replay()
-            dp.allreduce()
-            graphs[1].replay()
+        stepper([pool_batch(i)])
 
     for i in range(args.warmup):
         step(i)
@@ -321,7 +275,7 @@ def run_workload(args, device, rank, world, dist):
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    final_loss = float(last["loss"]) if "loss" in last else float("nan")
+    final_loss = float(stepper.row[0]) if stepper.row is not None else float("nan")
     return dt, m, dict(hip_graph=bool(use_graph), final_loss=final_loss)
 
 

@@ -31,7 +31,7 @@ _SIGNATURES = {
                               _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _vp],
     "hidvae_uniq_loss": [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
-    "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_total_loss_bwd": [_vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp],
     "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _i64, _vp, _vp, _vp, _vp],
@@ -58,7 +58,7 @@ _SIGNATURES = {
     "hidvae_gumbel_gemb": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp],
     "hidvae_gumbel_rows_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
     "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _vp],
-    "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
@@ -376,7 +376,7 @@ def total_loss(recon, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, 
     arr = lambda ts: _host_ptr_array(ts) if ts else None
     _check(lib().hidvae_total_loss(_p(recon), _p(qloss), recon.shape[0], arr(aligns), arr(preds), arr(accs), n_tag, float(tag_div),
                                    _p(ids), _p(z), L, float(uniq_weight), float(uniq_margin), float(w_a), float(w_p), float(w_u),
-                                   _p(loss), _p(uniq), _p(g_rows), _p(tagstats), _stream()), "hidvae_total_loss")
+                                   _p(loss), _p(uniq), _p(g_rows), _p(tagstats), None, _stream()), "hidvae_total_loss")
     return loss, uniq, g_rows, tagstats
 
 
@@ -389,7 +389,7 @@ def total_loss_bwd(g_loss, B, L, w_a, w_p, w_u, g_rows, want_gz):
 
 
 def loss_fwd(y, x, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want_grad):
-    """decoder tail + total loss -> (loss, recon, uniq, g_rows, tagstats)"""
+    """decoder tail + total loss -> (loss, recon, uniq, g_rows, tagstats, summary [6] = the training log row)"""
     _f32(y, "y"), _f32(x, "x")
     if y.shape != x.shape or not y.is_contiguous() or not x.is_contiguous():
         raise RuntimeError(f"loss: shapes differ or not contiguous ({tuple(y.shape)} vs {tuple(x.shape)})")
@@ -402,11 +402,12 @@ def loss_fwd(y, x, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, uni
     n_tag = len(aligns)
     g_rows = torch.empty((L, EMBED_DIM), device=dev, dtype=torch.float32) if (want_grad and ids is not None) else None
     tagstats = torch.empty((3 + 3 * n_tag,), device=dev, dtype=torch.float32) if n_tag else None
+    summary = torch.empty((6,), device=dev, dtype=torch.float32)
     arr = lambda ts: _host_ptr_array(ts) if ts else None
     _check(lib().hidvae_loss_fwd(_p(y), _p(x), B, N, _p(qloss), arr(aligns), arr(preds), arr(accs), n_tag, float(tag_div), _p(ids), _p(z), L,
                                  float(uniq_weight), float(uniq_margin), float(w_a), float(w_p), float(w_u), _p(recon), _p(loss), _p(uniq),
-                                 _p(g_rows), _p(tagstats), _stream()), "hidvae_loss_fwd")
-    return loss, recon, uniq, g_rows, tagstats
+                                 _p(g_rows), _p(tagstats), _p(summary), _stream()), "hidvae_loss_fwd")
+    return loss, recon, uniq, g_rows, tagstats, summary
 
 
 def loss_bwd(g_loss, y, x, L, w_a, w_p, w_u, g_rows, want_gz):

@@ -415,6 +415,7 @@ struct TotalArgs {
     float uniq_weight, uniq_margin;
     float w_a, w_p, w_u;
     float *loss, *uniq, *g_rows;
+    float *summary;   // optional [6]: loss, mean recon, mean qloss, tag align, tag pred, tag accuracy (the training log's row)
 };
 
 // executed by one whole 256-thread workgroup
@@ -453,6 +454,9 @@ __device__ __forceinline__ void total_loss_body(const TotalArgs &a) {
         t = t + a.w_u * uq;
         *a.loss = t;
         if (a.uniq != nullptr) *a.uniq = uq;
+        if (a.summary != nullptr) {
+            a.summary[0] = t; a.summary[1] = rm; a.summary[2] = qm; a.summary[3] = al; a.summary[4] = pr; a.summary[5] = ac;
+        }
     }
 }
 
@@ -503,7 +507,8 @@ extern "C" int hidvae_uniq_loss(const int64_t *ids, const float *z, int64_t B, i
 extern "C" int hidvae_total_loss(const float *recon, const float *qloss, int64_t B, const float *const *align_host,
                                  const float *const *pred_host, const float *const *acc_host, int n_tag, float tag_div,
                                  const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
-                                 float w_p, float w_u, float *loss, float *uniq, float *g_rows, float *tagstats, void *stream) {
+                                 float w_p, float w_u, float *loss, float *uniq, float *g_rows, float *tagstats, float *summary,
+                                 void *stream) {
     HV_REQUIRE(recon && qloss && loss && B >= 1, "total_loss: bad arguments");
     HV_REQUIRE(ids == nullptr || (z != nullptr && L >= 1 && L <= HIDVAE_MAX_LEVELS),
                "total_loss: uniqueness term needs z and 1 <= n_layers <= %d (L=%d)", HIDVAE_MAX_LEVELS, L);
@@ -516,7 +521,7 @@ extern "C" int hidvae_total_loss(const float *recon, const float *qloss, int64_t
         a.align[i] = align_host[i]; a.pred[i] = pred_host[i]; a.acc[i] = acc_host[i];
     }
     a.ids = ids; a.z = z; a.L = L; a.uniq_weight = uniq_weight; a.uniq_margin = uniq_margin;
-    a.w_a = w_a; a.w_p = w_p; a.w_u = w_u; a.loss = loss; a.uniq = uniq; a.g_rows = g_rows;
+    a.w_a = w_a; a.w_p = w_p; a.w_u = w_u; a.loss = loss; a.uniq = uniq; a.g_rows = g_rows; a.summary = summary;
     hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     HV_LAUNCH_CHECK("total_loss");
     return HIDVAE_OK;
@@ -531,7 +536,7 @@ extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_
                                const float *const *align_host, const float *const *pred_host, const float *const *acc_host, int n_tag,
                                float tag_div, const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
                                float w_p, float w_u, float *recon, float *loss, float *uniq, float *g_rows, float *tagstats,
-                               void *stream) {
+                               float *summary, void *stream) {
     HV_REQUIRE(y && x && qloss && recon && loss && B >= 1 && N >= 1, "loss_fwd: bad arguments");
     HV_REQUIRE(ids == nullptr || (z != nullptr && L >= 1 && L <= HIDVAE_MAX_LEVELS),
                "loss_fwd: uniqueness term needs z and 1 <= n_layers <= %d (L=%d)", HIDVAE_MAX_LEVELS, L);
@@ -544,7 +549,7 @@ extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_
         a.align[i] = align_host[i]; a.pred[i] = pred_host[i]; a.acc[i] = acc_host[i];
     }
     a.ids = ids; a.z = z; a.L = L; a.uniq_weight = uniq_weight; a.uniq_margin = uniq_margin;
-    a.w_a = w_a; a.w_p = w_p; a.w_u = w_u; a.loss = loss; a.uniq = uniq; a.g_rows = g_rows;
+    a.w_a = w_a; a.w_p = w_p; a.w_u = w_u; a.loss = loss; a.uniq = uniq; a.g_rows = g_rows; a.summary = summary;
     // two launches: a grid-wide hand-off inside one launch needs an agent-scope release per workgroup, and on 8 XCDs that
     // L2 write-back costs several times the second launch (measured 25 us fused vs 5 + 6.6 us)
     const unsigned grid = (unsigned)hv_cdiv(B, 4);

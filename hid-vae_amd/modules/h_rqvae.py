@@ -338,11 +338,12 @@ class HRqVae(nn.Module, _HubMixin):
         # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0) and the total loss in one launch
         # the alignment / uniqueness weights enter once inside their loss modules and once more here
         n_tag = len(tag_scalars) // 3
-        loss, recon, uniq, stats = StepLossFn.apply(y_dec if y_dec is not None else self.decoder.body(emb_sum), x, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
+        loss, recon, uniq, stats, summary = StepLossFn.apply(y_dec if y_dec is not None else self.decoder.body(emb_sum), x, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
                                                     self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight,
                                                     self.tag_prediction_weight, self.sem_id_uniqueness_weight, n_tag,
                                                     float(self.n_layers), *tag_scalars)
         main.wait_stream(side)  # the statistics above were computed beside the decoder
+        self.last_summary = summary  # device [6]: loss, mean recon, mean rqvae, tag align, tag pred, tag accuracy (training log row)
         zero = self._zero_scalar(x.device)
         if tagged:
             L = n_tag

@@ -358,7 +358,7 @@ class TotalLossFn(Function):
 
 class StepLossFn(Function):
     """ReconFn + TotalLossFn as HRqVae.forward pairs them, one launch each way (hidvae_loss_fwd / hidvae_loss_bwd).
-    Inputs: decoder body output y, the batch x, then as TotalLossFn.  Returns (loss, recon, uniq, tagstats); only `loss`
+    Inputs: decoder body output y, the batch x, then as TotalLossFn.  Returns (loss, recon, uniq, tagstats, summary); only `loss`
     is differentiable (the reconstruction term's gradient travels inside it)."""
 
     @staticmethod
@@ -366,7 +366,7 @@ class StepLossFn(Function):
         ctx.set_materialize_grads(False)
         want = z is not None and ctx.needs_input_grad[3]
         aligns, preds, accs = list(tag_scalars[:n_tag]), list(tag_scalars[n_tag:2 * n_tag]), list(tag_scalars[2 * n_tag:3 * n_tag])
-        loss, recon, uniq, g_rows, tagstats = _C.loss_fwd(y, x, qloss.detach(), [t.detach() for t in aligns], [t.detach() for t in preds],
+        loss, recon, uniq, g_rows, tagstats, summary = _C.loss_fwd(y, x, qloss.detach(), [t.detach() for t in aligns], [t.detach() for t in preds],
                                                           [t.detach() for t in accs], tag_div, ids, z, uniq_weight, uniq_margin, w_a,
                                                           w_p, w_u, want)
         ctx.meta = (y.shape[0], ids.shape[1] if ids is not None else 0, w_a, w_p, w_u, n_tag, tag_div, z is not None)
@@ -374,11 +374,11 @@ class StepLossFn(Function):
         ctx.save_for_backward(y, x)
         if tagstats is None:
             tagstats = torch.empty(0, device=loss.device)
-        ctx.mark_non_differentiable(recon, uniq, tagstats)
-        return loss, recon, uniq, tagstats
+        ctx.mark_non_differentiable(recon, uniq, tagstats, summary)
+        return loss, recon, uniq, tagstats, summary
 
     @staticmethod
-    def backward(ctx, g, _g_recon, _g_uniq, _g_stats):
+    def backward(ctx, g, _g_recon, _g_uniq, _g_stats, _g_summary):
         B, L, w_a, w_p, w_u, n_tag, tag_div, has_z = ctx.meta
         if g is None:
             return (None,) * (12 + 3 * n_tag)

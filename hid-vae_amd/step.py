@@ -1,0 +1,97 @@
+"""One optimizer step of the tokenizer as a replayable HIP graph.
+
+train_hidvae.train() and bench.py run the same sequence every iteration -- copy the batch into fixed input buffers, forward,
+backward, (all-reduce,) AdamW -- about 25 launches in the untagged case and 300 with the tag heads, most of them a few
+microseconds long.  Issued one by one from Python the step is host-bound (0.80 ms untagged / 7.2 ms tagged on MI355X); captured
+once and replayed it is 0.28 / 2.3 ms.  Nothing in the step synchronises with the host (losses, the mixup weight, the AdamW step
+counter and the learning-rate schedule live on the device), which is what makes the capture legal.
+
+Data parallel: collectives stay outside the graphs, so the step is  graph[zero_grad, forward, backward, seal]  ->  one RCCL
+all-reduce of the flat gradient buffer  ->  graph[AdamW]."""
+import types
+
+import torch
+
+
+class GraphedTrainStep:
+    """step = GraphedTrainStep(model, opt, example_batches, dp=None, gumbel_t=0.2)
+    row = step(batches)   # batches: list of `ga` batch records (x [, tags_emb, tags_indices]) of the example's shapes
+    `row` is a device tensor [6] = (total loss, mean recon, mean rqvae, tag align, tag pred, tag accuracy) that the NEXT call
+    overwrites: clone it to keep it.  The first calls run eagerly (allocator / kernel-attribute warm-up, and the randomness
+    provider learns the step's dropout requests); the capture happens on call number `warmup + 1`."""
+
+    def __init__(self, model, opt, example_batches, dp=None, gumbel_t=0.2, warmup=3, enabled=True):
+        self.model, self.opt, self.dp, self.t = model, opt, dp, gumbel_t
+        self.ga = len(example_batches)
+        self.tagged = getattr(example_batches[0], "tags_emb", None) is not None
+        self.static = []
+        for b in example_batches:
+            s = types.SimpleNamespace(x=torch.empty_like(b.x))
+            if self.tagged:
+                s.tags_emb, s.tags_indices = torch.empty_like(b.tags_emb), torch.empty_like(b.tags_indices)
+            self.static.append(s)
+        self.one = torch.ones((), device=example_batches[0].x.device)
+        self.row = None
+        self.calls, self.warmup, self.enabled = 0, warmup, enabled
+        self.graphs = None
+
+    # -- the step, as plain code (this is what gets captured)
+    def _fwd_bwd(self):
+        self.opt.zero_grad()
+        total = None
+        for s in self.static:
+            out = self.model(s, gumbel_t=self.t)
+            part = out.loss / self.ga if self.ga > 1 else out.loss
+            total = part if total is None else total + part
+        total.backward(gradient=self.one)
+        if self.opt.flat_grads:
+            self.opt.grad_buffer.seal()
+        summary = self.model.last_summary
+        self.row = summary if self.ga == 1 else torch.cat([total.detach().reshape(1), summary[1:]])
+
+    def _eager(self):
+        self._fwd_bwd()
+        if self.dp is not None:
+            self.opt.grad_scale, _ = self.dp.allreduce()
+        self.opt.step()
+
+    def _capture(self):
+        if self.dp is not None:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._fwd_bwd()
+            self.opt.grad_scale = 1.0 / self.dp.world
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self.opt.step()
+            self.graphs = (g1, g2)
+        else:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._eager()
+            self.graphs = (g1,)
+
+    def load(self, batches):
+        if len(batches) != self.ga:
+            raise RuntimeError(f"GraphedTrainStep was built for {self.ga} micro-batches, got {len(batches)}")
+        for s, b in zip(self.static, batches):
+            if b.x.shape != s.x.shape:
+                raise RuntimeError(f"batch shape {tuple(b.x.shape)} differs from the captured {tuple(s.x.shape)}")
+            s.x.copy_(b.x)
+            if self.tagged:
+                s.tags_emb.copy_(b.tags_emb)
+                s.tags_indices.copy_(b.tags_indices)
+
+    def __call__(self, batches):
+        self.load(batches)
+        self.calls += 1
+        if not self.enabled or self.calls <= self.warmup:
+            self._eager()
+            return self.row
+        if self.graphs is None:
+            torch.cuda.synchronize()
+            self._capture()  # (a capture only records: replay it for this call's batch)
+        self.graphs[0].replay()
+        if len(self.graphs) == 2:
+            self.dp.allreduce()
+            self.graphs[1].replay()
+        return self.row

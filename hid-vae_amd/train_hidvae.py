@@ -29,6 +29,7 @@ from .modules.quantize import QuantizeForwardMode
 from .modules.tokenizer.h_semids import HSemanticIdTokenizer
 from .optim import HidvaeAdamW
 from .parallel import DataParallel
+from .step import GraphedTrainStep
 
 
 def calculate_repetition_rate(item_ids):
@@ -105,7 +106,8 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
           eval_tta=True, eval_temperature=0.8, ensemble_predictions=True, use_lr_scheduler=True, lr_scheduler_type="cosine",
           lr_scheduler_T_max=400000, lr_scheduler_eta_min=1e-6, lr_scheduler_step_size=100000, lr_scheduler_gamma=0.5,
           lr_scheduler_factor=0.5, lr_scheduler_patience=10, sem_id_uniqueness_weight=0.5, sem_id_uniqueness_margin=0.5,
-          id_repetition_threshold=0.03, use_concatenated_ids=False, use_interleaved_ids=False, seed=0, log_every=100):
+          id_repetition_threshold=0.03, use_concatenated_ids=False, use_interleaved_ids=False, seed=0, log_every=100,
+          use_hip_graph=True):
     if amp:
         raise NotImplementedError("amp is False in every reference config; the HIP path computes in fp32")
     if lr_scheduler_type not in ("cosine", "step"):
@@ -198,7 +200,8 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
     tokenizer.hrq_vae = model
 
     sampler = RandomBatches(train_set, batch_size, seed=(dp.shard_seed(seed) if dp else seed))
-    window = deque(maxlen=1000)  # per-iteration device scalars; read back only when a log line is due
+    window = deque(maxlen=1000)  # per-iteration device rows; read back only when a log line is due
+    stepper = None
     series = {"iter": [], "loss": [], "eval": []}
     t = 0.2
     one = torch.ones((), device=device)
@@ -212,21 +215,13 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
             if dp is not None:  # rank 0's codebooks win (the reference lets them diverge)
                 dp.broadcast_codebooks([layer.embedding.weight for layer in model.layers], 0)
             log.info("K-means initialization complete")
-        opt.zero_grad()
-        total = None
-        for _ in range(ga):
-            out = model(sampler.next(), gumbel_t=t)
-            part = out.loss / ga if ga > 1 else out.loss
-            total = part if total is None else total + part
-        total.backward(gradient=one)
-        if dp is not None:
-            opt.grad_scale, _ = dp.allreduce()
-        opt.step()
-        window.append((total.detach(), out.reconstruction_loss.detach(), out.rqvae_loss.detach(), out.tag_align_loss.detach(),
-                       out.tag_pred_loss.detach(), out.tag_pred_accuracy.detach()))
+        micro = [sampler.next() for _ in range(ga)]
+        if stepper is None:  # built on the first regular step: its static buffers take the batch shapes
+            stepper = GraphedTrainStep(model, opt, micro, dp=dp, gumbel_t=t, enabled=use_hip_graph)
+        row = stepper(micro)  # device [6]: total loss, mean recon, mean rqvae, tag align, tag pred, tag accuracy
+        window.append(row.clone())
         if it % log_every == 0 and main_proc:
-            cols = list(zip(*window))
-            m = [float(torch.stack([c.mean() for c in col]).mean()) for col in cols]
+            m = torch.stack(list(window)).mean(0).tolist()
             series["iter"].append(it)
             series["loss"].append(m)
             log.info(f"Iter {it} - loss: {m[0]:.4f}, rl: {m[1]:.4f}, vl: {m[2]:.4f}, tal: {m[3]:.4f}, tpl: {m[4]:.4f}, acc: {m[5]:.4f}, "

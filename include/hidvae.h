@@ -172,7 +172,8 @@ int hidvae_l2norm_bwd(const float *g, int64_t ldg, const float *out, int64_t ldo
  * d loss / d z[0:L].  a1: total loss = mean(recon)+mean(qloss)+w_a*align+w_p*pred+w_u*uniq (h_rqvae.py:634-640),
  * the uniqueness term evaluated in the same launch when ids != NULL.  align/pred/acc: HOST arrays of n_tag per-level
  * device scalars (n_tag = 0 for an untagged batch); tag_align = sum_i align_i / tag_div etc. (h_rqvae.py:561-563);
- * tagstats [3+3*n_tag] (optional) receives the three means followed by the three by-layer vectors. */
+ * tagstats [3+3*n_tag] (optional) receives the three means followed by the three by-layer vectors; summary [6] (optional)
+ * receives {loss, mean recon, mean qloss, tag align, tag pred, tag accuracy}: the row train_hidvae.py:770-790 logs. */
 int hidvae_uniq_loss(const int64_t *ids, const float *z, int64_t B, int L, float weight, float margin, float *loss,
                      float *g_rows, void *stream);
 int hidvae_total_loss(const float *recon, const float *qloss, int64_t B,
@@ -180,7 +181,7 @@ int hidvae_total_loss(const float *recon, const float *qloss, int64_t B,
                       int n_tag, float tag_div,
                       const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin,
                       float w_a, float w_p, float w_u, float *loss, float *uniq, float *g_rows, float *tagstats,
-                      void *stream);
+                      float *summary, void *stream);
 /* backward of the above for a device scalar g = d/d loss: scal[0] = g/B (per-item grad of recon and qloss),
  * scal[1] = g*w_a, scal[2] = g*w_p (pass w_a/tag_div, w_p/tag_div to get the per-level gradients); g_z [B,32] (optional) = g*w_u*g_rows on rows < L, 0 elsewhere. */
 int hidvae_total_loss_bwd(const float *g_loss, int64_t B, int L, float w_a, float w_p, float w_u, const float *g_rows,
@@ -194,7 +195,7 @@ int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, const 
                     const float *const *align_host, const float *const *pred_host, const float *const *acc_host, int n_tag,
                     float tag_div, const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
                     float w_p, float w_u, float *recon, float *loss, float *uniq, float *g_rows, float *tagstats,
-                    void *stream);
+                    float *summary, void *stream);
 int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L, float w_a, float w_p,
                     float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, void *stream);
 

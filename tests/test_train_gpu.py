@@ -101,3 +101,27 @@ def test_checkpoint_round_trip(tmp_path):
     for k, v in m.state_dict().items():
         assert torch.equal(m2.state_dict()[k].cpu(), v.cpu()), k
     assert "self" not in m.config and m.config["codebook_size"] == 256
+
+
+def test_train_driver_graph_replay_equals_eager(tmp_path):
+    """train() replays the step from a HIP graph (hidvae_amd/step.py); the untagged step draws nothing at random inside the step,
+    so the replayed run must equal the eager run bit for bit: every logged row and every final parameter."""
+    import hidvae_amd  # noqa: F401
+    from hidvae_amd.modules.quantize import QuantizeForwardMode
+    from hidvae_amd.train_hidvae import train
+    g = torch.Generator().manual_seed(11)
+    x = torch.nn.functional.normalize(torch.randn(1500, 768, generator=g), dim=-1)
+
+    def run(graph, sub):
+        return train(iterations=14, batch_size=128, learning_rate=2.8e-4, weight_decay=0.015, dataset={"x": x}, save_dir_root=str(tmp_path / sub) + "/",
+                     use_kmeans_init=False, do_eval=False, gradient_accumulate_every=1, commitment_weight=0.4, vae_n_cat_feats=0,
+                     vae_input_dim=768, vae_embed_dim=32, vae_hidden_dims=[512, 256, 128], vae_codebook_size=256, vae_codebook_normalize=True,
+                     vae_codebook_mode=QuantizeForwardMode.ROTATION_TRICK, vae_n_layers=3, tag_class_counts=[38, 168, 348],
+                     lr_scheduler_T_max=1000, lr_scheduler_eta_min=7e-8, log_every=1, seed=3, use_hip_graph=graph)
+
+    m1, s1 = run(True, "g")
+    m0, s0 = run(False, "e")
+    assert len(s1["loss"]) == len(s0["loss"]) >= 14
+    assert s1["loss"] == s0["loss"]
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m0.state_dict().items()):
+        assert torch.equal(a, b), k
