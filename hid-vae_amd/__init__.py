@@ -8,7 +8,7 @@ import sys
 from . import _C  # noqa: F401
 
 _DROPIN = {
-    "modules": "modules", "modules.h_rqvae": "modules.h_rqvae", "modules.encoder": "modules.encoder",
+    "modules": "modules", "modules.h_rqvae": "modules.h_rqvae", "modules.rqvae": "modules.rqvae", "modules.encoder": "modules.encoder",
     "modules.quantize": "modules.quantize", "modules.loss": "modules.loss", "modules.normalize": "modules.normalize",
     "modules.tokenizer": "modules.tokenizer", "modules.tokenizer.h_semids": "modules.tokenizer.h_semids",
     "init": "init", "init.kmeans": "init.kmeans", "data.schemas": "data.schemas", "data.utils": "data.utils",

@@ -15,7 +15,9 @@ def case_names(kind="case"):
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
         n = os.path.basename(p)[:-4]
-        if kind == "case" and not (n.startswith("kmeans") or n.startswith("train")):
+        if kind == "rqvae" and n.startswith("rqvae"):
+            out.append(n)
+        elif kind == "case" and not (n.startswith("kmeans") or n.startswith("train") or n.startswith("rqvae")):
             out.append(n)
         elif kind == "kmeans" and n.startswith("kmeans"):
             out.append(n)

@@ -254,3 +254,47 @@ def test_fused_middle_launch_equals_the_separate_launches(name):
     assert set(g1) == set(g0)
     for k in g0:
         assert torch.equal(g1[k], g0[k]), k
+
+
+@pytest.mark.parametrize("name", H.case_names("rqvae"))
+def test_plain_rqvae_matches_reference_goldens(name):
+    """hidvae_amd.modules.rqvae.RqVae (reference modules/rqvae.py) on the same launches as the tokenizer step: ids bit-exact,
+    the five output fields and every gradient against the reference's own run."""
+    from hidvae_amd.modules.quantize import QuantizeForwardMode
+    from hidvae_amd.modules.rqvae import RqVae
+    fx, desc = H.load(name)
+    cfg = O.Cfg(**desc["cfg"])
+    P = O.formula_params(cfg, seed=100, with_tags=False)
+    x, _, _ = O.formula_batch(cfg, desc["B"], seed=7, tagged=False)
+    m = RqVae(input_dim=cfg.input_dim, embed_dim=cfg.embed_dim, hidden_dims=list(cfg.hidden_dims), codebook_size=cfg.codebook_size,
+              codebook_kmeans_init=False, codebook_normalize=cfg.codebook_normalize, codebook_sim_vq=False,
+              codebook_mode=QuantizeForwardMode(cfg.codebook_mode), n_layers=cfg.n_layers, commitment_weight=cfg.commitment_weight,
+              n_cat_features=0).cuda()
+    assert set(m.state_dict()) == set(P)
+    m.load_state_dict({k: v.clone() for k, v in P.items()})
+    m.train(desc["training"])
+    batch = types.SimpleNamespace(x=x.cuda())
+    if desc["training"]:
+        out = m(batch, gumbel_t=0.2)
+        out.loss.backward()
+        norms = json.loads(str(fx["grad_norms"]))
+        for k, p in m.named_parameters():
+            if "grad/" + k in fx:
+                assert H.close(p.grad.cpu().numpy(), fx["grad/" + k], 3e-5, 1e-8), k
+            else:
+                assert H.close(H.sample(p.grad), fx["gsample/" + k], 3e-5, 1e-8), k
+            assert abs(float(p.grad.double().norm()) - norms[k]) <= 3e-5 * norms[k], k
+    else:
+        with torch.no_grad():
+            out = m(batch, gumbel_t=0.2)
+    for k in ("loss", "reconstruction_loss", "rqvae_loss"):
+        assert abs(float(getattr(out, k).detach()) - float(fx[k])) <= TOL * abs(float(fx[k])), k
+    assert abs(float(out.p_unique_ids) - float(fx["p_unique_ids"])) < 1e-7
+    assert H.rel_err(out.embs_norm.cpu().numpy(), fx["embs_norm"]) <= TOL
+    assert (fx["margins"] > 1e-6).all()
+    with torch.no_grad():
+        q = m.get_semantic_ids(batch.x, 0.2)
+    assert np.array_equal(q.sem_ids.cpu().numpy(), fx["sem_ids"].astype(np.int64))
+    assert H.rel_err(q.embeddings.cpu().numpy(), fx["embeddings"]) <= TOL
+    assert H.rel_err(q.residuals.cpu().numpy(), fx["residuals"]) <= TOL
+    assert H.rel_err(q.quantize_loss.cpu().numpy(), fx["quantize_loss"]) <= TOL

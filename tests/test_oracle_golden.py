@@ -109,3 +109,30 @@ def test_train_loop_matches_reference(name):
                 assert H.rel_err(H.sample(P[k[8:]]), fx[k]) <= TOL, k
     for i in range(L):
         assert H.rel_err(bn[f"tag_projectors.{i}.1.running_mean"].numpy(), fx[f"bn_mean_{i}"]) <= TOL
+
+
+@pytest.mark.parametrize("name", H.case_names("rqvae"))
+def test_oracle_matches_reference_plain_rqvae(name):
+    """The plain RqVae (reference modules/rqvae.py) is the untagged step without the uniqueness term: the oracle's untagged
+    forward with sem_id_uniqueness_weight = 0 against the reference's own RqVae outputs."""
+    fx, desc = H.load(name)
+    cfg = O.Cfg(**{**desc["cfg"], "sem_id_uniqueness_weight": 0.0})
+    P = O.formula_params(cfg, seed=100, with_tags=False)
+    x, _, _ = O.formula_batch(cfg, desc["B"], seed=7, tagged=False)
+    if desc["training"]:
+        out, g = O.grads(P, cfg, x, training=True)
+        norms = json.loads(str(fx["grad_norms"]))
+        for k in P:
+            if "grad/" + k in fx:
+                assert H.close(g[k].numpy(), fx["grad/" + k], 2e-5, 1e-8), k
+            else:
+                assert H.close(H.sample(g[k]), fx["gsample/" + k], 2e-5, 1e-8), k
+            assert abs(float(g[k].double().norm()) - norms[k]) <= 2e-5 * norms[k], k
+    else:
+        with torch.no_grad():
+            out = O.forward(P, cfg, x, training=False)
+    assert np.array_equal(out["sem_ids"].numpy(), fx["sem_ids"].astype(np.int64))
+    assert abs(float(out["loss"].detach()) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    assert abs(float(out["reconstruction_loss"].mean()) - float(fx["reconstruction_loss"])) <= 1e-5 * abs(float(fx["reconstruction_loss"]))
+    assert abs(float(out["rqvae_loss"].mean()) - float(fx["rqvae_loss"])) <= 1e-5 * abs(float(fx["rqvae_loss"]))
+    assert abs(float(out["p_unique_ids"]) - float(fx["p_unique_ids"])) < 1e-7
