@@ -116,9 +116,11 @@ def time_kernel(fn, launches=20, reps=20):
 def kernel_rooflines(args, m, device):
     """Live per-kernel timings on the bench shapes.
     * gemm_direct_kernel (fp32 MFMA roofline, 157.3 TFLOP/s): the largest GEMMs of the step, forward and backward;
-    * rq_forward_kernel (HBM roofline, 8 TB/s): algorithmic bytes per item from SURVEY.md 8(d): read y 128 B, write ids
-      8L, emb_cat 128L, emb_sum 128, z 128, loss 4 (+ the codebooks 4*L*K*32 once per launch).  In exact fp32 this kernel
-      is bound by the fp32 MFMA rate, not by HBM (2*L*K*32 FLOP per item); both fractions are reported."""
+    * rq_forward_kernel (HBM roofline, 8 TB/s): ALGORITHMIC bytes per item exactly as SURVEY.md 8(d) counts them for the tagged
+      variant: read z 128 B, write ids 8L, per-level emb_out 128L, loss 4 = 540 B at L=3 (+ the codebooks 4*L*K*32 once per
+      launch).  The launch also writes emb_sum and z (128 B each, consumed by the decoder and the backward): `bytes_moved`
+      carries that 796 B/item figure, `traffic` the PMC measurement.  In exact fp32 this kernel is bound by the fp32 MFMA rate,
+      not by HBM (2*L*K*32 FLOP per item); both fractions are reported."""
     from hidvae_amd import _C
     B, L, K = args.batch, args.levels, args.codes
     out = []
@@ -141,17 +143,19 @@ def kernel_rooflines(args, m, device):
     tables = [layer.embedding.weight.detach() for layer in m.layers]
     cb, cc = _C.codebook_prepare(tables, [i == 0 for i in range(L)])
     t = time_kernel(lambda: _C.rq_forward(y, cb, cc, True, 3, True, 0.4))
-    alg = (128 + 8 * L + 128 * L + 128 + 128 + 4) * B + 4 * L * K * 32
+    alg = (128 + 8 * L + 128 * L + 4) * B + 4 * L * K * 32
     out.append(dict(kernel="rq_forward_kernel (fused L-level VQ, code-split variant)", bound="hbm", achieved=alg / t * 1e-3,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=alg / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t, algorithmic_bytes=alg,
+                    bytes_moved=(128 + 8 * L + 128 * L + 128 + 128 + 4) * B + 4 * L * K * 32,
                     mfma_f32_frac=2.0 * B * L * K * 32 / t * 1e-6 / MFMA_F32_PEAK_TF))
     # the same VQ kernel at a corpus-sized launch (where it is throughput-, not latency-bound)
     big = 1 << 20
     yb = torch.randn(big, 32, device=device)
     t = time_kernel(lambda: _C.rq_forward(yb, cb, cc, True, 3, True, 0.4), launches=2, reps=5)
-    algb = (128 + 8 * L + 128 * L + 128 + 128 + 4) * big + 4 * L * K * 32
+    algb = (128 + 8 * L + 128 * L + 4) * big + 4 * L * K * 32
     out.append(dict(kernel="rq_forward_kernel at 1,048,576 items (corpus-sized launch)", bound="hbm", achieved=algb / t * 1e-3,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=algb / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t, algorithmic_bytes=algb,
+                    bytes_moved=(128 + 8 * L + 128 * L + 128 + 128 + 4) * big + 4 * L * K * 32,
                     mfma_f32_frac=2.0 * big * L * K * 32 / t * 1e-6 / MFMA_F32_PEAK_TF, items_per_s=big / t * 1e6))
     return out
 
