@@ -22,6 +22,58 @@ class RecDataset(Enum):
 
 
 
+class _Opaque:
+    """stands in for any torch_geometric class named inside the reference's processed file (only the tensors are wanted)"""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {"state": state})
+
+
+class _GeometricFreePickle:
+    """pickle_module for torch.load that resolves `torch_geometric.*` globals to _Opaque, so the reference's processed dataset
+    (a torch.save of (HeteroData.to_dict(), slices, <class HeteroData>)) loads without torch_geometric installed"""
+    import pickle as _pickle
+
+    __name__ = "pickle"
+    Pickler = _pickle.Pickler
+    load = staticmethod(_pickle.load)
+    dump = staticmethod(_pickle.dump)
+
+    class Unpickler(_pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.split(".")[0] == "torch_geometric":
+                return type(name, (_Opaque,), {})
+            return super().find_class(module, name)
+
+
+def load_reference_processed(path):
+    """-> dict with x [N,768], optional tags_emb [N,T,768], tags_indices [N,T], is_train [N] from either file layout."""
+    try:
+        blob = torch.load(path, map_location="cpu", weights_only=False)
+    except (ModuleNotFoundError, AttributeError, ImportError):
+        blob = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_GeometricFreePickle)
+    if isinstance(blob, dict) and "x" in blob:
+        return blob
+    store = None
+    if isinstance(blob, (tuple, list)) and len(blob) >= 1 and isinstance(blob[0], dict):  # (data.to_dict(), slices, cls)
+        store = blob[0].get("item")
+    elif hasattr(blob, "__dict__"):  # a pickled HeteroData object
+        stores = getattr(blob, "_node_store_dict", None) or {}
+        store = stores.get("item")
+    if store is not None and not isinstance(store, dict):
+        store = getattr(store, "_mapping", None) or getattr(store, "__dict__", {}).get("_mapping")
+    if not isinstance(store, dict) or "x" not in store:
+        raise ValueError(f"{path}: neither a {{x, tags_emb, tags_indices, is_train}} dict nor the reference's processed HeteroData file")
+    out = {"x": torch.as_tensor(store["x"])}
+    for k in ("tags_emb", "tags_indices", "is_train"):
+        if k in store and store[k] is not None:
+            out[k] = torch.as_tensor(store[k])
+    return out
+
+
 class ResidentItemData:
     def __init__(self, x, tags_emb=None, tags_indices=None, device=None):
         dev = device or x.device
@@ -57,7 +109,9 @@ class ResidentItemData:
 
     @staticmethod
     def from_file(path, device):
-        blob = torch.load(path, map_location="cpu", weights_only=False)
+        """A plain dict {x, tags_emb, tags_indices, is_train}, or the reference's processed dataset file itself
+        (`title_data_<split>_5tags.pt`, written by torch_geometric's InMemoryDataset.save in data/tags_amazon.py:392-431)."""
+        blob = load_reference_processed(path)
         full = ResidentItemData(blob["x"], blob.get("tags_emb"), blob.get("tags_indices"), device=device)
         is_train = blob.get("is_train")
         return full, (is_train.to(device).bool() if is_train is not None else None)

@@ -105,3 +105,39 @@ def test_install_dropin_aliases_reference_module_names():
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_reference_processed_dataset_file_loads_without_torch_geometric(tmp_path):
+    """The reference writes its dataset with torch_geometric's InMemoryDataset.save: torch.save((HeteroData.to_dict(), slices,
+    <class HeteroData>), legacy serialization) (data/tags_amazon.py:392-431).  The loader must read it with torch_geometric
+    absent: a look-alike class is registered only while the file is WRITTEN, then removed."""
+    import sys
+    import types
+    import numpy as np
+    import torch
+    from hidvae_amd.data.items import load_reference_processed
+    assert "torch_geometric" not in sys.modules
+    pkg, sub, leaf = types.ModuleType("torch_geometric"), types.ModuleType("torch_geometric.data"), types.ModuleType("torch_geometric.data.hetero_data")
+    HeteroData = type("HeteroData", (), {"__module__": "torch_geometric.data.hetero_data"})
+    leaf.HeteroData = HeteroData
+    sys.modules.update({"torch_geometric": pkg, "torch_geometric.data": sub, "torch_geometric.data.hetero_data": leaf})
+    g = torch.Generator().manual_seed(0)
+    item = {"x": torch.randn(50, 768, generator=g), "text": np.array(["t%d" % i for i in range(50)]),
+            "tags_emb": torch.randn(50, 3, 768, generator=g), "tags": np.array([["a", "b", "c"]] * 50),
+            "tags_indices": torch.randint(-1, 30, (50, 3), generator=g), "is_train": torch.rand(50, generator=g) > 0.05}
+    payload = ({"_global_store": {}, "item": item, "user": {"x": torch.zeros(4, 2)}, ("user", "rated", "item"): {"edge_index": torch.zeros(2, 3)}},
+               None, HeteroData)
+    try:
+        for legacy in (False, True):  # the reference forces the legacy (non-zipfile) serialization
+            torch.save(payload, str(tmp_path / f"d{int(legacy)}.pt"), _use_new_zipfile_serialization=not legacy)
+    finally:
+        for k in ("torch_geometric", "torch_geometric.data", "torch_geometric.data.hetero_data"):
+            sys.modules.pop(k, None)
+    for legacy in (False, True):
+        got = load_reference_processed(str(tmp_path / f"d{int(legacy)}.pt"))
+        assert set(got) == {"x", "tags_emb", "tags_indices", "is_train"}
+        for k in got:
+            assert torch.equal(got[k], item[k]), k
+    plain = {"x": item["x"], "is_train": item["is_train"]}
+    torch.save(plain, str(tmp_path / "plain.pt"))
+    assert set(load_reference_processed(str(tmp_path / "plain.pt"))) == {"x", "is_train"}
