@@ -60,6 +60,8 @@ _SIGNATURES = {
     "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _vp],
     "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_padded_to_jagged": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp],
+    "hidvae_jagged_to_padded": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
 }
@@ -585,3 +587,25 @@ def gumbel_rows_bwd(P, gP, temperature):
 def gumbel_finish(g_x, x, emb, g_xx, g_l, beta, g_cb, cb, gS_colsum):
     _check(lib().hidvae_gumbel_finish(_p(g_x), _p(x), _p(emb), _p(g_xx), _p(g_l), _vec_stride(g_l), float(beta), x.shape[0], _p(g_cb), _p(cb),
                                       _p(gS_colsum), cb.shape[0], _stream()), "hidvae_gumbel_finish")
+
+
+# ------------------------------------------------------------------------------------------------ jagged copy (stage-2 op)
+def padded_to_jagged(x, offsets, total):
+    """x [B,N,D] (last dim contiguous, any dtype), offsets [B+1] int64 device -> values [total, D]"""
+    B, N, D = x.shape
+    if not x.is_cuda or x.stride(2) != 1:
+        raise RuntimeError("padded_to_jagged: expected a device tensor [B,N,D] with a contiguous last dim")
+    es = x.element_size()
+    values = torch.empty((total, D), device=x.device, dtype=x.dtype)
+    _check(lib().hidvae_padded_to_jagged(_p(x), x.stride(0) * es, x.stride(1) * es, _p(offsets), ctypes.c_void_p(values.data_ptr()), B, N,
+                                         D * es, _stream()), "hidvae_padded_to_jagged")
+    return values
+
+
+def jagged_to_padded(values, offsets, B, N):
+    D = values.shape[1]
+    es = values.element_size()
+    x = torch.empty((B, N, D), device=values.device, dtype=values.dtype)
+    _check(lib().hidvae_jagged_to_padded(ctypes.c_void_p(values.data_ptr()), _p(offsets), _p(x), N * D * es, D * es, B, N, D * es, _stream()),
+           "hidvae_jagged_to_padded")
+    return x

@@ -12,6 +12,7 @@ _DROPIN = {
     "modules.quantize": "modules.quantize", "modules.loss": "modules.loss", "modules.normalize": "modules.normalize",
     "modules.tokenizer": "modules.tokenizer", "modules.tokenizer.h_semids": "modules.tokenizer.h_semids",
     "init": "init", "init.kmeans": "init.kmeans", "data.schemas": "data.schemas", "data.utils": "data.utils",
+    "ops": "ops_hip", "ops.triton": "ops_hip", "ops.triton.jagged": "ops_hip.jagged",  # (stage-2 imports padded_to_jagged_tensor)
 }
 
 

@@ -313,6 +313,15 @@ int hidvae_gumbel_finish(float *g_x, const float *x, const float *emb, const flo
                          int64_t gl_stride, float beta, int64_t B, float *g_cb, const float *cb, const float *gS_colsum,
                          int64_t K, void *stream);
 
+/* ---- the stage-2 transformer's padded -> jagged copy (reference ops/triton/jagged.py:9-124, a Triton kernel
+ * there).  x [B, N, D] of any element type (strides in BYTES, D contiguous, row_bytes = D * element size); offsets [B+1] = the
+ * exclusive scan of lengths (int64, device); values [offsets[B], D] receives the first lengths[b] rows of every entry back to
+ * back.  jagged_to_padded is the adjoint (the reference's backward: padding rows become zero). */
+int hidvae_padded_to_jagged(const void *x, int64_t stride_b_bytes, int64_t stride_n_bytes, const int64_t *offsets, void *values,
+                            int64_t B, int64_t N, int64_t row_bytes, void *stream);
+int hidvae_jagged_to_padded(const void *values, const int64_t *offsets, void *x, int64_t stride_b_bytes, int64_t stride_n_bytes,
+                            int64_t B, int64_t N, int64_t row_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

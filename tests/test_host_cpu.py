@@ -99,7 +99,9 @@ def test_install_dropin_aliases_reference_module_names():
     code = ("import sys; sys.path.insert(0, %r); import hidvae_amd; hidvae_amd.install_dropin(); "
             "from modules.h_rqvae import HRqVae; from modules.quantize import QuantizeForwardMode, Quantize; "
             "from data.schemas import HRqVaeComputedLosses, TaggedSeqBatch; from modules.tokenizer.h_semids import HSemanticIdTokenizer; "
-            "from init.kmeans import kmeans_init_; "
+            "from init.kmeans import kmeans_init_; from modules.rqvae import RqVae; "
+            "from ops.triton.jagged import padded_to_jagged_tensor, jagged_to_flattened_tensor; "
+            "assert RqVae.__module__ == 'hidvae_amd.modules.rqvae' and padded_to_jagged_tensor.__module__ == 'hidvae_amd.ops_hip.jagged'; "
             "assert HRqVae.__module__ == 'hidvae_amd.modules.h_rqvae' and QuantizeForwardMode.ROTATION_TRICK.value == 3; "
             "assert HRqVaeComputedLosses._fields[0] == 'loss' and len(HRqVaeComputedLosses._fields) == 12; print('ok')"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -268,3 +268,28 @@ def test_bottleneck_launch_is_bit_identical_to_the_separate_launches(C, B, mode,
     want = dict(pre2=pre2, h2=h2, y=y, z=z, ids=ids, emb_cat=emb_cat, emb_sum=emb_sum, qloss=qloss, pre_d0=pre_d0, d0=d0, pre_d1=pre_d1, d1=d1)
     for k, v in want.items():
         assert torch.equal(o[k], v), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,D", [(7, 20, 64), (33, 5, 128), (4, 50, 6), (1, 1, 8)])
+def test_padded_to_jagged_and_its_backward(C, dtype, B, N, D):
+    """the stage-2 jagged copy (reference ops/triton/jagged.py) against its definition: values = the first lengths[b] rows of
+    every entry back to back; gradient = the same rows scattered back, zeros on the padding"""
+    from hidvae_amd.ops_hip.jagged import jagged_to_flattened_tensor, padded_to_jagged_tensor
+    g = torch.Generator().manual_seed(B * 100 + N)
+    x = torch.randn(B, N, D, generator=g).to(dtype).cuda().requires_grad_(True)
+    lengths = torch.randint(0, N + 1, (B,), generator=g)
+    lengths[0] = N
+    nt = padded_to_jagged_tensor(x, lengths.cuda(), N)
+    vals = jagged_to_flattened_tensor(nt)
+    want = torch.cat([x.detach()[b, :int(lengths[b])] for b in range(B)], 0)
+    assert vals.shape == want.shape and torch.equal(vals.detach(), want)
+    assert nt.is_nested and [int(t.shape[0]) for t in nt.unbind()] == lengths.tolist()
+    w = torch.randn(want.shape, generator=g).to(dtype).cuda()
+    (vals * w).sum().backward()
+    gx = torch.zeros(B, N, D, dtype=dtype, device="cuda")
+    row = 0
+    for b in range(B):
+        gx[b, :int(lengths[b])] = w[row:row + int(lengths[b])]
+        row += int(lengths[b])
+    assert torch.equal(x.grad, gx)
