@@ -348,8 +348,10 @@ def main():
             line["large_batch_step"] = large_extra
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
+        if world > 1:
+            dist.barrier()  # the other ranks wait for rank 0's kernel timings instead of tearing the group down under it
         dist.destroy_process_group()
 
 
