@@ -317,8 +317,11 @@ def main():
 
     if rank == 0:
         if not args.kernels:  # profiling run of the step only (rocprofv3 timelines): no roofline object
-            print(json.dumps({"value": args.batch * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "note": "--kernels 0"}))
+            print(json.dumps({"value": args.batch * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "note": "--kernels 0"}),
+                  flush=True)
             if dist is not None:
+                if world > 1:
+                    dist.barrier()
                 dist.destroy_process_group()
             return
         ks = kernel_rooflines(args, m, device)
