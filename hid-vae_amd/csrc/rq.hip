@@ -15,6 +15,7 @@
 // how the semantic ids are proven bit-exact.  Exact fp32 makes this kernel MFMA-bound, not HBM-bound
 // (2*K*32 FLOP per item-level at the vector rate) -- see DESIGN.md for the roofline.
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -300,6 +301,199 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
         float loss;
         float esum[8];
         rq_level_loop<MODE, TRAIN, RESIDENT, CSPLIT>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss);
+        if (valid) {
+            if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
+            if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large batches: split-bf16 PREFILTER + exact confirmation.  The exact search above spends 8 fp32 MFMAs (256 cycles) per
+// 16 codes x 16 items; here every code row and every residual is split into two bf16 numbers (x = hi + lo + O(2^-18 |x|)) and the
+// three products hi.hi + hi.lo + lo.hi run on v_mfma_f32_16x16x32_bf16 (3 x 16 cycles for the same tile).  The approximate score
+// s_k = |c_k|^2 - 2 dot~ differs from the exact fp32 distance (minus |x|^2) by less than
+//     e = 2 (3 * 2^-18 + 128 * 2^-24) |x||c_k| + 2^-21 (|x|^2 + |c_k|^2)  <  2^-15 (|x|^2 + max_k |c_k|^2),
+// so if the runner-up's score exceeds the best by more than DELTA = 2^-14 (|x|^2 + max|c|^2), the approximate argmin IS the
+// exact argmin (the exact winner k* has s_k* <= d_k* + e <= d_j + e <= s_j + 2e for every j).  Each lane keeps the smallest and the
+// second smallest score it has seen (one v_med3 on top of the running minimum); an item whose two best scores are closer than DELTA is
+// re-searched exactly (the fp32 MFMA chain of rq_level_loop, codes read from global memory instead of LDS) -- wave-uniformly,
+// i.e. for the 16 items of that wave; ~0.1 % of item-levels on codebook-like data.  Everything after the argmin (winner row,
+// rotation, loss, residual) is the exact fp32 code, so ids and every float are bit-identical to rq_forward_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int PF_ROW = 40;  // bf16 per LDS code row: 32 + 8 padding (80 B: conflict-free 128-bit fragment reads)
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {  // round-to-nearest-even (finite inputs)
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split_bf16(float x, unsigned &hi, unsigned &lo) {
+    hi = bf16_rne(x);
+    lo = bf16_rne(x - __uint_as_float(hi << 16));
+}
+
+__host__ __device__ __forceinline__ size_t pf_level_bytes(int KC) { return (size_t)KC * (2 * PF_ROW * 2 + 4); }
+
+// stage level `lvl`: hi / lo bf16 images [KC][PF_ROW], |c|^2 [KC] (padding codes: zeros / +inf), and max |c|^2 into *ccmax_bits
+__device__ __forceinline__ void pf_stage(char *base, const FwdArgs &a, int lvl, unsigned *ccmax_bits) {
+    unsigned short *Ch = reinterpret_cast<unsigned short *>(base);
+    unsigned short *Cl = Ch + (size_t)a.KC * PF_ROW;
+    float *ccs = reinterpret_cast<float *>(Cl + (size_t)a.KC * PF_ROW);
+    const float *src = a.cb_eff + (int64_t)lvl * a.K * D;
+    for (int idx = threadIdx.x; idx < a.KC * 8; idx += blockDim.x) {
+        const int kl = idx >> 3, d4 = idx & 7;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kl < a.K) v = *reinterpret_cast<const float4 *>(src + (int64_t)kl * D + 4 * d4);
+        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+        split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+        *reinterpret_cast<uint2 *>(Ch + kl * PF_ROW + 4 * d4) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+        *reinterpret_cast<uint2 *>(Cl + kl * PF_ROW + 4 * d4) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+    }
+    float mx = 0.0f;
+    for (int kl = threadIdx.x; kl < a.KC; kl += blockDim.x) {
+        const float c = kl < a.K ? a.cc[(int64_t)lvl * a.K + kl] : INFINITY;
+        ccs[kl] = c;
+        if (kl < a.K) mx = fmaxf(mx, c);
+    }
+    atomicMax(ccmax_bits, __float_as_uint(mx));  // |c|^2 >= 0: the bit patterns order like the values
+}
+
+template <int MODE, bool TRAIN, int NW>
+__global__ __launch_bounds__(64 * NW) void rq_forward_prefilter_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char pf_lds[];
+    __shared__ unsigned ccmax_bits[HIDVAE_MAX_LEVELS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int it = lane & 15, q = lane >> 4;
+    const size_t lvl_bytes = pf_level_bytes(a.KC);
+    if (threadIdx.x < HIDVAE_MAX_LEVELS) ccmax_bits[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int i = 0; i < a.L; i++) pf_stage(pf_lds + i * lvl_bytes, a, i, &ccmax_bits[i]);
+    __syncthreads();
+    constexpr int TILE_ITEMS = ITEMS_PER_WAVE * NW;
+    const int64_t ntiles = (a.B + TILE_ITEMS - 1) / TILE_ITEMS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t item = tile * TILE_ITEMS + wave * ITEMS_PER_WAVE + it;
+        const bool valid = item < a.B;
+        const int64_t src = valid ? item : a.B - 1;
+        float r[8];
+        load8(a.y + src * D + 8 * q, r);
+        if (a.normalize_input) {
+            const float den = fmaxf(sqrtf(dotQ(r, r)), 1e-12f);
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = r[j] / den;
+        }
+        if (a.z != nullptr && valid) store8(a.z + item * D + 8 * q, r);
+        float loss = 0.0f;
+        float esum[8];
+        for (int i = 0; i < a.L; i++) {
+            if (a.res_cat != nullptr && valid) store8(a.res_cat + item * (a.L * D) + i * D + 8 * q, r);
+            const float xx = dotQ(r, r);
+            const char *base = pf_lds + i * lvl_bytes;
+            const unsigned short *Ch = reinterpret_cast<const unsigned short *>(base);
+            const unsigned short *Cl = Ch + (size_t)a.KC * PF_ROW;
+            const float *ccs = reinterpret_cast<const float *>(Cl + (size_t)a.KC * PF_ROW);
+            // the residual as two bf16 B fragments (k = 8q + j: exactly the dims this lane holds)
+            unsigned hw[8], lw[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) split_bf16(r[j], hw[j], lw[j]);
+            const uint4 bhu = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+            const uint4 blu = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bhu), bl = __builtin_bit_cast(bf16x8_t, blu);
+            float best1 = INFINITY, best2 = INFINITY;
+            int idx1 = 0;
+            const unsigned short *ah_row = Ch + it * PF_ROW + 8 * q, *al_row = Cl + it * PF_ROW + 8 * q;
+            for (int t = 0; t < a.KC; t += 32) {  // two independent 16-code tiles per iteration
+                const bf16x8_t ah0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(ah_row + t * PF_ROW));
+                const bf16x8_t al0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(al_row + t * PF_ROW));
+                const bf16x8_t ah1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(ah_row + (t + 16) * PF_ROW));
+                const bf16x8_t al1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(al_row + (t + 16) * PF_ROW));
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bh, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bl, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bl, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bh, acc1, 0, 0, 0);
+                const float4 c0 = *reinterpret_cast<const float4 *>(ccs + t + 4 * q);
+                const float4 c1 = *reinterpret_cast<const float4 *>(ccs + t + 16 + 4 * q);
+                const float cc0[4] = {c0.x, c0.y, c0.z, c0.w};
+                const float cc1[4] = {c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float s0 = fmaf(-2.0f, acc0[g], cc0[g]);
+                    best2 = __builtin_amdgcn_fmed3f(best1, best2, s0);
+                    if (s0 < best1) { best1 = s0; idx1 = t + 4 * q + g; }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float s1 = fmaf(-2.0f, acc1[g], cc1[g]);
+                    best2 = __builtin_amdgcn_fmed3f(best1, best2, s1);
+                    if (s1 < best1) { best1 = s1; idx1 = t + 16 + 4 * q + g; }
+                }
+            }
+            // (packing the code number into the scores' low mantissa bits -- one v_max + one v_med3 per score -- was tried: 4 %
+            //  slower; the loop is bound by latencies, not by VALU issue)
+            // merge the item's 4 quarter-lanes: smallest (lowest index on ties) and second smallest of the union
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float o1 = __shfl_xor(best1, o), o2 = __shfl_xor(best2, o);
+                const int oi = __shfl_xor(idx1, o);
+                best2 = fminf(fmaxf(best1, o1), fminf(best2, o2));
+                if (o1 < best1 || (o1 == best1 && oi < idx1)) { best1 = o1; idx1 = oi; }
+            }
+            const float delta = 6.103515625e-05f * (xx + __uint_as_float(ccmax_bits[i]));  // 2^-14 (|x|^2 + max |c|^2)
+            int bidx = idx1;
+            if (__ballot(!(best2 - best1 > delta)) != 0ull) {  // some item of this wave is too close to call: exact search
+                float best = INFINITY;
+                bidx = 0;
+                const float *cbl = a.cb_eff + (int64_t)i * a.K * D;
+                const float *ccl = a.cc + (int64_t)i * a.K;
+                for (int t = 0; t < a.KC; t += 16) {
+                    float av[8];
+                    if (t + it < a.K) load8(cbl + (int64_t)(t + it) * D + 8 * q, av);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) av[j] = 0.0f;
+                    }
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], r[j], acc, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int k = t + 4 * q + g;
+                        const float cck = k < a.K ? ccl[k] : INFINITY;
+                        const float d0 = fmaf(-2.0f, acc[g], xx + cck);
+                        if (d0 < best) { best = d0; bidx = k; }
+                    }
+                }
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float ob = __shfl_xor(best, o);
+                    const int oi = __shfl_xor(bidx, o);
+                    if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+                }
+            }
+            float e[8];
+            load8(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 8 * q, e);
+            const float cce = a.cc[(int64_t)i * a.K + bidx];
+            float o[8], u[8], qv[8], w[8];
+            level_output<MODE, TRAIN>(r, e, xx, cce, o, u, qv, w);
+            float df[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) df[j] = r[j] - e[j];
+            const float l1 = dotQ(df, df);
+            loss = loss + (l1 + a.beta * l1);
+            if (valid) {
+                if (q == 0) a.ids[item * a.L + i] = (int64_t)bidx;
+                if (a.emb_cat != nullptr) store8(a.emb_cat + item * a.ld_cat + i * D + 8 * q, o);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                esum[j] = (i == 0) ? o[j] : esum[j] + o[j];
+                r[j] = r[j] - o[j];
+            }
+        }
         if (valid) {
             if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
             if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
@@ -733,6 +927,29 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     const int64_t ntiles = hv_cdiv(B, csplit ? ITEMS_PER_WAVE : ITEMS_PER_WAVE * nw);
     const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU (LDS-limited), grid-stride over tiles
     hipStream_t s = (hipStream_t)stream;
+    // large batches whose codebooks fit as bf16 hi/lo images: split-bf16 prefilter + exact confirmation (bit-identical results)
+    static const bool prefilter_on = !(getenv("HIDVAE_RQ_PREFILTER") && getenv("HIDVAE_RQ_PREFILTER")[0] == '0');
+    const int KCp = (int)(hv_cdiv(K, 32) * 32);
+    const size_t pf_lds_bytes = pf_level_bytes(KCp) * (size_t)L;
+    if (prefilter_on && B >= 256 * 256 && pf_lds_bytes <= 152 * 1024) {
+        FwdArgs p = a;
+        p.KC = KCp;
+        p.nchunks = 1;
+        const int64_t nt = hv_cdiv(B, ITEMS_PER_WAVE * 16);
+        const int pgrid = (int)(nt < 256 ? nt : 256);
+#define HV_PF(M, T)                                                                                                            \
+    {                                                                                                                          \
+        auto kern = rq_forward_prefilter_kernel<M, T, 16>;                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_lds_bytes); \
+        hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * 16), pf_lds_bytes, s, p);                                              \
+    }
+        if (!training) HV_PF(HIDVAE_MODE_STE, false)
+        else if (mode == HIDVAE_MODE_STE) HV_PF(HIDVAE_MODE_STE, true)
+        else HV_PF(HIDVAE_MODE_ROTATION, true)
+#undef HV_PF
+        HV_LAUNCH_CHECK("rq_forward prefilter");
+        return HIDVAE_OK;
+    }
     if (!training) return launch_fwd<HIDVAE_MODE_STE, false>(a, resident, csplit, nw, grid, lds, s);
     if (mode == HIDVAE_MODE_STE) return launch_fwd<HIDVAE_MODE_STE, true>(a, resident, csplit, nw, grid, lds, s);
     return launch_fwd<HIDVAE_MODE_ROTATION, true>(a, resident, csplit, nw, grid, lds, s);

@@ -160,3 +160,33 @@ def test_device_rand_provider_properties():
     r.begin_step(dev)
     odd = r.dropout_keep((100, 512), 0.1, dev)  # a different request list: individual draw, plan dropped
     assert tuple(odd.shape) == (100, 512) and r._plan is None
+
+
+@pytest.mark.parametrize("mode,training", [(3, True), (2, True), (3, False)])
+@pytest.mark.parametrize("kind", ["spread", "near_duplicates", "exact_duplicates", "tiny_residuals"])
+def test_prefilter_kernel_is_bit_identical_to_the_exact_kernel(C, mode, training, kind):
+    """Batches >= 65536 take the split-bf16 prefilter kernel (approximate scores on bf16 MFMA, exact re-search where the two best
+    scores are closer than the error bound); smaller launches take the exact fp32 kernel.  Same items through both: every output
+    must match bit for bit -- also when most items are ambiguous (near-duplicate / duplicate codes) and when residual norms
+    collapse (levels whose codes are far larger than the residual)."""
+    N, L, K = 70000, 3, 256
+    g = torch.Generator(device="cuda").manual_seed(17)
+    tabs = tables(L, K, 81)
+    if kind == "near_duplicates":
+        for t in tabs:
+            t[K // 2:] = t[:K // 2] * (1.0 + 1e-6 * torch.randn(K // 2, 1, device="cuda", generator=g))
+    elif kind == "exact_duplicates":
+        for t in tabs:
+            t[K // 2:] = t[:K // 2]
+    elif kind == "tiny_residuals":
+        tabs[1] = tabs[1] * 50.0
+        tabs[2] = tabs[2] * 1e-4
+    y = torch.randn(N, 32, device="cuda", generator=g)
+    cb, cc = C.codebook_prepare(tabs, [True, False, False])
+    big = C.rq_forward(y, cb, cc, True, mode, training, 0.4, want_res=True)
+    half = N // 2
+    parts = [C.rq_forward(y[lo:hi].contiguous(), cb, cc, True, mode, training, 0.4, want_res=True) for lo, hi in ((0, half), (half, N))]
+    names = ("z", "ids", "emb_cat", "emb_sum", "res_cat", "qloss")
+    for j, name in enumerate(names):
+        want = torch.cat([p[j] for p in parts], 0)
+        assert torch.equal(big[j], want), (kind, name, int((big[j] != want).sum()))
