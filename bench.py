@@ -153,10 +153,11 @@ def kernel_rooflines(args, m, device):
     yb = torch.randn(big, 32, device=device)
     t = time_kernel(lambda: _C.rq_forward(yb, cb, cc, True, 3, True, 0.4), launches=2, reps=5)
     algb = (128 + 8 * L + 128 * L + 4) * big + 4 * L * K * 32
-    out.append(dict(kernel="rq_forward_kernel at 1,048,576 items (corpus-sized launch)", bound="hbm", achieved=algb / t * 1e-3,
+    out.append(dict(kernel="rq_forward at 1,048,576 items (corpus-sized launch: rq_forward_prefilter_kernel, split-bf16 prefilter + exact confirmation)",
+                    bound="hbm", achieved=algb / t * 1e-3,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=algb / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t, algorithmic_bytes=algb,
                     bytes_moved=(128 + 8 * L + 128 * L + 128 + 128 + 4) * big + 4 * L * K * 32,
-                    mfma_f32_frac=2.0 * big * L * K * 32 / t * 1e-6 / MFMA_F32_PEAK_TF, items_per_s=big / t * 1e6))
+                    fp32_equivalent_mfma_frac=2.0 * big * L * K * 32 / t * 1e-6 / MFMA_F32_PEAK_TF, items_per_s=big / t * 1e6))
     return out
 
 

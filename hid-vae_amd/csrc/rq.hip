@@ -324,9 +324,9 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int PF_ROW = 40;  // bf16 per LDS code row: 32 + 8 padding (80 B: conflict-free 128-bit fragment reads)
 
-__device__ __forceinline__ unsigned bf16_rne(float x) {  // round-to-nearest-even (finite inputs)
-    const unsigned u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+__device__ __forceinline__ unsigned bf16_rne(float x) {  // round-to-nearest-even: v_cvt_pk_bf16_f32 on gfx950
+    const __bf16 h = (__bf16)x;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 __device__ __forceinline__ void split_bf16(float x, unsigned &hi, unsigned &lo) {
     hi = bf16_rne(x);
