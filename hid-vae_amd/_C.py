@@ -62,6 +62,7 @@ _SIGNATURES = {
     "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_padded_to_jagged": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp],
     "hidvae_jagged_to_padded": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
+    "hidvae_codebook_prepare_adamw": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
 }
@@ -213,8 +214,35 @@ def codebook_prepare(tables, normalize_flags):
     cb = torch.empty((L, K, D), device=tables[0].device, dtype=torch.float32)
     cc = torch.empty((L, K), device=tables[0].device, dtype=torch.float32)
     flags = (ctypes.c_int32 * L)(*[int(bool(f)) for f in normalize_flags])
+    carried = take_pending_adamw(tables[0].device)
+    if carried is not None:  # the optimizer's per-step scalars ride along in this launch (one workgroup more)
+        desc, step_dev, b1, b2, eta_min, T_max, step_size, gamma = carried
+        _check(lib().hidvae_codebook_prepare_adamw(_host_ptr_array(tables), flags, L, K, _p(cb), _p(cc), _p(step_dev), _p(desc["lr"]),
+                                                   _p(desc["wd"]), int(desc["n"]), float(b1), float(b2), float(eta_min), int(T_max),
+                                                   int(step_size), float(gamma), _p(desc["hyper"]), _stream()),
+               "hidvae_codebook_prepare_adamw")
+        return cb, cc
     _check(lib().hidvae_codebook_prepare(_host_ptr_array(tables), flags, L, K, _p(cb), _p(cc), _stream()), "hidvae_codebook_prepare")
     return cb, cc
+
+
+# The optimizer's start-of-step launch (adamw_prepare) may be deferred: whoever launches codebook_prepare next on the same device
+# carries it, and optimizer.step() launches it itself if nobody did.  `owner` lets the optimizer tell whether it is still pending.
+_PENDING_ADAMW = {}
+
+
+def defer_adamw_prepare(device, owner, args):
+    _PENDING_ADAMW[torch.device(device).index or 0] = (owner, args)
+
+
+def take_pending_adamw(device, owner=None):
+    key = torch.device(device).index or 0
+    ent = _PENDING_ADAMW.get(key)
+    if ent is None or (owner is not None and ent[0] is not owner):
+        return None
+    del _PENDING_ADAMW[key]
+    ent[0]._prepared = True
+    return ent[1]
 
 
 def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=False, want_z=True):

@@ -54,6 +54,35 @@ __device__ __forceinline__ float hv_dgelu(float a) {
     return cdf + a * pdf;
 }
 
+// per-step AdamW scalars in double precision, once per tensor (torch computes them on the host in double), and the step counter
+// itself.  Executed by ONE whole workgroup (adamw_prepare_kernel, or a spare workgroup of a launch that carries it).
+struct HvAdamPrepare {
+    int64_t *step;
+    const float *base_lr, *wd;
+    int n;
+    float beta1, beta2, eta_min;
+    int64_t T_max, step_size;
+    float gamma;
+    float *hyper;
+};
+__device__ __forceinline__ void hv_adamw_prepare(const HvAdamPrepare &a) {
+    const int64_t t1 = *a.step + 1;  // torch counts the step being taken from 1
+    for (int t = threadIdx.x; t < a.n; t += blockDim.x) {
+        double lr = (double)a.base_lr[t];
+        if (a.T_max > 0)  // CosineAnnealingLR after (t1 - 1) scheduler steps, closed form
+            lr = (double)a.eta_min + (lr - (double)a.eta_min) * (1.0 + cos(M_PI * (double)(t1 - 1) / (double)a.T_max)) * 0.5;
+        else if (a.step_size > 0)  // StepLR after (t1 - 1) scheduler steps: base * gamma^floor((t1-1)/step_size)
+            lr = lr * pow((double)a.gamma, (double)((t1 - 1) / a.step_size));
+        const double bc1 = 1.0 - pow((double)a.beta1, (double)t1);
+        const double bc2 = 1.0 - pow((double)a.beta2, (double)t1);
+        a.hyper[3 * t + 0] = (float)(1.0 - lr * (double)a.wd[t]);
+        a.hyper[3 * t + 1] = (float)(lr / bc1);
+        a.hyper[3 * t + 2] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *a.step = t1;
+}
+
 __device__ __forceinline__ float hv_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -146,26 +146,8 @@ struct AdamArgs {
     float beta1, beta2, eps, grad_scale;
 };
 
-// per-step scalars in double precision, once per tensor (torch computes them on the host in double), and the step
-// counter itself: one tiny launch that depends on nothing, so it runs on the helper stream beside forward/backward
-__global__ void adamw_prepare_kernel(int64_t *step, const float *base_lr, const float *wd, int n, float beta1, float beta2,
-                                     float eta_min, int64_t T_max, int64_t step_size, float gamma, float *hyper) {
-    const int64_t t1 = *step + 1;  // torch counts the step being taken from 1
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-        double lr = (double)base_lr[t];
-        if (T_max > 0)  // CosineAnnealingLR after (t1 - 1) scheduler steps, closed form
-            lr = (double)eta_min + (lr - (double)eta_min) * (1.0 + cos(M_PI * (double)(t1 - 1) / (double)T_max)) * 0.5;
-        else if (step_size > 0)  // StepLR after (t1 - 1) scheduler steps: base * gamma^floor((t1-1)/step_size)
-            lr = lr * pow((double)gamma, (double)((t1 - 1) / step_size));
-        const double bc1 = 1.0 - pow((double)beta1, (double)t1);
-        const double bc2 = 1.0 - pow((double)beta2, (double)t1);
-        hyper[3 * t + 0] = (float)(1.0 - lr * (double)wd[t]);
-        hyper[3 * t + 1] = (float)(lr / bc1);
-        hyper[3 * t + 2] = (float)sqrt(bc2);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *step = t1;
-}
+// one tiny launch (or a spare workgroup of hidvae_codebook_prepare_adamw, which saves the launch): see hv_adamw_prepare
+__global__ void adamw_prepare_kernel(HvAdamPrepare a) { hv_adamw_prepare(a); }
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     const int t = a.first + blockIdx.y;
@@ -286,8 +268,8 @@ extern "C" int hidvae_adamw_prepare(int64_t *step_dev, const float *base_lr_dev,
                                     float beta2, float eta_min, int64_t T_max, int64_t step_size, float gamma, float *hyper_dev,
                                     void *stream) {
     HV_REQUIRE(step_dev && base_lr_dev && wd_dev && hyper_dev && n_tensors >= 1, "adamw_prepare: bad arguments");
-    hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_dev, base_lr_dev, wd_dev, n_tensors,
-                       beta1, beta2, eta_min, T_max, step_size, gamma, hyper_dev);
+    const HvAdamPrepare a{step_dev, base_lr_dev, wd_dev, n_tensors, beta1, beta2, eta_min, T_max, step_size, gamma, hyper_dev};
+    hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     HV_LAUNCH_CHECK("adamw_prepare");
     return HIDVAE_OK;
 }

@@ -90,9 +90,15 @@ struct PrepArgs {
     int64_t K;
     float *cb_eff;
     float *cc;
+    int carry;             // one extra workgroup (the last) computes the optimizer's per-step scalars: both are tiny start-of-step
+    HvAdamPrepare adam;    // launches that depend on nothing, and a launch costs more than either of them
 };
 
 __global__ __launch_bounds__(WG_THREADS) void codebook_prepare_kernel(PrepArgs a) {
+    if (a.carry && blockIdx.x == gridDim.x - 1) {
+        hv_adamw_prepare(a.adam);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int it = lane & 15, q = lane >> 4;
     const int64_t rows = (int64_t)a.L * a.K;
@@ -894,6 +900,27 @@ extern "C" int hidvae_codebook_prepare(const float *const *E_host, const int32_t
     const int grid = (int)hv_cdiv((int64_t)L * K, ITEMS_PER_WG);
     hipLaunchKernelGGL(codebook_prepare_kernel, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
     HV_LAUNCH_CHECK("codebook_prepare");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_codebook_prepare_adamw(const float *const *E_host, const int32_t *normalize_host, int L, int64_t K, float *cb_eff,
+                                             float *cc, int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
+                                             float beta1, float beta2, float eta_min, int64_t T_max, int64_t step_size, float gamma,
+                                             float *hyper_dev, void *stream) {
+    HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "codebook_prepare_adamw: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
+    HV_REQUIRE(K >= 1 && E_host && cb_eff && cc, "codebook_prepare_adamw: bad arguments");
+    HV_REQUIRE(step_dev && base_lr_dev && wd_dev && hyper_dev && n_tensors >= 1, "codebook_prepare_adamw: bad optimizer arguments");
+    PrepArgs a{};
+    for (int i = 0; i < L; i++) {
+        a.E[i] = E_host[i];
+        a.normalize[i] = normalize_host ? normalize_host[i] : 0;
+    }
+    a.L = L; a.K = K; a.cb_eff = cb_eff; a.cc = cc;
+    a.carry = 1;
+    a.adam = HvAdamPrepare{step_dev, base_lr_dev, wd_dev, n_tensors, beta1, beta2, eta_min, T_max, step_size, gamma, hyper_dev};
+    const int grid = (int)hv_cdiv((int64_t)L * K, ITEMS_PER_WG) + 1;
+    hipLaunchKernelGGL(codebook_prepare_kernel, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("codebook_prepare_adamw");
     return HIDVAE_OK;
 }
 

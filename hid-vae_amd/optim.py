@@ -76,19 +76,29 @@ class HidvaeAdamW(torch.optim.Optimizer):
             self._build()
         return self
 
-    def _prepare_step_async(self):
-        """schedule / bias-correction scalars + step counter for the coming step, on the helper stream (depends on nothing)"""
-        from .ops import side_stream
-        main, side = torch.cuda.current_stream(), side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            _C.adamw_prepare(self._desc, self.step_dev, self.betas[0], self.betas[1], self.eta_min, self.T_max, self.step_size, self.gamma)
+    def _pending(self):
+        ent = _C._PENDING_ADAMW.get(self.step_dev.device.index or 0)
+        return ent is not None and ent[0] is self
+
+    def _prepare_args(self):
+        return (self._desc, self.step_dev, self.betas[0], self.betas[1], self.eta_min, self.T_max, self.step_size, self.gamma)
+
+    def _prepare_step_async(self, defer=False):
+        """schedule / bias-correction scalars + step counter for the coming step.  It depends on nothing, so at zero_grad() time
+        it is only REGISTERED: the model's codebook_prepare launch of the coming forward carries it in a spare workgroup
+        (_C.codebook_prepare), and step() launches it itself if no forward came by."""
+        if defer:
+            _C.defer_adamw_prepare(self.step_dev.device, self, self._prepare_args())
+            return
+        if _C.take_pending_adamw(self.step_dev.device, owner=self) is None and self._prepared:
+            return
+        _C.adamw_prepare(*self._prepare_args())
         self._prepared = True
 
     def zero_grad(self, set_to_none=True):
         self.prepare()
-        if not self._prepared:
-            self._prepare_step_async()
+        if not self._prepared and not self._pending():
+            self._prepare_step_async(defer=True)
         if self.flat_grads:
             self.grad_buffer.zero()
         else:

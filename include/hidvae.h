@@ -220,6 +220,12 @@ int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, in
 int hidvae_adamw_prepare(int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n,
                          float beta1, float beta2, float eta_min, int64_t T_max, int64_t step_size, float gamma,
                          float *hyper_dev, void *stream);
+/* hidvae_codebook_prepare and hidvae_adamw_prepare in ONE launch (one extra workgroup): both are start-of-step launches that
+ * depend on nothing, each far shorter than a launch costs. */
+int hidvae_codebook_prepare_adamw(const float *const *E_host, const int32_t *normalize_host, int L, int64_t K, float *cb_eff,
+                                  float *cc, int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
+                                  float beta1, float beta2, float eta_min, int64_t T_max, int64_t step_size, float gamma,
+                                  float *hyper_dev, void *stream);
 int hidvae_adamw_step(float *const *p_dev, const float *const *g_host, float *const *m_dev, float *const *v_dev,
                       const int64_t *numel_dev, const float *hyper_dev, int n_tensors, int64_t max_numel,
                       float beta1, float beta2, float eps, float grad_scale, void *stream);
