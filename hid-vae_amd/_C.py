@@ -266,7 +266,7 @@ def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=Fa
 
 def bottleneck_eligible(B, K2, N2, Nd0, Nd1, L, K):
     """the fused middle-of-the-step launch: small batches, widths the kernel keeps in LDS, codebooks resident beside them"""
-    Kp = (K + 127) // 128 * 128
+    Kp = (K + 255) // 256 * 256  # (the launch's 8 waves each scan a share of the codes, 32 at a time)
     lds = L * (33 * Kp + 64) * 4 + (2 * 16 * 64 + 2 * 64) * 16
     return (B <= 4096 and all(v % 16 == 0 and v >= 16 for v in (K2, N2, Nd0, Nd1)) and max(K2, N2, Nd0) <= 256 and Kp <= 1024
             and lds <= 160 * 1024 - 1024)

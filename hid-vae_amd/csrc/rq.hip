@@ -170,8 +170,8 @@ __device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl
 // search per wave; results are bit-identical to the unsplit kernel.
 // The level loop for one 16-item tile held as r[8] per lane (see the geometry note at the top): argmin per level, output,
 // loss, residual update, stores of ids / emb_cat / res_cat.  r is consumed; esum and loss are returned in registers.
-template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT>
-__device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, float (*cand_d)[4][16], int (*cand_i)[4][16], int &phase,
+template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT, int SW = 4>  // SW: waves that share the codes of one 16-item tile
+__device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, float (*cand_d)[SW][16], int (*cand_i)[SW][16], int &phase,
                                               int wave, int it, int q, int64_t item, bool valid, float (&r)[8], float (&esum)[8],
                                               float &loss) {
     const int LDK = a.KC + 2;
@@ -196,7 +196,7 @@ __device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, floa
             const float *arow = Cs + (8 * q) * LDK + it;
             const int cbase = c * a.KC + 4 * q;
             // two 16-code tiles per iteration: two independent accumulator chains keep the MFMA pipe full
-            const int t_lo = CSPLIT ? wave * (a.KC / 4) : 0, t_hi = CSPLIT ? (wave + 1) * (a.KC / 4) : a.KC;
+            const int t_lo = CSPLIT ? wave * (a.KC / SW) : 0, t_hi = CSPLIT ? (wave + 1) * (a.KC / SW) : a.KC;
             for (int t = t_lo; t < t_hi; t += 32) {
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -237,7 +237,7 @@ __device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, floa
             best = cand_d[pb][0][it];
             bidx = cand_i[pb][0][it];
 #pragma unroll
-            for (int ww = 1; ww < 4; ww++) {
+            for (int ww = 1; ww < SW; ww++) {
                 const float ob = cand_d[pb][ww][it];
                 const int oi = cand_i[pb][ww][it];
                 if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_prefilter_kernel(FwdArgs a
 // The narrow middle of the step in ONE launch (small batches): the encoder's last two layers, the L-level quantisation and the
 // decoder's first two layers are all row-local, 16 items wide here, and each is a ~5 us launch on its own:
 //     h2 = silu(h1 W2^T) -> y = h2 W3^T -> [z = normalize(y)] -> L levels -> d0 = silu(emb_sum Wd0^T) -> d1 = silu(d0 Wd1^T)
-// One workgroup (4 waves) per 16 items.  Every Linear runs on v_mfma_f32_16x16x4_f32 with the WEIGHT rows as the A operand
+// One workgroup (8 waves) per 16 items.  Every Linear runs on v_mfma_f32_16x16x4_f32 with the WEIGHT rows as the A operand
 // (straight from global memory, 16 bytes per lane per 16-wide k-block) and the 16 ITEMS as the B operand, which makes the
 // accumulator layout of one layer (lane = item + 16 q, register r  <->  feature 16 t + 4 q + r of output tile t) exactly the B
 // operand layout of k-block t of the next layer: activations pass from layer to layer as float4-per-lane images in LDS with no
@@ -536,14 +536,15 @@ struct BneckArgs {
 constexpr int BN_HMAX = 256;  // widest activation kept in LDS (features per item)
 
 // One Linear layer for the workgroup's 16 items.  Hin: K/16 float4-per-lane k-block images; outputs: pre (before the activation,
-// optional), act (after it) to global [B, N] and act to Hout (optional).  Output tiles are dealt to the 4 waves round-robin, two
-// tiles in flight per wave.
+// optional), act (after it) to global [B, N] and act to Hout (optional).  Output tiles are dealt to the workgroup's waves round-robin,
+// two tiles in flight per wave.
+template <int NWAVES>
 __device__ __forceinline__ void bneck_layer(const float *W, int N, int K, const float4 *Hin, bool silu, float *pre, float *act,
                                             float4 *Hout, int64_t item, bool valid, int wave, int lane) {
     const int i16 = lane & 15, q = lane >> 4;
     const int ntile = N / 16, nkb = K / 16;
-    for (int t0 = wave; t0 < ntile; t0 += 8) {
-        const int t1 = t0 + 4;
+    for (int t0 = wave; t0 < ntile; t0 += 2 * NWAVES) {
+        const int t1 = t0 + NWAVES;
         const bool two = t1 < ntile;
         const float *w0 = W + (int64_t)(16 * t0 + i16) * K + 4 * q;
         const float *w1 = W + (int64_t)(16 * (two ? t1 : t0) + i16) * K + 4 * q;
@@ -580,11 +581,13 @@ __device__ __forceinline__ void bneck_layer(const float *W, int N, int K, const 
     }
 }
 
+constexpr int BN_WAVES = 8;  // waves per workgroup: they share the 16 items; output tiles and code ranges are dealt among them
+
 template <int MODE>
-__global__ __launch_bounds__(WG_THREADS) void bottleneck_fwd_kernel(BneckArgs b) {
+__global__ __launch_bounds__(64 * BN_WAVES) void bottleneck_fwd_kernel(BneckArgs b) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float cand_d[2][4][16];
-    __shared__ int cand_i[2][4][16];
+    __shared__ float cand_d[2][BN_WAVES][16];
+    __shared__ int cand_i[2][BN_WAVES][16];
     const FwdArgs &a = b.rq;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int it = lane & 15, q = lane >> 4;
@@ -597,16 +600,16 @@ __global__ __launch_bounds__(WG_THREADS) void bottleneck_fwd_kernel(BneckArgs b)
     const bool in_range = item < a.B;
     const int64_t src = in_range ? item : a.B - 1;
     // the items' input rows as k-block images (all four waves need all of them)
-    for (int idx = threadIdx.x; idx < (b.K2 / 16) * 64; idx += WG_THREADS) {
+    for (int idx = threadIdx.x; idx < (b.K2 / 16) * 64; idx += 64 * BN_WAVES) {
         const int kb = idx >> 6, l = idx & 63;
         const int64_t row = (int64_t)blockIdx.x * ITEMS_PER_WAVE + (l & 15);
         HA[idx] = *reinterpret_cast<const float4 *>(b.h1 + (row < a.B ? row : a.B - 1) * b.K2 + 16 * kb + 4 * (l >> 4));
     }
     for (int i = 0; i < a.L; i++) stage_codes(lds + i * lvl_floats, a, i, 0);
     __syncthreads();
-    bneck_layer(b.W2, b.N2, b.K2, HA, true, b.pre2, b.h2, HB, item, in_range, wave, lane);
+    bneck_layer<BN_WAVES>(b.W2, b.N2, b.K2, HA, true, b.pre2, b.h2, HB, item, in_range, wave, lane);
     __syncthreads();
-    bneck_layer(b.W3, D, b.N2, HB, false, nullptr, b.y_out, HY, item, in_range, wave, lane);
+    bneck_layer<BN_WAVES>(b.W3, D, b.N2, HB, false, nullptr, b.y_out, HY, item, in_range, wave, lane);
     __syncthreads();
     // quantiser geometry: lane (it, q) holds dims 8q .. 8q+7 = registers of (tile q>>1, quarter 2(q&1)) and (.., 2(q&1)+1)
     float r[8];
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(WG_THREADS) void bottleneck_fwd_kernel(BneckArgs b)
     float loss;
     float esum[8];
     int phase = 0;
-    rq_level_loop<MODE, true, true, true>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss);
+    rq_level_loop<MODE, true, true, true, BN_WAVES>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss);
     if (valid) {
         if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
         if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
@@ -636,9 +639,9 @@ __global__ __launch_bounds__(WG_THREADS) void bottleneck_fwd_kernel(BneckArgs b)
         HY[(q >> 1) * 64 + (2 * (q & 1) + 1) * 16 + it] = make_float4(esum[4], esum[5], esum[6], esum[7]);
     }
     __syncthreads();
-    bneck_layer(b.Wd0, b.Nd0, D, HY, true, b.pre_d0, b.d0, HA, item, in_range, wave, lane);
+    bneck_layer<BN_WAVES>(b.Wd0, b.Nd0, D, HY, true, b.pre_d0, b.d0, HA, item, in_range, wave, lane);
     __syncthreads();
-    bneck_layer(b.Wd1, b.Nd1, b.Nd0, HA, true, b.pre_d1, b.d1, nullptr, item, in_range, wave, lane);
+    bneck_layer<BN_WAVES>(b.Wd1, b.Nd1, b.Nd0, HA, true, b.pre_d1, b.d1, nullptr, item, in_range, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -998,12 +1001,12 @@ extern "C" int hidvae_bottleneck_fwd(const float *h1, int64_t B, int K2, int N2,
     BneckArgs b{};
     FwdArgs &a = b.rq;
     a.y = nullptr; a.B = B; a.normalize_input = normalize_input; a.cb_eff = cb_eff; a.cc = cc; a.L = L; a.K = K;
-    const int64_t Kp = hv_cdiv(K, 128) * 128;  // the four waves each scan a quarter, 32 codes at a time (padding: +inf)
+    const int64_t Kp = hv_cdiv(K, 32 * BN_WAVES) * (32 * BN_WAVES);  // every wave scans its share, 32 codes at a time (padding: +inf)
     a.KC = (int)Kp;
     a.nchunks = 1;
     a.beta = beta; a.z = z; a.ids = ids; a.emb_cat = emb_cat; a.ld_cat = ld_cat; a.emb_sum = emb_sum; a.res_cat = nullptr; a.qloss = qloss;
     const size_t lds = level_lds_bytes(a.KC) * (size_t)L + (size_t)(2 * (BN_HMAX / 16) * 64 + 2 * 64) * sizeof(float4);
-    HV_REQUIRE(a.KC % 128 == 0 && a.KC <= MAX_KC && lds <= 160 * 1024 - 1024,
+    HV_REQUIRE(a.KC % (32 * BN_WAVES) == 0 && a.KC <= MAX_KC && lds <= 160 * 1024 - 1024,
                "bottleneck_fwd: the codebooks (L=%d, K=%lld) do not fit in LDS beside the activations", L, (long long)K);
     b.h1 = h1; b.K2 = K2; b.N2 = N2; b.W2 = W2; b.W3 = W3; b.pre2 = pre2; b.h2 = h2; b.y_out = y;
     b.Nd0 = Nd0; b.Nd1 = Nd1; b.Wd0 = Wd0; b.Wd1 = Wd1; b.pre_d0 = pre_d0; b.d0 = d0; b.pre_d1 = pre_d1; b.d1 = d1;
@@ -1012,11 +1015,11 @@ extern "C" int hidvae_bottleneck_fwd(const float *h1, int64_t B, int K2, int N2,
     if (mode == HIDVAE_MODE_STE) {
         auto kern = bottleneck_fwd_kernel<HIDVAE_MODE_STE>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, b);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * BN_WAVES), lds, s, b);
     } else {
         auto kern = bottleneck_fwd_kernel<HIDVAE_MODE_ROTATION>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WG_THREADS), lds, s, b);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * BN_WAVES), lds, s, b);
     }
     HV_LAUNCH_CHECK("bottleneck_fwd");
     return HIDVAE_OK;
