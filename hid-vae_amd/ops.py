@@ -132,9 +132,11 @@ class MLPFrontFn(Function):
             out = _C.gemm(_C.GEMM_NT, h, w, epilogue=_C.EPI_SILU, aux=pre)
             saved.append((h, pre))
             h = out
+        pre_last = saved[-1][1]
+        saved[-1] = (saved[-1][0], None)  # (an output: this node's backward does not need it, and holding it would be a cycle)
         ctx.saved, ctx.weights, ctx.need_x = saved, weights, ctx.needs_input_grad[0]
         ctx.mark_non_differentiable(h)
-        return saved[-1][1], h
+        return pre_last, h
 
     @staticmethod
     def backward(ctx, g_pre, _g_h):
@@ -182,7 +184,7 @@ class BottleneckFn(Function):
         ctx.cfg = (normalize_input, mode, beta, tuple(normalize_flags))
         ctx.params = (W2, W3, Wd0, Wd1)
         ctx.tables = tables
-        ctx.stash = (pre1, h1, o["pre2"], o["h2"], o["y"], o["z"], o["ids"], o["emb_sum"], o["pre_d0"], o["d0"], cb, cc)
+        ctx.save_for_backward(pre1, h1, o["pre2"], o["h2"], o["y"], o["z"], o["ids"], o["emb_sum"], o["pre_d0"], o["d0"], cb, cc)
         ctx.mark_non_differentiable(o["ids"], o["emb_sum"], o["d1"])
         return o["z"], o["ids"], o["emb_cat"], o["emb_sum"], o["qloss"], o["pre_d1"], o["d1"]
 
@@ -190,7 +192,7 @@ class BottleneckFn(Function):
     def backward(ctx, g_z, _g_ids, g_cat, _g_sum, g_q, g_pre_d1, _g_d1):
         normalize_input, mode, beta, flags = ctx.cfg
         W2, W3, Wd0, Wd1 = ctx.params
-        pre1, h1, pre2, h2, y, z, ids, emb_sum, pre_d0, d0, cb, cc = ctx.stash
+        pre1, h1, pre2, h2, y, z, ids, emb_sum, pre_d0, d0, cb, cc = ctx.saved_tensors
         g_sum = None
         gWd0 = gWd1 = None
         if g_pre_d1 is not None:
@@ -221,7 +223,6 @@ class BottleneckFn(Function):
         gW2, g_pre1 = _C.linear_bwd(g_pre2, h1, W2, ctx.needs_input_grad[0], _C.EPI_DSILU, pre1, dW=dst, accumulate=acc)
         if dst is not None:
             gW2 = None
-        ctx.stash = None
         return (g_pre1, None, gW2, gW3, gWd0, gWd1, None, None, None, None, None) + tuple(gE)
 
 
@@ -261,7 +262,11 @@ class RQFn(Function):
         z, ids, emb_cat, emb_sum, res, qloss = _C.rq_forward(y, cb, cc, normalize_input, mode, training, beta, want_res=want_res)
         ctx.cfg = (normalize_input, mode, training, beta, tuple(normalize_flags))
         ctx.tables = tables
-        ctx.stash = (y, z, ids, cb, cc)
+        # (save_for_backward, not attributes: z and ids are OUTPUTS of this node, and an output held by its own ctx is a reference
+        #  cycle -- a forward that is never followed by a backward, e.g. the k-means warm-up pass, would then keep its whole autograd
+        #  graph, AccumulateGrad nodes included, alive until the garbage collector runs; those stale nodes sit on the stream of that
+        #  forward and break a later HIP-graph capture)
+        ctx.save_for_backward(y, z, ids, cb, cc)
         ctx.mark_non_differentiable(ids)
         if res is None:
             res = torch.empty(0, device=y.device)
@@ -273,7 +278,7 @@ class RQFn(Function):
         normalize_input, mode, training, beta, flags = ctx.cfg
         if not training:
             raise RuntimeError("the eval branch of Quantize (o = codebook[ids]) is not differentiated on the fused path")
-        y, z, ids, cb, cc = ctx.stash
+        y, z, ids, cb, cc = ctx.saved_tensors
         if g_cat is not None:
             g_cat = g_cat.contiguous()
         if g_sum is not None:
@@ -299,7 +304,6 @@ class RQFn(Function):
             if t is not None:
                 t.record_stream(main)
         _join_after_backward()
-        ctx.stash = None
         return (g_y, None, None, None, None, None, None, None) + tuple(gE)
 
 

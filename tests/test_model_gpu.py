@@ -298,3 +298,27 @@ def test_plain_rqvae_matches_reference_goldens(name):
     assert H.rel_err(q.embeddings.cpu().numpy(), fx["embeddings"]) <= TOL
     assert H.rel_err(q.residuals.cpu().numpy(), fx["residuals"]) <= TOL
     assert H.rel_err(q.quantize_loss.cpu().numpy(), fx["quantize_loss"]) <= TOL
+
+
+def test_forward_without_backward_leaves_no_autograd_graph_behind():
+    """A training-mode forward whose result is dropped (k-means warm-up, evaluation with grad enabled) must free its autograd
+    graph by reference counting alone: no node may hold one of its own outputs (a cycle only the garbage collector breaks)."""
+    import gc
+    import weakref
+    fx, desc = H.load("rot_train_tag_b128")
+    cfg, P, x, te, ti = H.inputs_of(desc)
+    from hidvae_amd.rand import InjectedRand
+    gc.collect()
+    gc.disable()
+    try:
+        for fuse in (True, False):
+            m = build_model(cfg, P).train()
+            m.fuse_bottleneck = fuse
+            m.rand = InjectedRand(O.FormulaRand(**desc["rand"]))
+            out = m(make_batch(x, te, ti), gumbel_t=0.2)
+            node = weakref.ref(out.loss.grad_fn)
+            assert node() is not None
+            del out
+            assert node() is None, f"the forward's autograd graph survived its outputs (fused middle launch: {fuse})"
+    finally:
+        gc.enable()

@@ -63,14 +63,18 @@ def test_three_iterations_match_the_reference_run(name, flat):
         assert int(sd[f"tag_projectors.{i}.1.num_batches_tracked"]) == desc["iters"] * desc["ga"]
 
 
-def test_train_driver_end_to_end(tmp_path):
-    """train(): synthetic resident items, k-means warm-up, focal + rare-tag remap, eval with TTA and id diversity, series dump."""
+@pytest.mark.parametrize("ga", [2, 1])
+def test_train_driver_end_to_end(tmp_path, ga):
+    """train(): synthetic resident items, k-means warm-up, focal + rare-tag remap, eval with TTA and id diversity, series dump.
+    (ga = 1 is a regression case: the k-means warm-up is a forward without a backward; autograd nodes that held their own outputs
+    kept that pass's graph -- and its AccumulateGrad nodes on the default stream -- alive, which broke the HIP-graph capture of
+    the step a few iterations later.)"""
     import hidvae_amd  # noqa: F401
     from hidvae_amd.modules.quantize import QuantizeForwardMode
     from hidvae_amd.train_hidvae import train
     model, series = train(
         iterations=30, batch_size=128, learning_rate=2.8e-4, weight_decay=0.015, dataset="synthetic:3000", save_dir_root=str(tmp_path) + "/",
-        use_kmeans_init=True, do_eval=True, gradient_accumulate_every=2, eval_every=30, commitment_weight=0.4, tag_alignment_weight=0.15,
+        use_kmeans_init=True, do_eval=True, gradient_accumulate_every=ga, eval_every=30, commitment_weight=0.4, tag_alignment_weight=0.15,
         tag_prediction_weight=0.55, vae_n_cat_feats=0, vae_input_dim=768, vae_embed_dim=32, vae_hidden_dims=[512, 256, 128],
         vae_codebook_size=256, vae_codebook_normalize=True, vae_codebook_mode=QuantizeForwardMode.ROTATION_TRICK, vae_n_layers=3,
         tag_class_counts=[38, 168, 348], use_focal_loss=True, focal_loss_gamma_base=2.7, focal_loss_alpha_base=0.24, rare_tag_threshold=5,
