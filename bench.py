@@ -139,6 +139,15 @@ def kernel_rooflines(args, m, device):
     out.append(dict(kernel="gemm_direct_kernel<TN,8,3> dW encoder layer 0: [512,B]x[B,768] (in-workgroup split-K)", bound="mfma",
                     achieved=fl / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
                     us=t, flops=fl))
+    # the same layer in the throughput regime (LDS-tiled kernel; corpus tokenisation and large-batch training run here)
+    bigm = 1 << 16
+    xb, ob, ab = torch.randn(bigm, 768, device=device), torch.empty(bigm, 512, device=device), torch.empty(bigm, 512, device=device)
+    t = time_kernel(lambda: _C.gemm(_C.GEMM_NT, xb, w0, out=ob, epilogue=_C.EPI_SILU, aux=ab), launches=4, reps=5)
+    flb = 2.0 * bigm * 768 * 512
+    out.append(dict(kernel="gemm_f32_kernel<2,2,NT> encoder layer 0 at 65,536 rows (LDS-tiled, throughput regime)", bound="mfma",
+                    achieved=flb / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=flb / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
+                    us=t, flops=flb))
+    del xb, ob, ab
     y = torch.randn(B, 32, device=device)
     tables = [layer.embedding.weight.detach() for layer in m.layers]
     cb, cc = _C.codebook_prepare(tables, [i == 0 for i in range(L)])
