@@ -153,7 +153,7 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     ws = None
-    if split_k > 1 and ((M + 31) // 32) * ((N + 31) // 32) >= 4096:  # only the LDS-tiled (large-batch) path uses slabs
+    if split_k > 1 and ((M + 31) // 32) * ((N + 31) // 32) >= 2048:  # only the LDS-tiled (large-batch) path uses slabs
         ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32)
     ldaux = _row_stride(aux, "aux") if aux is not None else 0
     ldmask = _row_stride(mask, "mask") if mask is not None else 0

@@ -855,7 +855,9 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles32 = hv_cdiv(M, 32) * hv_cdiv(N, 32);
     const bool fits32 = fits32bit(layout, M, N, K, lda, ldb);
-    const bool big = (tiles32 >= 4096 && K >= 64) || !fits32;  // enough tiles that LDS sharing beats per-wave operand loads
+    // enough tiles that LDS sharing beats per-wave operand loads (measured crossover: 2048 tiles -- at 4096 rows the encoder's
+    // first layer takes 46 us tiled vs 52 us direct, at 2048 rows 33 vs 30)
+    const bool big = (tiles32 >= 2048 && K >= 64) || !fits32;
     if (!big || split_k == 1) {
         if (!big) {
             // direct path.  split_k == 1: one wave per tile, sequential (ORDER-G) chain; otherwise spread K over up to 16
@@ -917,7 +919,7 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
                "linear_bwd: dX epilogue %d", dx_epilogue);
     // dW [n_out, n_in] = g^T x : TN with M = n_out, N = n_in, K = B;   dX [B, n_in] = g W : NN with M = B, N = n_in, K = n_out
     const bool small = dX != nullptr && fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw) &&
-                       hv_cdiv(n_out, 32) * hv_cdiv(n_in, 32) < 4096 && hv_cdiv(B, 32) * hv_cdiv(n_in, 32) < 4096;
+                       hv_cdiv(n_out, 32) * hv_cdiv(n_in, 32) < 2048 && hv_cdiv(B, 32) * hv_cdiv(n_in, 32) < 2048;
     const bool pair16 = small && use_direct16(n_out, n_in, B) && use_direct16(B, n_in, n_out);
     const int s32_0 = pick_split32(n_out, n_in, B, 0), s32_1 = pick_split32(B, n_in, n_out, 0);
     const bool pair32 = small && !use_direct16(n_out, n_in, B) && !use_direct16(B, n_in, n_out) && s32_0 <= 8 && s32_1 <= 8;
