@@ -783,8 +783,8 @@ __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a)
     // (B) walk the list and add the rows (lanes 0..31 hold d).  Ascending item order => bit-reproducible sums.
     // Every wave needs the ids of ALL items of its level; read straight from global memory that is L*K waves x B strided 8-byte
     // loads (150 MB of L2 traffic at B = 8192, 69 us); staged, a workgroup reads each chunk once for its four waves.
-    __shared__ int hits[4][1024];
-    __shared__ int chunk[STAGED ? 1024 : 1];
+    __shared__ int hits[4][2048];
+    __shared__ int chunk[STAGED ? 4096 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     const bool live = row < (int64_t)a.L * a.K;
@@ -799,44 +799,56 @@ __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a)
     const bool nrm = a.normalize[lvl] != 0;
     const float ev = nrm ? a.E[lvl][k * D + d] : 0.0f;
     const float cv = nrm ? a.cb_eff[rowc * D + d] : 0.0f;
-    for (int64_t c0 = 0; c0 < a.B; c0 += 1024) {
-        int n = 0;
-        int64_t idv[16];
-        if (STAGED) {
-            __syncthreads();  // the previous chunk has been consumed by every wave
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int64_t b = c0 + j * 256 + threadIdx.x;
-                chunk[j * 256 + threadIdx.x] = b < a.B ? (int)a.ids[b * a.L + lvl] : -1;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 16; j++) idv[j] = chunk[j * 64 + lane];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {  // 16 independent loads in flight
-                const int64_t b = c0 + j * 64 + lane;
-                idv[j] = b < a.B ? a.ids[b * a.L + lvl] : -1;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const bool hit = idv[j] == k;
-            const unsigned long long m = __ballot(hit);
-            if (hit) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (int)(j * 64 + lane);
-            n += __popcll(m);
-        }
+    int n = 0;
+    // (B) the list so far, rows fetched eight at a time and added in ascending item order.  It runs when the list could overflow
+    // on the next chunk and at the end: normally ONCE, so the scan of all chunks is not interleaved with dependent row loads.
+    auto drain = [&]() {
         __builtin_amdgcn_wave_barrier();
-        for (int e0 = 0; e0 < n; e0 += 8) {  // rows fetched eight at a time, added in ascending item order
+        for (int e0 = 0; e0 < n; e0 += 8) {
             float r[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) r[j] = e0 + j < n ? a.dE_rows[(c0 + list[e0 + j]) * ((int64_t)a.L * D) + lvl * D + d] : 0.0f;
+            for (int j = 0; j < 8; j++) r[j] = e0 + j < n ? a.dE_rows[(int64_t)list[e0 + j] * ((int64_t)a.L * D) + lvl * D + d] : 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 if (e0 + j < n) acc += r[j];
         }
         __builtin_amdgcn_wave_barrier();
+        n = 0;
+    };
+    constexpr int CH = STAGED ? 4096 : 1024;  // items per staging round (16 independent id loads per thread in flight)
+    for (int64_t c0 = 0; c0 < a.B; c0 += CH) {
+        if (STAGED) {
+            __syncthreads();  // the previous chunk has been consumed by every wave
+#pragma unroll
+            for (int j = 0; j < CH / 256; j++) {
+                const int64_t b = c0 + j * 256 + threadIdx.x;
+                chunk[j * 256 + threadIdx.x] = b < a.B ? (int)a.ids[b * a.L + lvl] : -1;
+            }
+            __syncthreads();
+        }
+        for (int s0 = 0; s0 < CH && c0 + s0 < a.B; s0 += 1024) {
+            if (n > 1024) drain();  // (wave-uniform)
+            int64_t idv[16];
+            if (STAGED) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) idv[j] = chunk[s0 + j * 64 + lane];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {  // 16 independent loads in flight
+                    const int64_t b = c0 + j * 64 + lane;
+                    idv[j] = b < a.B ? a.ids[b * a.L + lvl] : -1;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const bool hit = idv[j] == k;
+                const unsigned long long m = __ballot(hit);
+                if (hit) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (int)(c0 + s0 + j * 64 + lane);
+                n += __popcll(m);
+            }
+        }
     }
+    drain();
     if (!live) return;
     if (nrm) {  // c = E / max(|E|, eps)  =>  gE = (g - c (c.g)) / max(|E|, eps)
         float n2 = ev * ev, cg = cv * acc;
