@@ -780,7 +780,8 @@ template <bool STAGED>  // STAGED (K % 4 == 0: the workgroup's four codes share 
 __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a) {
     // Two phases per 1024-item chunk so that no load depends on another: (A) scan the ids of the chunk (independent,
     // coalesced loads) and append the matching item numbers, in ascending order, to a per-wave LDS list;
-    // (B) walk the list and add the rows (lanes 0..31 hold d).  Ascending item order => bit-reproducible sums.
+    // (B) walk the list and add the rows (lane & 31 = d; lanes 0..31 add the even entries, lanes 32..63 the odd ones, each in
+    // ascending item order, and the two chains are added at the end) => a fixed summation order, bit-reproducible sums.
     // Every wave needs the ids of ALL items of its level; read straight from global memory that is L*K waves x B strided 8-byte
     // loads (150 MB of L2 traffic at B = 8192, 69 us); staged, a workgroup reads each chunk once for its four waves.
     __shared__ int hits[4][2048];
@@ -802,15 +803,19 @@ __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a)
     int n = 0;
     // (B) the list so far, rows fetched eight at a time and added in ascending item order.  It runs when the list could overflow
     // on the next chunk and at the end: normally ONCE, so the scan of all chunks is not interleaved with dependent row loads.
+    const int half = lane >> 5;  // the two half-waves take the even / the odd entries of the list: two fixed-order chains
     auto drain = [&]() {
         __builtin_amdgcn_wave_barrier();
-        for (int e0 = 0; e0 < n; e0 += 8) {
+        for (int e0 = 0; e0 < n; e0 += 16) {
             float r[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) r[j] = e0 + j < n ? a.dE_rows[(int64_t)list[e0 + j] * ((int64_t)a.L * D) + lvl * D + d] : 0.0f;
+            for (int j = 0; j < 8; j++) {
+                const int e = e0 + 2 * j + half;
+                r[j] = e < n ? a.dE_rows[(int64_t)list[e] * ((int64_t)a.L * D) + lvl * D + d] : 0.0f;
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if (e0 + j < n) acc += r[j];
+                if (e0 + 2 * j + half < n) acc += r[j];
         }
         __builtin_amdgcn_wave_barrier();
         n = 0;
@@ -849,6 +854,7 @@ __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a)
         }
     }
     drain();
+    acc = acc + __shfl_xor(acc, 32);  // even-entry chain + odd-entry chain (the same value on both halves)
     if (!live) return;
     if (nrm) {  // c = E / max(|E|, eps)  =>  gE = (g - c (c.g)) / max(|E|, eps)
         float n2 = ev * ev, cg = cv * acc;
