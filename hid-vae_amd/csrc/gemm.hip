@@ -54,6 +54,27 @@ __device__ __forceinline__ float apply_epilogue(int epi, float v, const float *a
     }
 }
 
+// XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), and every XCD has its own
+// L2: with the identity mapping each XCD touches every row block and every column block, so each L2 pulls its own copy of both
+// operands (PMC, round 1: 26.6 MB fetched for 4.7 MB of operands on the encoder's first layer).  Remapping dispatch slot i to
+// tile (i % 8) * (T/8) + i / 8 gives XCD j the j-th contiguous eighth of the row-major tile list, i.e. a band of rows: its L2
+// then holds one eighth of A and all of B.  A bijection when T % 8 == 0, otherwise the identity is kept.
+// The band runs along the LONGER output dimension (rows if M >= N, else columns), so the operand that is split eight ways is
+// the larger one and the replicated one the smaller.
+__device__ __forceinline__ void xcd_tile(int nbx, int nby, bool row_bands, int &bx, int &by) {
+    const int total = nbx * nby;
+    if ((total & 7) != 0) return;
+    const int id = by * nbx + bx;
+    const int t = (id & 7) * (total >> 3) + (id >> 3);
+    if (row_bands) {
+        by = t / nbx;
+        bx = t - by * nbx;
+    } else {
+        bx = t / nby;
+        by = t - bx * nby;
+    }
+}
+
 // Load a [ROWS x BK] operand tile (ROWS = 32*W along m or n) into registers.  KCONTIG: element (row, k) is at
 // P[row*ld + k]; otherwise at P[k*ld + row].  Out-of-range elements read as 0.
 template <int ROWS, int NT, bool KCONTIG>
@@ -168,7 +189,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    // (PMC at 65,536 x 768 x 512 before this mapping: 1.6 GB fetched for 203 MB of operands -- the 8 column tiles that share a
+    //  row block are neighbours in dispatch order, i.e. on 8 different XCDs, and every one pulled the block from HBM itself)
+    int bx = blockIdx.x, by = blockIdx.y;
+    xcd_tile(gridDim.x, gridDim.y, g.M >= g.N, bx, by);
+    const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
     const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
     const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
 
@@ -342,27 +367,6 @@ __device__ __forceinline__ void load_tail(__amdgpu_buffer_rsrc_t rsrc, int ld4, 
         const bool ok = k0 + kk + 4 * h < kend;
         if (KCONTIG) v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? voff + 4 * kk : HV_OOB, k0 * 4, 0));
         else v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? voff : HV_OOB, (k0 + kk) * ld4, 0));
-    }
-}
-
-// XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), and every XCD has its own
-// L2: with the identity mapping each XCD touches every row block and every column block, so each L2 pulls its own copy of both
-// operands (PMC, round 1: 26.6 MB fetched for 4.7 MB of operands on the encoder's first layer).  Remapping dispatch slot i to
-// tile (i % 8) * (T/8) + i / 8 gives XCD j the j-th contiguous eighth of the row-major tile list, i.e. a band of rows: its L2
-// then holds one eighth of A and all of B.  A bijection when T % 8 == 0, otherwise the identity is kept.
-// The band runs along the LONGER output dimension (rows if M >= N, else columns), so the operand that is split eight ways is
-// the larger one and the replicated one the smaller.
-__device__ __forceinline__ void xcd_tile(int nbx, int nby, bool row_bands, int &bx, int &by) {
-    const int total = nbx * nby;
-    if ((total & 7) != 0) return;
-    const int id = by * nbx + bx;
-    const int t = (id & 7) * (total >> 3) + (id >> 3);
-    if (row_bands) {
-        by = t / nbx;
-        bx = t - by * nbx;
-    } else {
-        bx = t / nby;
-        by = t - bx * nby;
     }
 }
 

@@ -33,7 +33,10 @@ for _ in range(10):
     _C.gemm(_C.GEMM_TN, g, x, out=gw, split_k=0)
     _C.linear_bwd(g1, o0, w1, True, _C.EPI_DSILU, pre)  # the paired dW + dX launch of encoder layer 1
     _C.rq_forward(y_small, cb, cc, True, 3, True, 0.4)
+xb = torch.randn(1 << 16, 768, device=dev)
+ob, ab = torch.empty(1 << 16, 512, device=dev), torch.empty(1 << 16, 512, device=dev)
 for _ in range(5):
     _C.rq_forward(y_big, cb, cc, True, 3, True, 0.4)
+    _C.gemm(_C.GEMM_NT, xb, w0, out=ob, epilogue=_C.EPI_SILU, aux=ab)  # the LDS-tiled kernel (throughput regime)
 torch.cuda.synchronize()
 print("done")
