@@ -155,6 +155,8 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
     ws = None
     if split_k > 1 and ((M + 31) // 32) * ((N + 31) // 32) >= 2048:  # only the LDS-tiled (large-batch) path uses slabs
         ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32)
+    elif split_k == 0 and K >= 4096:  # deep-K problems (weight gradients at large batch) may be cut into up to 16 slabs
+        ws = torch.empty((16 * M * N,), device=A.device, dtype=torch.float32)
     ldaux = _row_stride(aux, "aux") if aux is not None else 0
     ldmask = _row_stride(mask, "mask") if mask is not None else 0
     _check(lib().hidvae_gemm_f32(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(out), _row_stride(out, "C"),
@@ -176,12 +178,15 @@ def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accu
     elif tuple(dW.shape) != (n_out, n_in) or not dW.is_contiguous():
         raise RuntimeError(f"linear_bwd: dW slot has shape {tuple(dW.shape)}, expected {(n_out, n_in)} contiguous")
     dX = torch.empty((B, n_in), device=g.device, dtype=torch.float32) if need_dx else None
-    ws = None
+    ws_floats = 0
     if bias:
         if db is None:
             db = torch.empty((n_out,), device=g.device, dtype=torch.float32)
             accumulate_db = False
-        ws = torch.empty(((B + 63) // 64 * n_out,), device=g.device, dtype=torch.float32)
+        ws_floats = (B + 63) // 64 * n_out
+    if B >= 4096:  # the unpaired dW product may be cut into up to 16 K-slabs
+        ws_floats = max(ws_floats, 16 * n_out * n_in)
+    ws = torch.empty((ws_floats,), device=g.device, dtype=torch.float32) if ws_floats else None
     _check(lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
                                    _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, int(bool(accumulate)), _p(dX), n_in,
                                    int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, _p(db if bias else None),

@@ -861,7 +861,15 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
     const bool fits32 = fits32bit(layout, M, N, K, lda, ldb);
     // enough tiles that LDS sharing beats per-wave operand loads (measured crossover: 2048 tiles -- at 4096 rows the encoder's
     // first layer takes 46 us tiled vs 52 us direct, at 2048 rows 33 vs 30)
-    const bool big = (tiles32 >= 2048 && K >= 64) || !fits32;
+    // deep-K problems with few output tiles (weight gradients at large batch: K = batch): the LDS-tiled kernel with the K range
+    // cut into grid-level slabs, summed in slab order by splitk_reduce_kernel.  Needs the workspace (slabs * M * N floats).
+    int deep_splits = 0;
+    if (split_k == 0 && workspace != nullptr && K >= 4096 && tiles32 < 2048 && M > 32 && N > 32) {
+        deep_splits = (int)(K / 512 < 16 ? K / 512 : 16);
+        const int64_t wgs = hv_cdiv(M, 64) * hv_cdiv(N, 64);
+        while (deep_splits > 2 && wgs * deep_splits > 2048) deep_splits /= 2;
+    }
+    const bool big = (tiles32 >= 2048 && K >= 64) || !fits32 || deep_splits > 1;
     if (!big || split_k == 1) {
         if (!big) {
             // direct path.  split_k == 1: one wave per tile, sequential (ORDER-G) chain; otherwise spread K over up to 16
@@ -894,7 +902,7 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
         }
     }
     // LDS-tiled path (large batches); grid-level split-K through the workspace when asked for and available
-    int splits = (split_k > 1 && workspace != nullptr) ? split_k : 1;
+    int splits = (split_k > 1 && workspace != nullptr) ? split_k : (deep_splits > 1 ? deep_splits : 1);
     int64_t kps = hv_cdiv(hv_cdiv(K, splits), BK) * BK;
     splits = (int)hv_cdiv(K, kps);
     g.k_per_split = kps;
@@ -930,9 +938,12 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
     const bool pair = pair16 || pair32;
     HV_REQUIRE(db == nullptr || pair || workspace != nullptr || B <= 16384, "linear_bwd: the unpaired bias gradient needs the colsum workspace");
     if (!pair) {
-        int rc = hidvae_gemm_f32(HIDVAE_GEMM_TN, n_out, n_in, B, g, ldg, x, ldx, nullptr, dW, lddw, HIDVAE_EPI_NONE, nullptr, 0, nullptr, 0,
-                                 1.0f, 0, nullptr, accumulate_dw, stream);
-        if (rc == HIDVAE_OK && db != nullptr) rc = hidvae_colsum(g, B, n_out, ldg, db, accumulate_db, workspace, stream);
+        // (the workspace serves the bias column sums first -- only for B > 16384 -- and then, in stream order, the slabs of dW)
+        int rc = HIDVAE_OK;
+        if (db != nullptr) rc = hidvae_colsum(g, B, n_out, ldg, db, accumulate_db, workspace, stream);
+        if (rc == HIDVAE_OK)
+            rc = hidvae_gemm_f32(HIDVAE_GEMM_TN, n_out, n_in, B, g, ldg, x, ldx, nullptr, dW, lddw, HIDVAE_EPI_NONE, nullptr, 0, nullptr, 0,
+                                 1.0f, 0, workspace, accumulate_dw, stream);
         if (rc != HIDVAE_OK || dX == nullptr) return rc;
         return hidvae_gemm_f32(HIDVAE_GEMM_NN, B, n_in, n_out, g, ldg, W, ldw, nullptr, dX, lddx, dx_epilogue, aux, ldaux, nullptr, 0, 1.0f, 0,
                                nullptr, 0, stream);

@@ -81,7 +81,8 @@ int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K,
  * the results are bit-identical to the two separate calls.  Shapes outside the small-problem regime fall back to them.
  * accumulate_dw: dW += g^T x (gradient accumulation straight into a flat gradient buffer's slot).
  * db (optional): the bias gradient db[n_out] = column sums of g, from the same launch (fixed summation order; the fallback
- * uses hidvae_colsum and needs its workspace of ceil(B/64)*n_out floats). */
+ * uses hidvae_colsum and needs its workspace of ceil(B/64)*n_out floats when B > 16384).  workspace (optional) is also what lets the
+ * unpaired dW product of a LARGE batch (B >= 4096) run as K-slabs on the LDS-tiled kernel: give it max(that, 16*n_out*n_in) floats. */
 int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
                       int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
                       int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
