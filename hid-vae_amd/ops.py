@@ -10,11 +10,6 @@ from torch.autograd import Function
 from . import _C
 
 
-def _weight_grad_split(m_out, n_in, k_batch):
-    """split-K policy for the backward GEMMs: 0 = let the library spread K over the waves of a workgroup."""
-    return 0
-
-
 _SIDE = {}
 
 
