@@ -1,7 +1,6 @@
 """Autograd operators of the tokenizer step: each forward/backward is one or a few C-ABI launches (_C.py).
 
 No torch arithmetic runs on the hot path: torch supplies device memory, streams and the autograd tape only."""
-import math
 import os
 
 import torch

@@ -15,7 +15,7 @@ from torch import nn
 from torch.autograd import Function
 
 from . import _C
-from .ops import L2NormFn, LinearFn, _join_after_backward, side_stream
+from .ops import L2NormFn, LinearFn
 
 
 def _keep_scale(p):

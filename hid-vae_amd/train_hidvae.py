@@ -14,7 +14,6 @@ replaced by torch.distributed + one flat-gradient all-reduce; the matplotlib plo
 of the same series."""
 import json
 import logging
-import math
 import os
 import sys
 from collections import deque
