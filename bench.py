@@ -162,7 +162,7 @@ def kernel_rooflines(args, m, device):
     yb = torch.randn(big, 32, device=device)
     t = time_kernel(lambda: _C.rq_forward(yb, cb, cc, True, 3, True, 0.4), launches=2, reps=5)
     algb = (128 + 8 * L + 128 * L + 4) * big + 4 * L * K * 32
-    out.append(dict(kernel="rq_forward at 1,048,576 items (corpus-sized launch: rq_forward_prefilter_kernel, split-bf16 prefilter + exact confirmation)",
+    out.append(dict(kernel="rq_forward at 1,048,576 items (corpus-sized launch: rq_forward_pf32_kernel, split-bf16 prefilter on 32x32x16 MFMA + exact confirmation)",
                     bound="hbm", achieved=algb / t * 1e-3,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=algb / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t, algorithmic_bytes=algb,
                     bytes_moved=(128 + 8 * L + 128 * L + 128 + 128 + 4) * big + 4 * L * K * 32,

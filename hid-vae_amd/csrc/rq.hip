@@ -508,6 +508,377 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_prefilter_kernel(FwdArgs a
 }
 
 // ------------------------------------------------------------------------------------------------
+// Corpus-sized batches (B >= 131072): the same split-bf16 prefilter on v_mfma_f32_32x32x16_bf16, 32 items per wave.
+// The 16-item kernel above is bound by vector-instruction issue, not by the matrix pipe (rocprofv3 at 1M items: SQ_ACTIVE_INST_ANY
+// = 70 % of the SIMD issue slots, MFMA busy 16 %): per score it spends an fma, a compare, two selects and a med3, its MFMAs hold the
+// issue port for 8 cycles per 256 scores, and the per-level scalar work (square roots, divisions, cross-lane sums) is replicated on
+// the 4 lanes that share an item.  Here
+//   * lane = (n = lane & 31, h = lane >> 5) holds dims [16h, 16h+16) of item n: two lanes per item, one cross-lane step per reduction
+//     (p0+p1 | p2+p3 are in-lane, then one v_permlane32_swap: the same (p0+p1)+(p2+p3) as everywhere else, bit for bit);
+//   * the LDS images hold bf16 hi/lo of -2c and the accumulators start from |c|^2, so a score IS the accumulator (no fma);
+//   * the lane's running best carries its accumulator number j in the 4 low mantissa bits (one v_and_or per score, |error| < 2^-19 |s|,
+//     inside the slack of DELTA), the 32-code tile is tracked by one compare per 16 scores: per score and_or + med3 + min;
+//   * one 32x32x16 MFMA yields 1024 partial scores per 8 issue cycles (16x16x32: 256);
+//   * an undecided item does not send its wave through all K codes again: pf32_confirm re-scans the scores for the codes within DELTA
+//     of the best (usually two) and gives only those the exact fp32 distance (the full re-search cost 100 of 550 us on random data,
+//     where ~0.3 % of item-levels -- 9 % of 32-item waves -- are undecided; the confirmation costs 16 us).
+// 64-byte code rows are stored with their four 16-byte chunks XOR-swizzled by (code >> 2) & 3: ds_read_b128 fragment reads are
+// conflict-free without padding (SQ_LDS_BANK_CONFLICT 0; 33 KB per level at K = 256).  Everything after the argmin is the exact fp32
+// code in the new lane geometry.  12 waves per workgroup (three per SIMD, <= 170 VGPRs: at 16 waves / 128 VGPRs the 16-dims-per-lane
+// tail spills).  Measured at 1,048,576 items, 3x256, ROTATION: 394-440 us against 433-500 us for the 16-item kernel on the same box.
+// What the launch is NOT bound by (each measured): the winner-row gather (removing it changes nothing), in-order
+// vmcnt waits behind the stores (prefetching the next tile ahead of the stores changes nothing, scratch/store_stream.hip), LDS
+// bandwidth; its 668 B/item of stores cost ~110-180 us on top of the arithmetic instead of hiding under it, and neither quad-transposed
+// 64-byte stores nor whole-line stores staged through LDS moved that inside this kernel (the staging's extra registers cost more).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float PF_PAD_CC = 1.0e30f;  // |c|^2 of padding codes: finite (the packed index must not turn +inf into a NaN)
+
+__device__ __forceinline__ float swap32_sum(float p) {  // p(lane) + p(lane ^ 32), the same bits on both lanes
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ unsigned swap32_other(unsigned v, int h) {  // v of lane ^ 32
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return h ? r[0] : r[1];
+}
+__device__ __forceinline__ float dotH(const float (&a)[16], const float (&b)[16]) {
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) p0 = fmaf(a[j], b[j], p0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) p1 = fmaf(a[8 + j], b[8 + j], p1);
+    return swap32_sum(p0 + p1);
+}
+__device__ __forceinline__ void load16(const float *p, float (&v)[16]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float4 a = *reinterpret_cast<const float4 *>(p + 4 * k);
+        v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
+    }
+}
+__device__ __forceinline__ void store16(float *p, const float (&v)[16]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) *reinterpret_cast<float4 *>(p + 4 * k) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+
+template <int MODE, bool TRAIN>
+__device__ __forceinline__ void level_output16(const float (&r)[16], const float (&e)[16], float xx, float cce, float (&o)[16]) {
+    if (!TRAIN) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[j] = e[j];
+    } else if (MODE == HIDVAE_MODE_STE) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[j] = r[j] + (e[j] - r[j]);
+    } else {  // (the arithmetic of level_output, 16 dims per lane)
+        const float inr = 1.0f / (sqrtf(xx) + 1e-8f);
+        const float ine = 1.0f / (sqrtf(cce) + 1e-8f);
+        float u[16], qv[16], s[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            u[j] = r[j] * inr;
+            qv[j] = e[j] * ine;
+            s[j] = u[j] + qv[j];
+        }
+        const float inw = 1.0f / fmaxf(sqrtf(dotH(s, s)), 1e-6f);
+        float w[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) w[j] = s[j] * inw;
+        const float rw = dotH(r, w), ru = dotH(r, u);
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[j] = (r[j] - 2.0f * (rw * w[j])) + 2.0f * (ru * qv[j]);
+    }
+}
+
+__host__ __device__ __forceinline__ size_t pf32_level_bytes(int KC) { return (size_t)KC * (64 + 64 + 4); }
+
+// stage level `lvl`: bf16 hi / lo images of -2c (64-byte rows, chunks swizzled), |c|^2 (padding: PF_PAD_CC), max |c|^2
+__device__ __forceinline__ void pf32_stage(char *base, const FwdArgs &a, int lvl, unsigned *ccmax_bits) {
+    char *Ch = base;
+    char *Cl = base + (size_t)a.KC * 64;
+    float *ccs = reinterpret_cast<float *>(base + (size_t)a.KC * 128);
+    const float *src = a.cb_eff + (int64_t)lvl * a.K * D;
+    for (int idx = threadIdx.x; idx < a.KC * 8; idx += blockDim.x) {
+        const int kl = idx >> 3, d4 = idx & 7;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kl < a.K) v = *reinterpret_cast<const float4 *>(src + (int64_t)kl * D + 4 * d4);
+        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+        split_bf16(-2.0f * v.x, h0, l0); split_bf16(-2.0f * v.y, h1, l1); split_bf16(-2.0f * v.z, h2, l2); split_bf16(-2.0f * v.w, h3, l3);
+        const int off = kl * 64 + ((((d4 >> 1) ^ (kl >> 2)) & 3) << 4) + ((d4 & 1) << 3);
+        *reinterpret_cast<uint2 *>(Ch + off) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+        *reinterpret_cast<uint2 *>(Cl + off) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+    }
+    float mx = 0.0f;
+    for (int kl = threadIdx.x; kl < a.KC; kl += blockDim.x) {
+        const float c = kl < a.K ? a.cc[(int64_t)lvl * a.K + kl] : PF_PAD_CC;
+        ccs[kl] = c;
+        if (kl < a.K) mx = fmaxf(mx, c);
+    }
+    atomicMax(ccmax_bits, __float_as_uint(mx));
+}
+
+// exact argmin for the wave's 32 items (rare path): two passes of the 16-item fp32 chain of rq_level_loop, codes from global memory
+__device__ __forceinline__ int pf32_exact_search(const FwdArgs &a, int lvl, const float (&r)[16], float xx, int lane) {
+    const int it = lane & 15, q = lane >> 4, n = lane & 31;
+    const float *cbl = a.cb_eff + (int64_t)lvl * a.K * D;
+    const float *ccl = a.cc + (int64_t)lvl * a.K;
+    int res[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int srcl = it + 16 * pass + 32 * (q >> 1);  // the lane that holds dims [8q, 8q+8) of item it + 16 pass
+        float rq[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float lo = __shfl(r[j], srcl), hi = __shfl(r[8 + j], srcl);
+            rq[j] = (q & 1) ? hi : lo;
+        }
+        const float xxq = __shfl(xx, srcl);
+        float best = INFINITY;
+        int bidx = 0;
+        for (int t = 0; t < a.KC; t += 16) {
+            float av[8];
+            if (t + it < a.K) load8(cbl + (int64_t)(t + it) * D + 8 * q, av);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) av[j] = 0.0f;
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], rq[j], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int k = t + 4 * q + g;
+                const float cck = k < a.K ? ccl[k] : INFINITY;
+                const float d0 = fmaf(-2.0f, acc[g], xxq + cck);
+                if (d0 < best) { best = d0; bidx = k; }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        }
+        res[pass] = bidx;
+    }
+    const int v0 = __shfl(res[0], n & 15), v1 = __shfl(res[1], n & 15);
+    return (n >> 4) ? v1 : v0;
+}
+
+// Too close to call (rare): by the argument above the exact argmin is one of the codes whose approximate score lies within DELTA of
+// the best one -- usually two codes.  Re-scan the level's scores, every lane keeping up to four such codes of its half of the
+// codebook, then give exactly those the exact fp32 distance (the ORDER-P fmaf chain of the 16x16x4 MFMA, here on the vector ALU,
+// codes from global memory) and keep the smallest, lowest code on ties.  A lane with more than four candidates (duplicated codes)
+// sends the wave to the full exact search.  thr = best + DELTA for the undecided items, -inf for the others (they keep idx1).
+template <int NT>
+__device__ __forceinline__ int pf32_confirm(const FwdArgs &a, int lvl, const char *Ch, const char *Cl, const float *ccs, int off_p0,
+                                            int off_p1, int h, int lane, const float (&r)[16], float xx, float thr, int idx1) {
+    unsigned hw[16], lw[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) split_bf16(r[j], hw[j], lw[j]);
+    bf16x8_t bh[2], bl[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        bh[p] = __builtin_bit_cast(bf16x8_t, make_uint4(hw[8 * p] | (hw[8 * p + 1] << 16), hw[8 * p + 2] | (hw[8 * p + 3] << 16),
+                                                        hw[8 * p + 4] | (hw[8 * p + 5] << 16), hw[8 * p + 6] | (hw[8 * p + 7] << 16)));
+        bl[p] = __builtin_bit_cast(bf16x8_t, make_uint4(lw[8 * p] | (lw[8 * p + 1] << 16), lw[8 * p + 2] | (lw[8 * p + 3] << 16),
+                                                        lw[8 * p + 4] | (lw[8 * p + 5] << 16), lw[8 * p + 6] | (lw[8 * p + 7] << 16)));
+    }
+    unsigned long long cands = 0ull;
+    int cnt = 0;
+    for (int t = 0; t < a.KC; t += 32) {
+        const int rowb = t * 64;
+        const bf16x8_t ah0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Ch + rowb + off_p0));
+        const bf16x8_t ah1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Ch + rowb + off_p1));
+        const bf16x8_t al0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Cl + rowb + off_p0));
+        const bf16x8_t al1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Cl + rowb + off_p1));
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(ccs + t + 8 * g + 4 * h);
+            acc[4 * g] = c4.x; acc[4 * g + 1] = c4.y; acc[4 * g + 2] = c4.z; acc[4 * g + 3] = c4.w;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[0], acc, 0, 0, 0);  // (the very MFMAs of pf32_tile: the same scores)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float s = __uint_as_float((__float_as_uint(acc[j]) & 0xfffffff0u) | (unsigned)j);
+            if (s <= thr) {
+                cands = (cands << 16) | (unsigned long long)(unsigned)(t + (j & 3) + 8 * (j >> 2) + 4 * h);
+                cnt++;
+            }
+        }
+    }
+    if (__ballot(cnt > 4) != 0ull) return pf32_exact_search(a, lvl, r, xx, lane);
+    float xlo[16], xhi[16];  // the whole residual on both lanes of the item
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float other = __uint_as_float(swap32_other(__float_as_uint(r[j]), h));
+        xlo[j] = h ? other : r[j];
+        xhi[j] = h ? r[j] : other;
+    }
+    float dbest = INFINITY;
+    int kbest = 0x7fffffff;
+    for (int c = 0; __ballot(c < cnt) != 0ull; c++) {
+        if (c < cnt) {
+            const int k = (int)((cands >> (16 * c)) & 0xffffull);
+            const float *row = a.cb_eff + ((int64_t)lvl * a.K + k) * D;
+            float clo[16], chi[16];
+            load16(row, clo);
+            load16(row + 16, chi);
+            float dot = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {  // d = j, 8 + j, 16 + j, 24 + j: the order in which the MFMA chain meets them
+                dot = fmaf(clo[j], xlo[j], dot);
+                dot = fmaf(clo[8 + j], xlo[8 + j], dot);
+                dot = fmaf(chi[j], xhi[j], dot);
+                dot = fmaf(chi[8 + j], xhi[8 + j], dot);
+            }
+            const float d = fmaf(-2.0f, dot, xx + a.cc[(int64_t)lvl * a.K + k]);
+            if (d < dbest || (d == dbest && k < kbest)) { dbest = d; kbest = k; }
+        }
+    }
+    const float od = __uint_as_float(swap32_other(__float_as_uint(dbest), h));
+    const int ok = (int)swap32_other((unsigned)kbest, h);
+    if (od < dbest || (od == dbest && ok < kbest)) kbest = ok;
+    return thr == -INFINITY ? idx1 : kbest;
+}
+
+__device__ __forceinline__ float vmin_f32(float x, float y) {  // one v_min_f32 (fminf would canonicalise its operands first)
+    float m;
+    asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y));
+    return m;
+}
+
+// one 32-code tile against the wave's 32 items: scores in the accumulators, running (smallest, second smallest, tile of the smallest)
+__device__ __forceinline__ void pf32_tile(const char *Ch, const char *Cl, const float *ccs, int t, int off_p0, int off_p1, int h,
+                                          const bf16x8_t (&bh)[2], const bf16x8_t (&bl)[2], float &best1, float &best2, int &tbest) {
+    const int rowb = t * 64;
+    const bf16x8_t ah0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Ch + rowb + off_p0));
+    const bf16x8_t ah1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Ch + rowb + off_p1));
+    const bf16x8_t al0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Cl + rowb + off_p0));
+    const bf16x8_t al1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Cl + rowb + off_p1));
+    f32x16 acc;  // accumulator j <-> code t + (j & 3) + 8 (j >> 2) + 4 h: starts from |c|^2
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const float4 c4 = *reinterpret_cast<const float4 *>(ccs + t + 8 * g + 4 * h);
+        acc[4 * g] = c4.x; acc[4 * g + 1] = c4.y; acc[4 * g + 2] = c4.z; acc[4 * g + 3] = c4.w;
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[1], acc, 0, 0, 0);
+    const float before = best1;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float s = __uint_as_float((__float_as_uint(acc[j]) & 0xfffffff0u) | (unsigned)j);
+        best2 = __builtin_amdgcn_fmed3f(best1, best2, s);
+        best1 = vmin_f32(best1, s);
+    }
+    if (best1 < before) tbest = t;
+}
+
+template <int MODE, bool TRAIN, int NW, int NT>  // NT: 32-code tiles per level when known at compile time (full unroll), else 0
+__global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char pf_lds[];
+    __shared__ unsigned ccmax_bits[HIDVAE_MAX_LEVELS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const size_t lvl_bytes = pf32_level_bytes(a.KC);
+    if (threadIdx.x < HIDVAE_MAX_LEVELS) ccmax_bits[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int i = 0; i < a.L; i++) pf32_stage(pf_lds + i * lvl_bytes, a, i, &ccmax_bits[i]);
+    __syncthreads();
+    constexpr int TILE_ITEMS = 32 * NW;
+    const int sw = (n >> 2) & 3;
+    const int off_p0 = n * 64 + (((2 * h) ^ sw) << 4), off_p1 = n * 64 + (((2 * h + 1) ^ sw) << 4);  // this lane's A-fragment chunks
+    const int64_t ntiles = (a.B + TILE_ITEMS - 1) / TILE_ITEMS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t item = tile * TILE_ITEMS + wave * 32 + n;
+        const bool valid = item < a.B;
+        const int64_t src = valid ? item : a.B - 1;
+        float r[16];
+        load16(a.y + src * D + 16 * h, r);
+        if (a.normalize_input) {
+            const float den = fmaxf(sqrtf(dotH(r, r)), 1e-12f);
+#pragma unroll
+            for (int j = 0; j < 16; j++) r[j] = r[j] / den;
+        }
+        if (a.z != nullptr && valid) store16(a.z + item * D + 16 * h, r);
+        float loss = 0.0f;
+        float esum[16];
+        for (int i = 0; i < a.L; i++) {
+            if (a.res_cat != nullptr && valid) store16(a.res_cat + item * (a.L * D) + i * D + 16 * h, r);
+            const float xx = dotH(r, r);
+            const char *Ch = pf_lds + i * lvl_bytes;
+            const char *Cl = Ch + (size_t)a.KC * 64;
+            const float *ccs = reinterpret_cast<const float *>(Ch + (size_t)a.KC * 128);
+            // the residual as bf16 hi / lo B fragments: pass p contracts dims [16h + 8p, 16h + 8p + 8) = r[8p .. 8p+7]
+            unsigned hw[16], lw[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) split_bf16(r[j], hw[j], lw[j]);
+            bf16x8_t bh[2], bl[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const uint4 hu = make_uint4(hw[8 * p] | (hw[8 * p + 1] << 16), hw[8 * p + 2] | (hw[8 * p + 3] << 16),
+                                            hw[8 * p + 4] | (hw[8 * p + 5] << 16), hw[8 * p + 6] | (hw[8 * p + 7] << 16));
+                const uint4 lu = make_uint4(lw[8 * p] | (lw[8 * p + 1] << 16), lw[8 * p + 2] | (lw[8 * p + 3] << 16),
+                                            lw[8 * p + 4] | (lw[8 * p + 5] << 16), lw[8 * p + 6] | (lw[8 * p + 7] << 16));
+                bh[p] = __builtin_bit_cast(bf16x8_t, hu);
+                bl[p] = __builtin_bit_cast(bf16x8_t, lu);
+            }
+            float best1 = INFINITY, best2 = INFINITY;
+            int tbest = 0;
+            if (NT > 0) {
+#pragma unroll
+                for (int tt = 0; tt < NT; tt++) pf32_tile(Ch, Cl, ccs, 32 * tt, off_p0, off_p1, h, bh, bl, best1, best2, tbest);
+            } else {
+                for (int t = 0; t < a.KC; t += 32) pf32_tile(Ch, Cl, ccs, t, off_p0, off_p1, h, bh, bl, best1, best2, tbest);
+            }
+            const int jb = (int)(__float_as_uint(best1) & 15u);
+            int idx1 = tbest + (jb & 3) + 8 * (jb >> 2) + 4 * h;
+            {   // merge the item's two lanes: smallest (lowest index on ties) and second smallest of the union
+                const float o1 = __uint_as_float(swap32_other(__float_as_uint(best1), h));
+                const float o2 = __uint_as_float(swap32_other(__float_as_uint(best2), h));
+                const int oi = (int)swap32_other((unsigned)idx1, h);
+                best2 = fminf(fmaxf(best1, o1), fminf(best2, o2));
+                if (o1 < best1 || (o1 == best1 && oi < idx1)) { best1 = o1; idx1 = oi; }
+            }
+            const float delta = 6.103515625e-05f * (xx + __uint_as_float(ccmax_bits[i]));  // 2^-14 (|x|^2 + max |c|^2)
+            int bidx = idx1;
+            const bool undecided = !(best2 - best1 > delta);
+            if (__ballot(undecided) != 0ull)
+                bidx = pf32_confirm<NT>(a, i, Ch, Cl, ccs, off_p0, off_p1, h, lane, r, xx, undecided ? best1 + delta : -INFINITY, idx1);
+            float e[16];
+            load16(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 16 * h, e);
+            const float cce = a.cc[(int64_t)i * a.K + bidx];
+            float o[16];
+            level_output16<MODE, TRAIN>(r, e, xx, cce, o);
+            float df[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) df[j] = r[j] - e[j];
+            const float l1 = dotH(df, df);
+            loss = loss + (l1 + a.beta * l1);
+            if (valid && h == 0) a.ids[item * a.L + i] = (int64_t)bidx;
+            if (a.emb_cat != nullptr && valid) store16(a.emb_cat + item * a.ld_cat + i * D + 16 * h, o);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                esum[j] = (i == 0) ? o[j] : esum[j] + o[j];
+                r[j] = r[j] - o[j];
+            }
+        }
+        if (a.emb_sum != nullptr && valid) store16(a.emb_sum + item * D + 16 * h, esum);
+        if (valid && a.qloss != nullptr && h == 0) a.qloss[item] = loss;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The narrow middle of the step in ONE launch (small batches): the encoder's last two layers, the L-level quantisation and the
 // decoder's first two layers are all row-local, 16 items wide here, and each is a ~5 us launch on its own:
 //     h2 = silu(h1 W2^T) -> y = h2 W3^T -> [z = normalize(y)] -> L levels -> d0 = silu(emb_sum Wd0^T) -> d1 = silu(d0 Wd1^T)
@@ -995,8 +1366,32 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU (LDS-limited), grid-stride over tiles
     hipStream_t s = (hipStream_t)stream;
     // large batches whose codebooks fit as bf16 hi/lo images: split-bf16 prefilter + exact confirmation (bit-identical results)
-    static const bool prefilter_on = !(getenv("HIDVAE_RQ_PREFILTER") && getenv("HIDVAE_RQ_PREFILTER")[0] == '0');
+    // HIDVAE_RQ_PREFILTER: 0 = exact kernel only, 16 = the 16-item prefilter only, 32 = the 32-item kernel from 65536 items on
+    static const int pf_env = getenv("HIDVAE_RQ_PREFILTER") ? atoi(getenv("HIDVAE_RQ_PREFILTER")) : -1;
+    const bool prefilter_on = pf_env != 0;
     const int KCp = (int)(hv_cdiv(K, 32) * 32);
+    const size_t pf32_bytes = pf32_level_bytes(KCp) * (size_t)L;
+    if (prefilter_on && pf_env != 16 && B >= (pf_env == 32 ? 256 * 256 : 128 * 1024) && pf32_bytes <= 152 * 1024) {
+        FwdArgs p = a;
+        p.KC = KCp;
+        p.nchunks = 1;
+        constexpr int PF32_NW = 12;  // waves per workgroup: three per SIMD, up to 170 VGPRs each (measured at 1M items: 16 waves / 128 VGPRs
+                                     // with spills 480-500 us, 12 waves 436-448 us, 8 waves 457 us)
+        const int64_t nt = hv_cdiv(B, 32 * PF32_NW);
+        const int pgrid = (int)(nt < 256 ? nt : 256);
+#define HV_PF32(M, T)                                                                                                          \
+    {                                                                                                                          \
+        auto kern = KCp == 256 ? rq_forward_pf32_kernel<M, T, PF32_NW, 8> : rq_forward_pf32_kernel<M, T, PF32_NW, 0>;                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf32_bytes); \
+        hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * PF32_NW), pf32_bytes, s, p);                                           \
+    }
+        if (!training) HV_PF32(HIDVAE_MODE_STE, false)
+        else if (mode == HIDVAE_MODE_STE) HV_PF32(HIDVAE_MODE_STE, true)
+        else HV_PF32(HIDVAE_MODE_ROTATION, true)
+#undef HV_PF32
+        HV_LAUNCH_CHECK("rq_forward prefilter32");
+        return HIDVAE_OK;
+    }
     const size_t pf_lds_bytes = pf_level_bytes(KCp) * (size_t)L;
     if (prefilter_on && B >= 256 * 256 && pf_lds_bytes <= 152 * 1024) {
         FwdArgs p = a;

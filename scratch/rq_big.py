@@ -7,7 +7,7 @@ torch.manual_seed(0)
 L, K = 3, 256
 tabs = [(torch.rand(K, 32, device=dev) * 2 - 1) * (1.0 if i == 0 else 0.35 * 0.5 ** i) for i in range(L)]
 cb, cc = _C.codebook_prepare(tabs, [i == 0 for i in range(L)])
-for B in (1 << 17, 1 << 20):
+for B in (1 << 17, 1 << 18, 1 << 19, 1 << 20):
     y = torch.randn(B, 32, device=dev)
     for train in (True, False):
         for _ in range(3): out = _C.rq_forward(y, cb, cc, True, 3, train, 0.4)

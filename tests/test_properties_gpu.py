@@ -164,12 +164,14 @@ def test_device_rand_provider_properties():
 
 @pytest.mark.parametrize("mode,training", [(3, True), (2, True), (3, False)])
 @pytest.mark.parametrize("kind", ["spread", "near_duplicates", "exact_duplicates", "tiny_residuals"])
-def test_prefilter_kernel_is_bit_identical_to_the_exact_kernel(C, mode, training, kind):
+@pytest.mark.parametrize("N,K", [(70000, 256), (270001, 256), (262144 + 77, 96)])
+def test_prefilter_kernel_is_bit_identical_to_the_exact_kernel(C, mode, training, kind, N, K):
     """Batches >= 65536 take the split-bf16 prefilter kernel (approximate scores on bf16 MFMA, exact re-search where the two best
-    scores are closer than the error bound); smaller launches take the exact fp32 kernel.  Same items through both: every output
-    must match bit for bit -- also when most items are ambiguous (near-duplicate / duplicate codes) and when residual norms
-    collapse (levels whose codes are far larger than the residual)."""
-    N, L, K = 70000, 3, 256
+    scores are closer than the error bound), batches >= 262144 its 32-items-per-wave form (32x32x16 MFMA, index packed into the
+    scores' low bits; K = 96 takes the not-unrolled instance); smaller launches take the exact fp32 kernel.  Same items through
+    both: every output must match bit for bit -- also when most items are ambiguous (near-duplicate / duplicate codes) and when
+    residual norms collapse (levels whose codes are far larger than the residual)."""
+    L = 3
     g = torch.Generator(device="cuda").manual_seed(17)
     tabs = tables(L, K, 81)
     if kind == "near_duplicates":
@@ -184,8 +186,8 @@ def test_prefilter_kernel_is_bit_identical_to_the_exact_kernel(C, mode, training
     y = torch.randn(N, 32, device="cuda", generator=g)
     cb, cc = C.codebook_prepare(tabs, [True, False, False])
     big = C.rq_forward(y, cb, cc, True, mode, training, 0.4, want_res=True)
-    half = N // 2
-    parts = [C.rq_forward(y[lo:hi].contiguous(), cb, cc, True, mode, training, 0.4, want_res=True) for lo, hi in ((0, half), (half, N))]
+    cuts = list(range(0, N, 60000)) + [N]  # every piece below 65536 items: the exact kernel
+    parts = [C.rq_forward(y[lo:hi].contiguous(), cb, cc, True, mode, training, 0.4, want_res=True) for lo, hi in zip(cuts[:-1], cuts[1:])]
     names = ("z", "ids", "emb_cat", "emb_sum", "res_cat", "qloss")
     for j, name in enumerate(names):
         want = torch.cat([p[j] for p in parts], 0)
