@@ -28,7 +28,7 @@ _SIGNATURES = {
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "hidvae_bottleneck_fwd": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp,
-                              _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                              _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _vp],
     "hidvae_uniq_loss": [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
     "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -277,8 +277,16 @@ def bottleneck_eligible(B, K2, N2, Nd0, Nd1, L, K):
             and lds <= 160 * 1024 - 1024)
 
 
-def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1):
-    """-> dict of every tensor the launch writes (see include/hidvae.h)"""
+_CENSUS_SCRATCH = {}
+
+
+def census_eligible(L, K):
+    """can the fused middle launch carry the id census (10 bits per level in a 40-bit slot field)?"""
+    return L <= 4 and K <= 1024
+
+
+def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1, id_stats=False):
+    """-> dict of every tensor the launch writes (see include/hidvae.h); id_stats: also embs_norm [B,L] and p_unique"""
     _f32(h1, "h1")
     B, K2 = h1.shape
     N2, Nd0, Nd1 = W2.shape[0], Wd0.shape[0], Wd1.shape[0]
@@ -291,10 +299,23 @@ def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1
         raise RuntimeError("bottleneck_fwd: operands must be contiguous")
     if tuple(W2.shape) != (N2, K2) or tuple(W3.shape) != (EMBED_DIM, N2) or tuple(Wd0.shape) != (Nd0, EMBED_DIM) or tuple(Wd1.shape) != (Nd1, Nd0):
         raise RuntimeError("bottleneck_fwd: layer shapes do not chain")
+    scratch = None
+    if id_stats:
+        if not census_eligible(L, K):
+            raise RuntimeError(f"bottleneck_fwd: the fused id census needs L <= 4 and K <= 1024 (got {L}, {K})")
+        key = (dev.index, B)
+        scratch = _CENSUS_SCRATCH.get(key)
+        if scratch is None:  # zero-filled once; the kernel keeps it consistent between calls (include/hidvae.h)
+            if len(_CENSUS_SCRATCH) > 64:
+                _CENSUS_SCRATCH.clear()
+            scratch = _CENSUS_SCRATCH[key] = torch.zeros((4 * B + 3,), device=dev, dtype=torch.int64)
+        o["embs_norm"] = f(B, L)
+        o["p_unique"] = torch.empty((), device=dev, dtype=torch.float32)
     _check(lib().hidvae_bottleneck_fwd(_p(h1), B, K2, N2, _p(W2), _p(W3), _p(o["pre2"]), _p(o["h2"]), _p(o["y"]), int(bool(normalize_input)),
                                        _p(cb_eff), _p(cc), L, K, int(mode), float(beta), _p(o["z"]), _p(o["ids"]), _p(o["emb_cat"]),
                                        L * EMBED_DIM, _p(o["emb_sum"]), _p(o["qloss"]), Nd0, Nd1, _p(Wd0), _p(Wd1), _p(o["pre_d0"]),
-                                       _p(o["d0"]), _p(o["pre_d1"]), _p(o["d1"]), _stream()), "hidvae_bottleneck_fwd")
+                                       _p(o["d0"]), _p(o["pre_d1"]), _p(o["d1"]), _p(o.get("embs_norm")), _p(o.get("p_unique")),
+                                       _p(scratch), _stream()), "hidvae_bottleneck_fwd")
     return o
 
 

@@ -141,6 +141,11 @@ struct FwdArgs {
     float *emb_sum;
     float *res_cat;
     float *qloss;
+    // optional, fused middle launch only (hidvae_bottleneck_fwd): the debug statistics of h_rqvae.py:643-648
+    float *embs_norm;             // [B, L]: |emb_out_i| per item and level, summed in id_stats_kernel's order
+    unsigned long long *census;   // id-tuple census table (census_size slots + 3 control words), see bottleneck_fwd_kernel
+    int64_t census_size;
+    float *p_unique;
 };
 
 // stage codes [c0, c0+KC) of level `lvl` into LDS, d-major: Cs[d][KC+2], then |c|^2 (padding: 0 / +inf)
@@ -173,7 +178,8 @@ __device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl
 template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT, int SW = 4>  // SW: waves that share the codes of one 16-item tile
 __device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, float (*cand_d)[SW][16], int (*cand_i)[SW][16], int &phase,
                                               int wave, int it, int q, int64_t item, bool valid, float (&r)[8], float (&esum)[8],
-                                              float &loss) {
+                                              float &loss, unsigned long long &tuple) {
+    tuple = 0ull;  // the item's ids, 10 bits per level (meaningful for L <= 4, K <= 1024: what the fused census needs)
     const int LDK = a.KC + 2;
     const int lvl_floats = 32 * LDK + a.KC;
     loss = 0.0f;
@@ -265,6 +271,20 @@ __device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, floa
             if (q == 0) a.ids[item * a.L + i] = (int64_t)bidx;
             if (a.emb_cat != nullptr) store8(a.emb_cat + item * a.ld_cat + i * D + 8 * q, o);
         }
+        tuple |= (unsigned long long)(unsigned)bidx << (10 * (i & 3));
+        if (a.embs_norm != nullptr) {
+            // |o|: id_stats_kernel adds ((x^2+y^2)+(z^2+w^2)) of the row's eight float4 one after the other; the lane quarter q
+            // holds float4 number 2q and 2q+1, so the running sum walks q = 0, 1, 2, 3
+            const float ta = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+            const float tb = (o[4] * o[4] + o[5] * o[5]) + (o[6] * o[6] + o[7] * o[7]);
+            float sn = ta + tb;
+#pragma unroll
+            for (int step = 1; step < 4; step++) {
+                const float prev = __shfl(sn, (threadIdx.x - 16) & 63);
+                if (q == step) sn = (prev + ta) + tb;
+            }
+            if (valid && q == 3) a.embs_norm[item * a.L + i] = sqrtf(sn);
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             esum[j] = (i == 0) ? o[j] : esum[j] + o[j];
@@ -306,7 +326,8 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
         if (a.z != nullptr && valid) store8(a.z + item * D + 8 * q, r);
         float loss;
         float esum[8];
-        rq_level_loop<MODE, TRAIN, RESIDENT, CSPLIT>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss);
+        unsigned long long tuple;
+        rq_level_loop<MODE, TRAIN, RESIDENT, CSPLIT>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss, tuple);
         if (valid) {
             if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
             if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
@@ -999,10 +1020,26 @@ __global__ __launch_bounds__(64 * BN_WAVES) void bottleneck_fwd_kernel(BneckArgs
     float loss;
     float esum[8];
     int phase = 0;
-    rq_level_loop<MODE, true, true, true, BN_WAVES>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss);
+    unsigned long long tuple;
+    rq_level_loop<MODE, true, true, true, BN_WAVES>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss, tuple);
     if (valid) {
         if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
         if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
+    }
+    // id census, first half: the first table probe is issued here and read after the decoder layers (its latency hides under them)
+    const bool census_lane = a.census != nullptr && valid && q == 0;
+    unsigned long long census_calls = 0ull, census_cur = 0ull;
+    int64_t census_slot = 0;
+    if (a.census != nullptr && wave == 0) census_calls = a.census[a.census_size + 2];
+    if (census_lane) {
+        unsigned long long h = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < a.L; i++) {
+            h ^= ((tuple >> (10 * i)) & 1023ull) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 29;
+        }
+        census_slot = (int64_t)(h % (unsigned long long)a.census_size);
+        census_cur = __atomic_load_n(a.census + census_slot, __ATOMIC_RELAXED);
     }
     __syncthreads();  // HY is free again (every wave has read its r)
     if (wave == 0) {  // every wave carries the same esum: one of them writes the k-block images of the decoder's input
@@ -1012,7 +1049,62 @@ __global__ __launch_bounds__(64 * BN_WAVES) void bottleneck_fwd_kernel(BneckArgs
     __syncthreads();
     bneck_layer<BN_WAVES>(b.Wd0, b.Nd0, D, HY, true, b.pre_d0, b.d0, HA, item, in_range, wave, lane);
     __syncthreads();
+    // id census, middle: the probe has landed; a slot of an older generation is claimed now, the answer is read after the last layer
+    constexpr unsigned long long CENSUS_GEN_MOD = 0xFFFFFEull;
+    const unsigned long long census_gen = census_calls % CENSUS_GEN_MOD + 1ull;
+    bool census_claimed = false;
+    unsigned long long census_prev = 0ull;
+    if (census_lane && (census_cur >> 40) != census_gen) {
+        census_prev = atomicCAS(a.census + census_slot, census_cur, (census_gen << 40) | tuple);
+        census_claimed = true;
+    }
     bneck_layer<BN_WAVES>(b.Wd1, b.Nd1, b.Nd0, HA, true, b.pre_d1, b.d1, nullptr, item, in_range, wave, lane);
+    // id census, second half (p_unique_ids of h_rqvae.py:645-648 = distinct id tuples / B): the scheme of id_stats_kernel
+    // (core_ops.hip) -- a never-cleared open-addressing table with generation-tagged slots and ONE packed ticket/count atomic per
+    // workgroup -- except that a slot holds the tuple itself, (generation << 40) | 10 bits per level, so no workgroup reads ids
+    // another one wrote in this launch.  Saves the 11 us launch of its own; costs one atomic round trip at this kernel's tail.
+    if (a.census != nullptr && wave == 0) {
+        constexpr unsigned long long GEN_MOD = CENSUS_GEN_MOD, LOW40 = (1ull << 40) - 1ull;
+        unsigned long long *ctrl = a.census + a.census_size;
+        const unsigned long long gen = census_gen;
+        bool is_new = census_claimed && census_prev == census_cur;  // first item with this tuple, settled by the early claim
+        if (census_lane && !is_new) {
+            const unsigned long long mine = (gen << 40) | tuple;
+            unsigned long long cur = census_claimed ? census_prev : census_cur;  // (a lost claim returns the slot's real content)
+            int64_t slot = census_slot;
+            for (int64_t probe = 0; probe < a.census_size;) {
+                if ((cur >> 40) != gen) {
+                    const unsigned long long prev = atomicCAS(a.census + slot, cur, mine);
+                    if (prev == cur) { is_new = true; break; }  // first item with this tuple
+                    cur = prev;
+                    if ((cur >> 40) != gen) continue;  // lost a race against a stale view of the slot: look again
+                }
+                if ((cur & LOW40) == tuple) break;  // duplicate of an already counted tuple
+                slot = slot + 1 == a.census_size ? 0 : slot + 1;
+                cur = __atomic_load_n(a.census + slot, __ATOMIC_RELAXED);
+                probe++;
+            }
+        }
+        const int fresh = __popcll(__ballot(is_new));
+        int last = 0;
+        unsigned long long total = 0ull;
+        if (lane == 0) {
+            const unsigned long long old = atomicAdd(ctrl, ((unsigned long long)fresh << 32) + 1ull);
+            last = (old & 0xFFFFFFFFull) == (unsigned long long)gridDim.x - 1ull;
+            total = (unsigned long long)fresh + (old >> 32);
+        }
+        last = __shfl(last, 0);
+        if (last) {  // every other workgroup has drawn its ticket, i.e. finished its probes
+            if (lane == 0) {
+                *a.p_unique = (float)total / (float)a.B;
+                ctrl[0] = 0ull;
+                ctrl[1] = 0ull;
+                ctrl[2] = census_calls + 1ull;
+            }
+            if ((census_calls + 1ull) % GEN_MOD == 0ull)
+                for (int64_t i = lane; i < a.census_size; i += 64) a.census[i] = 0ull;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1421,7 +1513,7 @@ extern "C" int hidvae_bottleneck_fwd(const float *h1, int64_t B, int K2, int N2,
                                      float *y, int normalize_input, const float *cb_eff, const float *cc, int L, int64_t K, int mode,
                                      float beta, float *z, int64_t *ids, float *emb_cat, int64_t ld_cat, float *emb_sum, float *qloss,
                                      int Nd0, int Nd1, const float *Wd0, const float *Wd1, float *pre_d0, float *d0, float *pre_d1,
-                                     float *d1, void *stream) {
+                                     float *d1, float *embs_norm, float *p_unique, int64_t *census_scratch, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS && B >= 1 && K >= 1, "bottleneck_fwd: bad sizes");
     HV_REQUIRE(h1 && W2 && W3 && h2 && y && cb_eff && cc && ids && emb_sum && Wd0 && Wd1 && d0 && d1 && pre2 && pre_d0 && pre_d1,
                "bottleneck_fwd: null pointer");
@@ -1440,6 +1532,13 @@ extern "C" int hidvae_bottleneck_fwd(const float *h1, int64_t B, int K2, int N2,
     const size_t lds = level_lds_bytes(a.KC) * (size_t)L + (size_t)(2 * (BN_HMAX / 16) * 64 + 2 * 64) * sizeof(float4);
     HV_REQUIRE(a.KC % (32 * BN_WAVES) == 0 && a.KC <= MAX_KC && lds <= 160 * 1024 - 1024,
                "bottleneck_fwd: the codebooks (L=%d, K=%lld) do not fit in LDS beside the activations", L, (long long)K);
+    HV_REQUIRE((embs_norm == nullptr) == (census_scratch == nullptr) && (p_unique == nullptr) == (census_scratch == nullptr),
+               "bottleneck_fwd: embs_norm, p_unique and census_scratch come together or not at all");
+    HV_REQUIRE(census_scratch == nullptr || (L <= 4 && K <= 1024 && emb_cat != nullptr),
+               "bottleneck_fwd: the fused id census packs 10 bits per level into 40 (L=%d, K=%lld)", L, (long long)K);
+    a.embs_norm = embs_norm; a.p_unique = p_unique;
+    a.census = reinterpret_cast<unsigned long long *>(census_scratch);
+    a.census_size = 4 * B;
     b.h1 = h1; b.K2 = K2; b.N2 = N2; b.W2 = W2; b.W3 = W3; b.pre2 = pre2; b.h2 = h2; b.y_out = y;
     b.Nd0 = Nd0; b.Nd1 = Nd1; b.Wd0 = Wd0; b.Wd1 = Wd1; b.pre_d0 = pre_d0; b.d0 = d0; b.pre_d1 = pre_d1; b.d1 = d1;
     const int grid = (int)hv_cdiv(B, ITEMS_PER_WAVE);

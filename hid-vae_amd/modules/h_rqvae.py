@@ -305,13 +305,14 @@ class HRqVae(nn.Module, _HubMixin):
                 r.begin_step(x.device)  # all dropout keep-masks of the step from one launch (rand.DeviceRand)
         self._prepared = self._prepare_codebooks_async()  # effective codebooks + |c|^2 on the helper stream, beside the encoder
         y_dec = None
+        embs_norm = p_unique = None  # (the fused middle launch produces them itself when it can)
         if self._bottleneck_ok(x):
             # small batches: encoder[-2:] + the L levels + decoder[:2] are one launch (ops.BottleneckFn); the stacks either side
             # hand over (pre-activation, activation) pairs so no elementwise launch appears at the cuts
             from ..ops import BottleneckFn, MLPBackFn, MLPFrontFn
             We, Wd = self.encoder.weights(), self.decoder.weights()
             pre1, h1 = MLPFrontFn.apply(x, *We[:-2])
-            z, ids, emb_cat, emb_sum, qloss, pre_d1, d1 = BottleneckFn.apply(
+            z, ids, emb_cat, emb_sum, qloss, pre_d1, d1, embs_norm, p_unique = BottleneckFn.apply(
                 pre1, h1, We[-2], We[-1], Wd[0], Wd[1], self.codebook_normalize, self._fused_mode(), self.commitment_weight,
                 self._normalize_flags(), self._prepared, *self._tables())
             y_dec = MLPBackFn.apply(pre_d1, d1, *Wd[2:])
@@ -328,13 +329,14 @@ class HRqVae(nn.Module, _HubMixin):
         # helper stream beside the decoder instead of after it
         from ..ops import side_stream
         main, side = torch.cuda.current_stream(), side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side), torch.no_grad():
-            embs_norm, p_unique = _C.id_stats(emb_cat.detach(), ids)
-        for t in (embs_norm, p_unique):
-            t.record_stream(main)
-        for t in (emb_cat, ids):
-            t.record_stream(side)
+        if embs_norm is None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                embs_norm, p_unique = _C.id_stats(emb_cat.detach(), ids)
+            for t in (embs_norm, p_unique):
+                t.record_stream(main)
+            for t in (emb_cat, ids):
+                t.record_stream(side)
         # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0) and the total loss in one launch
         # the alignment / uniqueness weights enter once inside their loss modules and once more here
         n_tag = len(tag_scalars) // 3

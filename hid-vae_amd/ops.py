@@ -164,7 +164,8 @@ class BottleneckFn(Function):
     """encoder[-2:] + all L quantisation levels + decoder[:2] in one launch (csrc/rq.hip bottleneck_fwd_kernel); the backward is
     the same sequence of launches as the unfused path (paired Linear backward x4, rq_backward, codebook_grad).
     inputs : pre1 / h1 (the cut pair), W2, W3, Wd0, Wd1, config, prepared codebooks or None, the L raw tables
-    outputs: z, ids, emb_cat, emb_sum (non-differentiable here: its gradient is produced inside), qloss, pre_d1 / d1 (cut pair)"""
+    outputs: z, ids, emb_cat, emb_sum (non-differentiable here: its gradient is produced inside), qloss, pre_d1 / d1 (cut pair),
+             embs_norm, p_unique (the debug statistics of h_rqvae.py:643-648 when the launch can carry the id census, else None)"""
 
     @staticmethod
     def forward(ctx, pre1, h1, W2, W3, Wd0, Wd1, normalize_input, mode, beta, normalize_flags, prepared, *tables):
@@ -174,16 +175,19 @@ class BottleneckFn(Function):
             join_side()
         else:
             cb, cc = _C.codebook_prepare([t.detach() for t in tables], normalize_flags)
-        o = _C.bottleneck_fwd(h1, W2.detach(), W3.detach(), cb, cc, normalize_input, mode, beta, Wd0.detach(), Wd1.detach())
+        census = _C.census_eligible(cb.shape[0], cb.shape[1]) and os.environ.get("HIDVAE_FUSED_CENSUS", "1") != "0"
+        o = _C.bottleneck_fwd(h1, W2.detach(), W3.detach(), cb, cc, normalize_input, mode, beta, Wd0.detach(), Wd1.detach(), id_stats=census)
         ctx.cfg = (normalize_input, mode, beta, tuple(normalize_flags))
         ctx.params = (W2, W3, Wd0, Wd1)
         ctx.tables = tables
         ctx.save_for_backward(pre1, h1, o["pre2"], o["h2"], o["y"], o["z"], o["ids"], o["emb_sum"], o["pre_d0"], o["d0"], cb, cc)
         ctx.mark_non_differentiable(o["ids"], o["emb_sum"], o["d1"])
-        return o["z"], o["ids"], o["emb_cat"], o["emb_sum"], o["qloss"], o["pre_d1"], o["d1"]
+        if census:
+            ctx.mark_non_differentiable(o["embs_norm"], o["p_unique"])
+        return o["z"], o["ids"], o["emb_cat"], o["emb_sum"], o["qloss"], o["pre_d1"], o["d1"], o.get("embs_norm"), o.get("p_unique")
 
     @staticmethod
-    def backward(ctx, g_z, _g_ids, g_cat, _g_sum, g_q, g_pre_d1, _g_d1):
+    def backward(ctx, g_z, _g_ids, g_cat, _g_sum, g_q, g_pre_d1, _g_d1, _g_norm=None, _g_pu=None):
         normalize_input, mode, beta, flags = ctx.cfg
         W2, W3, Wd0, Wd1 = ctx.params
         pre1, h1, pre2, h2, y, z, ids, emb_sum, pre_d0, d0, cb, cc = ctx.saved_tensors

@@ -125,12 +125,16 @@ int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
  *   z, ids, emb_cat, emb_sum, qloss = hidvae_rq_forward(y, ...)  (same arguments and results)
  *   d0 = silu(emb_sum Wd0^T) [B,Nd0],  d1 = silu(d0 Wd1^T) [B,Nd1]
  * pre2 / pre_d0 / pre_d1 receive the pre-activations (the backward's saved tensors).  All widths multiples of 16; K2, N2, Nd0
- * <= 256.  Every output is bit-identical to the separate launches (hidvae_gemm_f32 split_k=1 + hidvae_rq_forward). */
+ * <= 256.  Every output is bit-identical to the separate launches (hidvae_gemm_f32 split_k=1 + hidvae_rq_forward).
+ * Optionally (all three pointers, or none) the launch also produces the debug statistics of h_rqvae.py:643-648 that
+ * hidvae_id_stats computes: embs_norm [B,L] and *p_unique, same values bit for bit; census_scratch = 4*B+3 int64, zero-filled ONCE
+ * by its owner and then only touched by this entry point (NOT shared with hidvae_id_stats: its slots carry the id tuple itself,
+ * 10 bits per level, so L <= 4 and K <= 1024). */
 int hidvae_bottleneck_fwd(const float *h1, int64_t B, int K2, int N2, const float *W2, const float *W3, float *pre2, float *h2,
                           float *y, int normalize_input, const float *cb_eff, const float *cc, int L, int64_t K, int mode,
                           float beta, float *z, int64_t *ids, float *emb_cat, int64_t ld_cat, float *emb_sum, float *qloss,
                           int Nd0, int Nd1, const float *Wd0, const float *Wd1, float *pre_d0, float *d0, float *pre_d1,
-                          float *d1, void *stream);
+                          float *d1, float *embs_norm, float *p_unique, int64_t *census_scratch, void *stream);
 
 /* ---- fused RQ backward (autograd of the above) --------------------------------
  *   g_cat [B, ld_gcat] grad wrt each o_i (NULL = 0); g_sum [B,32] grad wrt sum_i o_i (NULL = 0);

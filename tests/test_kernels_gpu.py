@@ -268,6 +268,19 @@ def test_bottleneck_launch_is_bit_identical_to_the_separate_launches(C, B, mode,
     want = dict(pre2=pre2, h2=h2, y=y, z=z, ids=ids, emb_cat=emb_cat, emb_sum=emb_sum, qloss=qloss, pre_d0=pre_d0, d0=d0, pre_d1=pre_d1, d1=d1)
     for k, v in want.items():
         assert torch.equal(o[k], v), k
+    # the same launch carrying the debug statistics (id census + |emb_out| per level) against hidvae_id_stats; repeated calls walk
+    # the census table's generations, and a batch of copies has few distinct tuples
+    for rep in range(3):
+        oc = C.bottleneck_fwd(h1, W2, W3, cb, cc, norm, mode, 0.4, Wd0, Wd1, id_stats=True)
+        norms, pu = C.id_stats(oc["emb_cat"], oc["ids"])
+        for k, v in want.items():
+            assert torch.equal(oc[k], v), k
+        assert torch.equal(oc["embs_norm"], norms) and float(oc["p_unique"]) == float(pu), rep
+    hdup = h1[torch.arange(B, device="cuda") % 5].contiguous()
+    od = C.bottleneck_fwd(hdup, W2, W3, cb, cc, norm, mode, 0.4, Wd0, Wd1, id_stats=True)
+    distinct = len({tuple(r) for r in od["ids"].cpu().tolist()})
+    assert float(od["p_unique"]) == float(torch.tensor(distinct, dtype=torch.float32) / torch.tensor(B, dtype=torch.float32))
+    assert torch.equal(od["embs_norm"], C.id_stats(od["emb_cat"], od["ids"])[0])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
