@@ -50,6 +50,7 @@ _SIGNATURES = {
     "hidvae_batchnorm_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp],
     "hidvae_infonce_rows": [_vp, _i64, _f, _f, _vp, _vp, _vp],
     "hidvae_infonce_dlogits": [_vp, _i64, _f, _f, _vp, _vp],
+    "hidvae_mixup_plan": [_vp, _i64, _i, _i64, _vp, _f, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_fwd": [_vp, _i64, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "hidvae_kmeans_iter": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -582,6 +583,24 @@ def infonce_rows(S, tau, scale):
 def infonce_dlogits(P, tau, scale, g):
     _check(lib().hidvae_infonce_dlogits(_p(P), P.shape[0], float(tau), float(scale), _p(g), _stream()), "hidvae_infonce_dlogits")
     return P
+
+
+MIXUP_PLAN_MAX_B = 4096
+
+
+def mixup_plan(targets, uniforms, alpha):
+    """targets [B, L] int64, uniforms [L, B+64] -> partner [L,B], inverse [L,B] (int64), lam [L]: one launch for all levels"""
+    B, L = targets.shape
+    if targets.dtype != torch.int64 or targets.stride(1) != 1 or tuple(uniforms.shape) != (L, B + 64) or not uniforms.is_contiguous():
+        raise RuntimeError("mixup_plan: expected int64 targets [B,L] with contiguous rows and float32 uniforms [L,B+64]")
+    _f32(uniforms, "uniforms")
+    dev = targets.device
+    partner = torch.empty((L, B), device=dev, dtype=torch.int64)
+    inverse = torch.empty((L, B), device=dev, dtype=torch.int64)
+    lam = torch.empty((L,), device=dev, dtype=torch.float32)
+    _check(lib().hidvae_mixup_plan(_p(targets), B, L, targets.stride(0) if B > 1 else L, _p(uniforms), float(alpha), _p(partner), _p(inverse),
+                                   _p(lam), _stream()), "hidvae_mixup_plan")
+    return partner, inverse, lam
 
 
 def tag_loss_fwd(logits, target, partner, lam, focal, gamma, alpha, smooth, ce_ls, want_grad):

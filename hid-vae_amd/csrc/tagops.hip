@@ -959,6 +959,112 @@ extern "C" int hidvae_infonce_dlogits(float *P, int64_t B, float tau, float scal
     return HIDVAE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Mixup plan of a training step (loss.py:139-147: perm = randperm(n_valid), lam ~ Beta(alpha, alpha)), all levels in one launch.
+// The torch composition (rand / where / argsort / cumsum / gather / scatter_ / Beta.sample) is ~40 launches, ~190 us of the tagged
+// step; here one workgroup per level sorts (uniform key, row) pairs of the valid rows in LDS (bitonic, ties by row), so
+//   partner[b] = the row mixed into b  (a uniformly random permutation of the valid rows among themselves, -1 on invalid rows)
+//   inverse[partner[b]] = b
+// and one thread draws lam from two Marsaglia-Tsang gamma variates.  The randomness comes in as uniforms u [L, B + 64] from the
+// caller's generator (B keys + 64 spare draws per level for the rejection sampler), so graph replay semantics stay torch's.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int MIX_MAXB = 4096, MIX_SPARE = 64;
+
+__device__ float mix_gamma(float shape, const float *u, int &k) {  // Gamma(shape, 1), shape > 0
+    const float boost = shape < 1.0f ? powf(fmaxf(u[k++ % MIX_SPARE], 1e-30f), 1.0f / shape) : 1.0f;  // G(a) = G(a+1) U^(1/a)
+    const float a = shape < 1.0f ? shape + 1.0f : shape;
+    const float d = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+    float v = 1.0f;
+    for (int attempt = 0; attempt < 16; attempt++) {
+        const float u1 = fmaxf(u[k++ % MIX_SPARE], 1e-30f), u2 = u[k++ % MIX_SPARE], u3 = fmaxf(u[k++ % MIX_SPARE], 1e-30f);
+        const float x = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);  // Box-Muller
+        v = 1.0f + c * x;
+        if (v <= 0.0f) { v = 1.0f; continue; }
+        v = v * v * v;
+        const float x2 = x * x;
+        if (u3 < 1.0f - 0.0331f * x2 * x2 || logf(u3) < 0.5f * x2 + d * (1.0f - v + logf(v))) break;
+    }
+    return d * v * boost;
+}
+
+__global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets, int64_t B, int64_t ldt, const float *u, float alpha,
+                                                          int64_t *partner, int64_t *inverse, float *lam) {
+    __shared__ float key[MIX_MAXB];
+    __shared__ int idx[MIX_MAXB];
+    __shared__ int inv[MIX_MAXB];
+    __shared__ int part[1024];
+    const int lvl = blockIdx.x, tid = threadIdx.x;
+    const float *ul = u + (int64_t)lvl * (B + MIX_SPARE);
+    int n2 = 1024;
+    while (n2 < B) n2 <<= 1;
+    for (int i = tid; i < n2; i += 1024) {
+        const bool valid = i < B && targets[(int64_t)i * ldt + lvl] >= 0;
+        key[i] = valid ? ul[i] : (i < B ? 2.0f : 3.0f);  // valid rows first, then the invalid ones, then the padding
+        idx[i] = i;
+        inv[i] = -1;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool up = (i & k) == 0;
+                    const float ka = key[i], kb = key[p];
+                    const int ia = idx[i], ib = idx[p];
+                    const bool gt = ka > kb || (ka == kb && ia > ib);
+                    if (gt == up) { key[i] = kb; key[p] = ka; idx[i] = ib; idx[p] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    // rank of each valid row among the valid rows: `per` consecutive rows per thread, scan of the per-thread counts
+    const int per = n2 / 1024;
+    int cnt = 0;
+    for (int r = 0; r < per; r++) {
+        const int i = tid * per + r;
+        cnt += (i < B && targets[(int64_t)i * ldt + lvl] >= 0) ? 1 : 0;
+    }
+    part[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int rank = part[tid] - cnt;
+    for (int r = 0; r < per; r++) {
+        const int i = tid * per + r;
+        if (i >= B) break;
+        const bool valid = targets[(int64_t)i * ldt + lvl] >= 0;
+        const int pr = valid ? idx[rank] : -1;
+        partner[(int64_t)lvl * B + i] = pr;
+        if (valid) { inv[pr] = i; rank++; }
+    }
+    __syncthreads();
+    for (int i = tid; i < B; i += 1024) inverse[(int64_t)lvl * B + i] = inv[i];
+    if (tid == 0) {
+        int k = 0;
+        const float x = mix_gamma(alpha, ul + B, k), y = mix_gamma(alpha, ul + B, k);
+        const float s = x + y;
+        lam[lvl] = s > 0.0f ? x / s : 0.5f;
+    }
+}
+}  // namespace
+
+extern "C" int hidvae_mixup_plan(const int64_t *targets, int64_t B, int L, int64_t ld_targets, const float *uniforms, float alpha,
+                                 int64_t *partner, int64_t *inverse, float *lam, void *stream) {
+    HV_REQUIRE(targets && uniforms && partner && inverse && lam && B >= 1 && L >= 1 && ld_targets >= L && alpha > 0.0f,
+               "mixup_plan: bad arguments");
+    HV_REQUIRE(B <= MIX_MAXB, "mixup_plan: B=%lld rows do not fit the in-LDS sort (max %d)", (long long)B, MIX_MAXB);
+    hipLaunchKernelGGL(mixup_plan_kernel, dim3((unsigned)L), dim3(1024), 0, (hipStream_t)stream, targets, B, ld_targets, uniforms, alpha,
+                       partner, inverse, lam);
+    HV_LAUNCH_CHECK("mixup_plan");
+    return HIDVAE_OK;
+}
+
 extern "C" int hidvae_tag_loss_fwd(const float *logits, int64_t B, int64_t C, const int64_t *target, const int64_t *partner,
                                    const float *lam_dev,
                                    int focal, float gamma, float alpha, float smooth, float ce_label_smoothing, float *loss,

@@ -64,6 +64,12 @@ class DeviceRand:
         """targets [B, L] -> per level (partner, inverse, lam), every op batched over the levels.
         Random pairing of the VALID rows (target >= 0) among themselves, as loss.py:144 does on the compacted rows:
         partner[b] = row mixed into b, inverse[partner[b]] = b, -1 on invalid rows; lam ~ Beta(alpha, alpha) (device)."""
+        B, L = targets.shape
+        if targets.is_cuda and B <= 4096 and targets.dtype == torch.int64 and targets.stride(1) == 1:
+            # one launch (csrc/tagops.hip mixup_plan_kernel) on one torch.rand: the torch composition below is ~40 small launches
+            from . import _C
+            partner, inverse, lam = _C.mixup_plan(targets, torch.rand((L, B + 64), device=device, dtype=torch.float32), self.mixup_alpha)
+            return [(partner[i], inverse[i], lam[i]) for i in range(L)]
         t = targets.t()  # [L, B]
         L, B = t.shape
         valid = t >= 0

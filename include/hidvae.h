@@ -285,6 +285,12 @@ int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx, const flo
  * dlogits: P <- (g*scale/(B*tau)) (P - I) in place, g a device scalar -- feed it to two GEMMs for d c / d t. */
 int hidvae_infonce_rows(float *S, int64_t B, float tau, float scale, float *row_loss, float *loss, void *stream);
 int hidvae_infonce_dlogits(float *P, int64_t B, float tau, float scale, const float *g_dev, void *stream);
+/* The mixup plan of one training step for all L levels (loss.py:139-147: perm = randperm(n_valid), lam ~ Beta(alpha, alpha)):
+ * targets [B, ld>=L] int64 (-1 = invalid row); uniforms [L, B+64] in [0,1) from the caller's generator (B sort keys + 64 spare
+ * draws for the gamma sampler, per level).  partner [L,B]: partner[l][b] = the row mixed into b, a uniformly random permutation
+ * of level l's valid rows among themselves, -1 on invalid rows; inverse [L,B]: inverse[l][partner[l][b]] = b; lam [L].  B <= 4096. */
+int hidvae_mixup_plan(const int64_t *targets, int64_t B, int L, int64_t ld_targets, const float *uniforms, float alpha,
+                      int64_t *partner, int64_t *inverse, float *lam, void *stream);
 /* TagPredictionLoss (loss.py:107-265) with the model's layer_idx = 0 call.  target -1 = invalid row.
  * partner[b] (NULL = no mixup): original-index row mixed into row b with weight 1-lam (loss.py:144-154); lam is a
  * DEVICE scalar (it is drawn per step, also under graph replay).

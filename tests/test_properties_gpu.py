@@ -192,3 +192,40 @@ def test_prefilter_kernel_is_bit_identical_to_the_exact_kernel(C, mode, training
     for j, name in enumerate(names):
         want = torch.cat([p[j] for p in parts], 0)
         assert torch.equal(big[j], want), (kind, name, int((big[j] != want).sum()))
+
+
+def test_mixup_plan_kernel_properties(C):
+    """hidvae_mixup_plan (one launch for the pairings and lambdas of all levels): partner is a permutation of the valid rows among
+    themselves with the matching inverse, -1 on invalid rows, for ragged / maximal / single-row shapes; over many draws lam has the
+    mean and variance of Beta(alpha, alpha) and the pairing is not biased towards any row."""
+    g = torch.Generator(device="cuda").manual_seed(23)
+    for B, L in ((1, 1), (7, 3), (1000, 3), (1025, 2), (4096, 8)):
+        t = torch.randint(0, 5, (B, L), device="cuda", generator=g)
+        t[torch.rand(B, device="cuda", generator=g) < 0.3, 0] = -1
+        if L > 1:
+            t[:, L - 1] = -1
+            t[B // 2, L - 1] = 2  # a level with one valid row
+        u = torch.rand(L, B + 64, device="cuda", generator=g)
+        partner, inverse, lam = C.mixup_plan(t, u, 0.2)
+        for l in range(L):
+            valid = (t[:, l] >= 0).cpu()
+            p, inv = partner[l].cpu(), inverse[l].cpu()
+            rows = torch.nonzero(valid).flatten()
+            assert (p[~valid] == -1).all() and (inv[~valid] == -1).all()
+            assert sorted(p[valid].tolist()) == rows.tolist()
+            assert (inv[p[valid]] == rows).all()
+            assert 0.0 <= float(lam[l]) <= 1.0
+        again = C.mixup_plan(t, u, 0.2)  # same uniforms, same plan
+        assert torch.equal(again[0], partner) and torch.equal(again[2], lam)
+    B, L, alpha = 64, 8, 0.2
+    t = torch.zeros(B, L, dtype=torch.int64, device="cuda")
+    lams, firsts = [], []
+    for _ in range(250):
+        partner, _, lam = C.mixup_plan(t, torch.rand(L, B + 64, device="cuda", generator=g), alpha)
+        lams.append(lam)
+        firsts.append(partner[:, 0])
+    lams, firsts = torch.cat(lams).double().cpu(), torch.cat(firsts).cpu()
+    assert abs(float(lams.mean()) - 0.5) < 0.03
+    assert abs(float(lams.var()) - 1.0 / (4 * (2 * alpha + 1))) < 0.02   # Var Beta(a,a) = 1 / (4 (2a + 1))
+    counts = torch.bincount(firsts, minlength=B).double()  # partner of row 0: uniform over the 64 rows (2000 draws)
+    assert float(((counts - counts.mean()) ** 2 / counts.mean()).sum()) < 120.0  # chi-square, 63 dof (mean 63, sd 11)
