@@ -33,7 +33,7 @@ _SIGNATURES = {
     "hidvae_uniq_loss": [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
     "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_total_loss_bwd": [_vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp],
-    "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp],
+    "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _i64, _vp, _vp, _vp, _vp],
     "hidvae_l2norm_fwd": [_vp, _i64, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm32_fwd": [_vp, _i64, _i64, _f, _vp, _i64, _vp, _vp],
@@ -339,8 +339,9 @@ def codebook_grad(ids, dE_rows, tables, cb_eff, normalize_flags, grads=None, acc
     if grads is None:
         grads = [torch.empty_like(t) for t in tables]
     flags = (ctypes.c_int32 * L)(*[int(bool(f)) for f in normalize_flags])
+    ws = torch.empty((L * K * ((B + 2047) // 2048) * EMBED_DIM,), device=ids.device, dtype=torch.float32) if B > 2048 else None
     _check(lib().hidvae_codebook_grad(_p(ids), _p(dE_rows), B, L, K, _host_ptr_array(tables), _p(cb_eff), flags,
-                                      _host_ptr_array(grads), int(accumulate), _stream()), "hidvae_codebook_grad")
+                                      _host_ptr_array(grads), int(accumulate), _p(ws), _stream()), "hidvae_codebook_grad")
     return grads
 
 

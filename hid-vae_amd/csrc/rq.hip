@@ -1237,6 +1237,11 @@ struct CbGradArgs {
     int normalize[HIDVAE_MAX_LEVELS];
     float *gE[HIDVAE_MAX_LEVELS];
     int accumulate;
+    // large batches: blockIdx.y = slab of `slab_items` items; every (code, slab) wave leaves its sum in partial[row][slab][32] and
+    // codebook_grad_final_kernel adds the slabs in ascending order (slabs == 1: the one-pass form, partial unused)
+    int slabs;
+    int64_t slab_items;
+    float *partial;
 };
 
 template <bool STAGED>  // STAGED (K % 4 == 0: the workgroup's four codes share a level): the chunk's ids go through LDS once
@@ -1284,17 +1289,19 @@ __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a)
         n = 0;
     };
     constexpr int CH = STAGED ? 4096 : 1024;  // items per staging round (16 independent id loads per thread in flight)
-    for (int64_t c0 = 0; c0 < a.B; c0 += CH) {
+    const int64_t lo = (int64_t)blockIdx.y * a.slab_items;
+    const int64_t hi = lo + a.slab_items < a.B ? lo + a.slab_items : a.B;
+    for (int64_t c0 = lo; c0 < hi; c0 += CH) {
         if (STAGED) {
             __syncthreads();  // the previous chunk has been consumed by every wave
 #pragma unroll
             for (int j = 0; j < CH / 256; j++) {
                 const int64_t b = c0 + j * 256 + threadIdx.x;
-                chunk[j * 256 + threadIdx.x] = b < a.B ? (int)a.ids[b * a.L + lvl] : -1;
+                chunk[j * 256 + threadIdx.x] = b < hi ? (int)a.ids[b * a.L + lvl] : -1;
             }
             __syncthreads();
         }
-        for (int s0 = 0; s0 < CH && c0 + s0 < a.B; s0 += 1024) {
+        for (int s0 = 0; s0 < CH && c0 + s0 < hi; s0 += 1024) {
             if (n > 1024) drain();  // (wave-uniform)
             int64_t idv[16];
             if (STAGED) {
@@ -1303,8 +1310,8 @@ __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a)
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; j++) {  // 16 independent loads in flight
-                    const int64_t b = c0 + j * 64 + lane;
-                    idv[j] = b < a.B ? a.ids[b * a.L + lvl] : -1;
+                    const int64_t b = c0 + s0 + j * 64 + lane;
+                    idv[j] = b < hi ? a.ids[b * a.L + lvl] : -1;
                 }
             }
 #pragma unroll
@@ -1319,7 +1326,40 @@ __global__ __launch_bounds__(WG_THREADS) void codebook_grad_kernel(CbGradArgs a)
     drain();
     acc = acc + __shfl_xor(acc, 32);  // even-entry chain + odd-entry chain (the same value on both halves)
     if (!live) return;
+    if (a.slabs > 1) {  // this slab's share; the epilogue runs in codebook_grad_final_kernel
+        if (lane < 32) a.partial[(rowc * a.slabs + blockIdx.y) * D + d] = acc;
+        return;
+    }
     if (nrm) {  // c = E / max(|E|, eps)  =>  gE = (g - c (c.g)) / max(|E|, eps)
+        float n2 = ev * ev, cg = cv * acc;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            n2 += __shfl_xor(n2, o);
+            cg += __shfl_xor(cg, o);
+        }
+        acc = (acc - cv * cg) / fmaxf(sqrtf(n2), 1e-12f);
+    }
+    if (lane < 32) {
+        float *dst = a.gE[lvl] + k * D + d;
+        *dst = a.accumulate ? *dst + acc : acc;
+    }
+}
+
+// slabs of a large batch, added in ascending order, then the same epilogue: one half-wave per (level, code)
+__global__ __launch_bounds__(WG_THREADS) void codebook_grad_final_kernel(CbGradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= (int64_t)a.L * a.K) return;
+    const int lvl = (int)(row / a.K);
+    const int64_t k = row - (int64_t)lvl * a.K;
+    const int d = lane & 31;
+    const bool nrm = a.normalize[lvl] != 0;
+    const float ev = nrm ? a.E[lvl][k * D + d] : 0.0f;
+    const float cv = nrm ? a.cb_eff[row * D + d] : 0.0f;
+    const float *p = a.partial + row * a.slabs * D + d;
+    float acc = p[0];
+    for (int s = 1; s < a.slabs; s++) acc += p[(int64_t)s * D];
+    if (nrm) {
         float n2 = ev * ev, cg = cv * acc;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) {
@@ -1573,7 +1613,7 @@ extern "C" int hidvae_rq_backward(const float *y, const float *z, int64_t B, int
 
 extern "C" int hidvae_codebook_grad(const int64_t *ids, const float *dE_rows, int64_t B, int L, int64_t K,
                                     const float *const *E_host, const float *cb_eff, const int32_t *normalize_host,
-                                    float *const *gE_host, int accumulate, void *stream) {
+                                    float *const *gE_host, int accumulate, float *workspace, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS && B >= 1 && K >= 1, "codebook_grad: bad sizes");
     HV_REQUIRE(ids && dE_rows && E_host && cb_eff && gE_host, "codebook_grad: null pointer");
     CbGradArgs a{};
@@ -1583,10 +1623,21 @@ extern "C" int hidvae_codebook_grad(const int64_t *ids, const float *dE_rows, in
         a.normalize[i] = normalize_host ? normalize_host[i] : 0;
         a.gE[i] = gE_host[i];
     }
-    const int grid = (int)hv_cdiv((int64_t)L * K, 4);
-    if (K % 4 == 0) hipLaunchKernelGGL(codebook_grad_kernel<true>, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(codebook_grad_kernel<false>, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+    // one wave per (level, code) walks the items in ascending order: fine for a training batch, but the longest code's chain sets
+    // the time (47 us at B = 8192 with the skewed ids of an untrained model).  With a workspace, batches above 2048 items are
+    // summed in slabs of 2048 by (level, code, slab) waves and the slabs added in ascending order by a second launch.
+    a.slab_items = 2048;
+    a.slabs = (workspace != nullptr && B > a.slab_items) ? (int)hv_cdiv(B, a.slab_items) : 1;
+    if (a.slabs == 1) a.slab_items = B;
+    a.partial = workspace;
+    const dim3 grid((unsigned)hv_cdiv((int64_t)L * K, 4), (unsigned)a.slabs);
+    if (K % 4 == 0) hipLaunchKernelGGL(codebook_grad_kernel<true>, grid, dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(codebook_grad_kernel<false>, grid, dim3(WG_THREADS), 0, (hipStream_t)stream, a);
     HV_LAUNCH_CHECK("codebook_grad");
+    if (a.slabs > 1) {
+        hipLaunchKernelGGL(codebook_grad_final_kernel, dim3(grid.x), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+        HV_LAUNCH_CHECK("codebook_grad_final");
+    }
     return HIDVAE_OK;
 }
 

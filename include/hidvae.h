@@ -149,10 +149,13 @@ int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_
                        int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows, void *stream);
 
 /* gE[i][k][:] (+)= sum_{b: ids[b,i]==k} dE_rows[b, i*32:(i+1)*32], pushed through the row-normalise
- * Jacobian for levels with normalize[i] (E_host: raw tables, needed for |E_k|).  gE_host: L device ptrs. */
+ * Jacobian for levels with normalize[i] (E_host: raw tables, needed for |E_k|).  gE_host: L device ptrs.
+ * Summation order: items ascending (two interleaved chains per code).  workspace (optional, L*K*ceil(B/2048)*32 floats): batches
+ * above 2048 items are summed in slabs of 2048 items and the slabs added in ascending order (a second launch) -- the longest
+ * code's chain no longer sets the time; identical results for B <= 2048, a different fixed order above. */
 int hidvae_codebook_grad(const int64_t *ids, const float *dE_rows, int64_t B, int L, int64_t K,
                          const float *const *E_host, const float *cb_eff, const int32_t *normalize_host,
-                         float *const *gE_host, int accumulate, void *stream);
+                         float *const *gE_host, int accumulate, float *workspace, void *stream);
 
 /* ---- a3/a14: decoder tail.  x_hat = y / max(|y|,1e-12) (encoder.py:32), recon[b] = sum (x_hat-x)^2
  * (loss.py:11-12) and, if g_y != NULL, g_y = d(sum_b gscale_b * recon[b]) / dy with gscale_b = gscale *

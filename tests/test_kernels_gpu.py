@@ -132,7 +132,7 @@ def test_rq_forward_on_reference_goldens(C, name):
 
 
 @pytest.mark.parametrize("mode", [3, 2])
-@pytest.mark.parametrize("B,L,K,norm", [(50, 3, 256, True), (200, 4, 64, False), (17, 1, 16, True)])
+@pytest.mark.parametrize("B,L,K,norm", [(50, 3, 256, True), (200, 4, 64, False), (17, 1, 16, True), (5000, 3, 256, True), (4100, 2, 6, False)])
 def test_rq_backward_vs_autograd(C, mode, B, L, K, norm):
     y, tables = _rq_inputs(B, L, K, 31)
     g_cat = fill.uniform((B, L * 32), 32, -1, 1)
