@@ -2,7 +2,6 @@
 the reference's constructor arguments and the attributes train_hidvae.py pokes (loss.py:96-102 knobs)."""
 from torch import nn
 
-from .. import _C
 from ..ops import ReconFn
 
 

@@ -5,7 +5,6 @@ corpus ids and answers prefix-existence queries for constrained decoding.
 Differences in HOW (not what): the corpus is encoded in large resident chunks through the fused encode + RQ kernels
 instead of 512-item DataLoader batches, and `exists_prefix` is a sorted-key binary search (one sort per prefix length,
 cached) instead of a [queries, corpus, L] broadcast compare."""
-import math
 from typing import Dict, List, Optional, Tuple
 
 import torch
