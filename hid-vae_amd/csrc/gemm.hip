@@ -315,7 +315,13 @@ __global__ __launch_bounds__(1024) void colsum_one_kernel(const float *X, int64_
     const int64_t n = (int64_t)blockIdx.x * 32 + c;
     float s = 0.0f;
     if (n < N)
-        for (int64_t m = rg; m < M; m += 32) s += X[m * ldx + n];
+        for (int64_t m0 = rg; m0 < M; m0 += 8 * 32) {  // eight independent loads in flight, added in the same ascending order
+            float v[8];                                 // (rows past the end contribute +0.0f: s is unchanged by them)
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = m0 + 32 * j < M ? X[(m0 + 32 * j) * ldx + n] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) s += v[j];
+        }
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0 && n < N) {
@@ -586,7 +592,13 @@ __device__ __forceinline__ void colsum32_body(const PairArgs &p, int64_t c0, flo
     const int64_t c = c0 + col;
     float acc = 0.0f;
     if (c < p.cs_cols)
-        for (int64_t r = rg; r < p.cs_rows; r += nrg) acc += p.cs_x[r * p.cs_ld + c];
+        for (int64_t r0 = rg; r0 < p.cs_rows; r0 += 8 * (int64_t)nrg) {  // eight loads in flight, same ascending order of additions
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = r0 + (int64_t)nrg * j < p.cs_rows ? p.cs_x[(r0 + (int64_t)nrg * j) * p.cs_ld + c] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += v[j];
+        }
     part[rg * 32 + col] = acc;
     __syncthreads();
     if (threadIdx.x < 32 && c < p.cs_cols) {
