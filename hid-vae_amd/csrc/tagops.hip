@@ -270,7 +270,17 @@ __global__ __launch_bounds__(1024) void layernorm_param_final_kernel(const float
     const int64_t n = (int64_t)blockIdx.x * 32 + c;
     float a = 0.0f, b = 0.0f;
     if (n < N)
-        for (int64_t k = q; k < chunks; k += 32) { a += part[(k * 2 + 0) * N + n]; b += part[(k * 2 + 1) * N + n]; }
+        for (int64_t k0 = q; k0 < chunks; k0 += 8 * 32) {  // eight chunks' loads in flight, added in the same ascending order
+            float va[8], vb[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int64_t k = k0 + 32 * j;
+                va[j] = k < chunks ? part[(k * 2 + 0) * N + n] : 0.0f;
+                vb[j] = k < chunks ? part[(k * 2 + 1) * N + n] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) { a += va[j]; b += vb[j]; }
+        }
     red[0][q][c] = a;
     red[1][q][c] = b;
     __syncthreads();
@@ -453,7 +463,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *x, int64_t l
         float mu, rs;
         if (training) {
             float na = 0.0f, ma = 0.0f, qa = 0.0f;
-            for (int64_t k = 0; k < chunks; k++) chan_merge(na, ma, qa, part[(k * 3 + 0) * N + n], part[(k * 3 + 1) * N + n], part[(k * 3 + 2) * N + n]);
+            for (int64_t k0 = 0; k0 < chunks; k0 += 8) {  // eight chunks' loads in flight, merged in the same ascending order
+                float pn[8], pm[8], pq[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int64_t k = k0 + j < chunks ? k0 + j : chunks - 1;
+                    pn[j] = part[(k * 3 + 0) * N + n]; pm[j] = part[(k * 3 + 1) * N + n]; pq[j] = part[(k * 3 + 2) * N + n];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (k0 + j < chunks) chan_merge(na, ma, qa, pn[j], pm[j], pq[j]);
+            }
             const float var = qa / (float)M;
             mu = ma;
             rs = 1.0f / sqrtf(var + eps);
@@ -533,7 +553,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *gy, cons
     const int64_t n = (int64_t)blockIdx.x * 64 + c;
     if (rl == 0 && n < N) {
         float a = 0.0f, b = 0.0f;
-        for (int64_t k = 0; k < chunks; k++) { a += part[(k * 2 + 0) * N + n]; b += part[(k * 2 + 1) * N + n]; }
+        for (int64_t k0 = 0; k0 < chunks; k0 += 8) {  // eight chunks' loads in flight, added in the same ascending order
+            float va[8], vb[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                va[j] = k0 + j < chunks ? part[((k0 + j) * 2 + 0) * N + n] : 0.0f;
+                vb[j] = k0 + j < chunks ? part[((k0 + j) * 2 + 1) * N + n] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) { a += va[j]; b += vb[j]; }
+        }
         s_g[c] = a;
         s_b[c] = b;
         if (blockIdx.y == 0) {
