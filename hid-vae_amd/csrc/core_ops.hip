@@ -156,16 +156,29 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     float *p = a.p[t], *m = a.m[t], *v = a.v[t];
     const float *g = a.g[blockIdx.y];
     const float w1 = 1.0f - a.beta1, w2 = 1.0f - a.beta2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i] * a.grad_scale;
-        float pi = p[i] * decay;
-        const float mi = m[i] + (gi - m[i]) * w1;  // lerp
-        const float vi = v[i] * a.beta2 + (gi * gi) * w2;
-        const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
-        pi = pi - step_size * (mi / denom);
-        p[i] = pi;
-        m[i] = mi;
-        v[i] = vi;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {  // 16 independent loads in flight
+        float gv[4], pv[4], mv[4], vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int64_t i = i0 + j * stride;
+            const bool ok = i < n;
+            gv[j] = ok ? g[i] : 0.0f; pv[j] = ok ? p[i] : 0.0f; mv[j] = ok ? m[i] : 0.0f; vv[j] = ok ? v[i] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int64_t i = i0 + j * stride;
+            if (i >= n) break;
+            const float gi = gv[j] * a.grad_scale;
+            float pi = pv[j] * decay;
+            const float mi = mv[j] + (gi - mv[j]) * w1;  // lerp
+            const float vi = vv[j] * a.beta2 + (gi * gi) * w2;
+            const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+            pi = pi - step_size * (mi / denom);
+            p[i] = pi;
+            m[i] = mi;
+            v[i] = vi;
+        }
     }
 }
 
@@ -418,7 +431,17 @@ __device__ __forceinline__ void total_loss_body(const TotalArgs &a) {
     __shared__ float uq;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float r = 0.0f, q = 0.0f;
-    for (int64_t i = tid; i < a.B; i += 256) { r += a.recon[i]; q += a.qloss[i]; }
+    for (int64_t i0 = tid; i0 < a.B; i0 += 8 * 256) {  // sixteen loads in flight, added in the same ascending order
+        float rv[8], qv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int64_t i = i0 + 256 * j;
+            rv[j] = i < a.B ? a.recon[i] : 0.0f;
+            qv[j] = i < a.B ? a.qloss[i] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { r += rv[j]; q += qv[j]; }
+    }
     r = hv_wave_sum(r);
     q = hv_wave_sum(q);
     if (lane == 0) { red[0][wave] = r; red[1][wave] = q; }
