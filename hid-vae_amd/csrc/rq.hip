@@ -941,19 +941,31 @@ __device__ __forceinline__ void bneck_layer(const float *W, int N, int K, const 
         const float *w0 = W + (int64_t)(16 * t0 + i16) * K + 4 * q;
         const float *w1 = W + (int64_t)(16 * (two ? t1 : t0) + i16) * K + 4 * q;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (two) {
 #pragma unroll 4
-        for (int kb = 0; kb < nkb; kb++) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(w0 + 16 * kb);
-            const float4 a1 = *reinterpret_cast<const float4 *>(w1 + 16 * kb);
-            const float4 b = Hin[kb * 64 + lane];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0);
+            for (int kb = 0; kb < nkb; kb++) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(w0 + 16 * kb);
+                const float4 a1 = *reinterpret_cast<const float4 *>(w1 + 16 * kb);
+                const float4 b = Hin[kb * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0);
+            }
+        } else {  // one tile for this wave (layers of <= NWAVES tiles): no second chain to keep the matrix pipe busy for nothing
+#pragma unroll 8
+            for (int kb = 0; kb < nkb; kb++) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(w0 + 16 * kb);
+                const float4 b = Hin[kb * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int which = 0; which < 2; which++) {
