@@ -27,8 +27,13 @@ constexpr int ITEMS_PER_WG = 64;
 constexpr int MAX_KC = 1024;  // codes staged in LDS at a time (32*(1024+2)+1024 floats = 135.3 KB)
 
 __device__ __forceinline__ float sumQ(float p) {
-    float s = p + __shfl_xor(p, 16);
-    return s + __shfl_xor(s, 32);
+    // (p0+p1)+(p2+p3) over the item's four quarter-lanes.  v_permlane16_swap / v_permlane32_swap (gfx950) hand both partners' values to
+    // both lanes, so each step is one vector-ALU exchange + one add instead of a ds_bpermute round trip through the LDS crossbar
+    // (~120 cycles each, two per reduction, six reductions per level): same sums bit for bit (a+b on one lane, b+a on the other).
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float dotQ(const float (&a)[8], const float (&b)[8]) {
     float s = 0.0f;
