@@ -35,6 +35,15 @@ __device__ __forceinline__ float sumQ(float p) {
     const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// the value of lane ^ 16 / lane ^ 32 (one vector-ALU exchange + a select; see sumQ)
+__device__ __forceinline__ unsigned xchg16(unsigned v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (threadIdx.x & 16) ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned xchg32(unsigned v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (threadIdx.x & 32) ? r[0] : r[1];
+}
 __device__ __forceinline__ float dotQ(const float (&a)[8], const float (&b)[8]) {
     float s = 0.0f;
 #pragma unroll
@@ -234,10 +243,12 @@ __device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, floa
             }
         }
         // combine the 4 quarter-lanes of the item; equal distances resolve to the lowest code index
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            const float ob = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bidx, o);
+        {
+            float ob = __uint_as_float(xchg16(__float_as_uint(best)));
+            int oi = (int)xchg16((unsigned)bidx);
+            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            ob = __uint_as_float(xchg32(__float_as_uint(best)));
+            oi = (int)xchg32((unsigned)bidx);
             if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
         }
         if (CSPLIT) {  // merge the four code quarters (double-buffered by level parity: one barrier per level)
@@ -282,12 +293,13 @@ __device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, floa
             // holds float4 number 2q and 2q+1, so the running sum walks q = 0, 1, 2, 3
             const float ta = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
             const float tb = (o[4] * o[4] + o[5] * o[5]) + (o[6] * o[6] + o[7] * o[7]);
-            float sn = ta + tb;
-#pragma unroll
-            for (int step = 1; step < 4; step++) {
-                const float prev = __shfl(sn, (threadIdx.x - 16) & 63);
-                if (q == step) sn = (prev + ta) + tb;
-            }
+            float sn = ta + tb;                                                   // q = 0: t0 + t1
+            float prev = __uint_as_float(xchg16(__float_as_uint(sn)));            // q = 1 <- q = 0
+            if (q == 1) sn = (prev + ta) + tb;
+            prev = __uint_as_float(xchg16(xchg32(__float_as_uint(sn))));          // q = 2 <- q = 3 <- q = 1
+            if (q == 2) sn = (prev + ta) + tb;
+            prev = __uint_as_float(xchg16(__float_as_uint(sn)));                  // q = 3 <- q = 2
+            if (q == 3) sn = (prev + ta) + tb;
             if (valid && q == 3) a.embs_norm[item * a.L + i] = sqrtf(sn);
         }
 #pragma unroll
