@@ -167,15 +167,25 @@ __device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl
     const int LDK = a.KC + 2;
     float *ccs = Cs + 32 * LDK;
     const float *src = a.cb_eff + (int64_t)lvl * a.K * D;
-    for (int idx = threadIdx.x; idx < a.KC * 8; idx += blockDim.x) {
-        const int kl = idx >> 3, d4 = idx & 7;
-        const int64_t k = (int64_t)c0 + kl;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < a.K) v = *reinterpret_cast<const float4 *>(src + k * D + 4 * d4);
-        Cs[(4 * d4 + 0) * LDK + kl] = v.x;
-        Cs[(4 * d4 + 1) * LDK + kl] = v.y;
-        Cs[(4 * d4 + 2) * LDK + kl] = v.z;
-        Cs[(4 * d4 + 3) * LDK + kl] = v.w;
+    for (int idx0 = threadIdx.x; idx0 < a.KC * 8; idx0 += 4 * blockDim.x) {  // four loads in flight per thread, then their LDS writes
+        float4 v[4];                                                           // (one load per loop trip paid the L2 latency each time)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int idx = idx0 + j * blockDim.x;
+            const int64_t k = (int64_t)c0 + (idx >> 3);
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < a.KC * 8 && k < a.K) v[j] = *reinterpret_cast<const float4 *>(src + k * D + 4 * (idx & 7));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int idx = idx0 + j * blockDim.x;
+            if (idx >= a.KC * 8) break;
+            const int kl = idx >> 3, d4 = idx & 7;
+            Cs[(4 * d4 + 0) * LDK + kl] = v[j].x;
+            Cs[(4 * d4 + 1) * LDK + kl] = v[j].y;
+            Cs[(4 * d4 + 2) * LDK + kl] = v[j].z;
+            Cs[(4 * d4 + 3) * LDK + kl] = v[j].w;
+        }
     }
     for (int kl = threadIdx.x; kl < a.KC; kl += blockDim.x) {
         const int64_t k = (int64_t)c0 + kl;
@@ -1021,10 +1031,19 @@ __global__ __launch_bounds__(64 * BN_WAVES) void bottleneck_fwd_kernel(BneckArgs
     const bool in_range = item < a.B;
     const int64_t src = in_range ? item : a.B - 1;
     // the items' input rows as k-block images (all four waves need all of them)
-    for (int idx = threadIdx.x; idx < (b.K2 / 16) * 64; idx += 64 * BN_WAVES) {
-        const int kb = idx >> 6, l = idx & 63;
-        const int64_t row = (int64_t)blockIdx.x * ITEMS_PER_WAVE + (l & 15);
-        HA[idx] = *reinterpret_cast<const float4 *>(b.h1 + (row < a.B ? row : a.B - 1) * b.K2 + 16 * kb + 4 * (l >> 4));
+    for (int idx0 = threadIdx.x; idx0 < (b.K2 / 16) * 64; idx0 += 2 * 64 * BN_WAVES) {  // (two loads in flight per thread)
+        float4 v[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int idx = idx0 + j * 64 * BN_WAVES;
+            const int kb = idx >> 6, l = idx & 63;
+            const int64_t row = (int64_t)blockIdx.x * ITEMS_PER_WAVE + (l & 15);
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < (b.K2 / 16) * 64) v[j] = *reinterpret_cast<const float4 *>(b.h1 + (row < a.B ? row : a.B - 1) * b.K2 + 16 * kb + 4 * (l >> 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (idx0 + j * 64 * BN_WAVES < (b.K2 / 16) * 64) HA[idx0 + j * 64 * BN_WAVES] = v[j];
     }
     for (int i = 0; i < a.L; i++) stage_codes(lds + i * lvl_floats, a, i, 0);
     __syncthreads();
