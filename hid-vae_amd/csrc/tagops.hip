@@ -591,6 +591,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *gy, cons
 // InfoNCE rows (loss.py:70-77): S = cn tn^T already in `S` [B,B]; per row b: loss_b = logsumexp_j(S_bj/tau) - S_bb/tau,
 // and S is overwritten with the softmax P (the backward needs it).  row_loss [B].
 // ------------------------------------------------------------------------------------------------
+// B <= 64 * NV: the row lives in registers (one pass over memory, one expf per element; the generic kernel below reads the row three
+// times and takes the exponential twice, each of its loops paying the load latency per trip).  Same operations in the same order.
+template <int NV>
+__global__ __launch_bounds__(256) void infonce_rows_resident_kernel(float *S, int64_t B, float inv_tau, float *row_loss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float *s = S + row * B;
+    float v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NV; t++) {
+        const int64_t j = lane + 64 * t;
+        v[t] = j < B ? s[j] * inv_tau : -INFINITY;
+    }
+#pragma unroll
+    for (int t = 0; t < NV; t++)
+        if (lane + 64 * t < B) mx = fmaxf(mx, v[t]);
+    mx = hv_wave_max(mx);
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NV; t++)
+        if (lane + 64 * t < B) { v[t] = expf(v[t] - mx); sum += v[t]; }
+    sum = hv_wave_sum(sum);
+    const float lse = mx + logf(sum);
+    const float diag = s[row] * inv_tau;
+#pragma unroll
+    for (int t = 0; t < NV; t++)
+        if (lane + 64 * t < B) s[lane + 64 * t] = v[t] / sum;
+    if (lane == 0) row_loss[row] = lse - diag;
+}
+
 __global__ __launch_bounds__(256) void infonce_rows_kernel(float *S, int64_t B, float inv_tau, float *row_loss) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -973,7 +1005,10 @@ extern "C" int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx
 extern "C" int hidvae_infonce_rows(float *S, int64_t B, float tau, float scale, float *row_loss, float *loss, void *stream) {
     HV_REQUIRE(S && row_loss && loss && B >= 1 && tau > 0.0f, "infonce_rows: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(infonce_rows_kernel, dim3((unsigned)hv_cdiv(B, 4)), dim3(256), 0, s, S, B, 1.0f / tau, row_loss);
+    const dim3 grid((unsigned)hv_cdiv(B, 4));
+    if (B <= 1024) hipLaunchKernelGGL((infonce_rows_resident_kernel<16>), grid, dim3(256), 0, s, S, B, 1.0f / tau, row_loss);
+    else if (B <= 2048) hipLaunchKernelGGL((infonce_rows_resident_kernel<32>), grid, dim3(256), 0, s, S, B, 1.0f / tau, row_loss);
+    else hipLaunchKernelGGL(infonce_rows_kernel, grid, dim3(256), 0, s, S, B, 1.0f / tau, row_loss);
     HV_LAUNCH_CHECK("infonce_rows");
     hipLaunchKernelGGL(vec_mean_kernel, dim3(1), dim3(256), 0, s, row_loss, B, scale, loss);
     HV_LAUNCH_CHECK("infonce mean");
