@@ -66,7 +66,14 @@ _SIGNATURES = {
     "hidvae_codebook_prepare_adamw": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
+    "hidvae_query_workspace": [_i, _vp, _i, _vp],
+    "hidvae_sqdiff_rows": [_vp, _i64, _vp, _i64, _i64, _i64, _f, _vp, _vp],
+    "hidvae_sqdiff_rows_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _f, _f, _vp, _vp, _vp],
+    "hidvae_gumbel_noise": [_vp, _i64, _f, _vp, _vp],
+    "hidvae_gumbel_softmax_rows": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
 }
+WS_GEMM, WS_LINEAR_BWD, WS_COLSUM, WS_CODEBOOK_GRAD, WS_LAYERNORM_PARAM_GRAD, WS_LAYERNORM_BWD_ALL = 1, 2, 3, 4, 5, 6
+WS_BATCHNORM_FWD, WS_BATCHNORM_BWD, WS_ID_CENSUS, WS_KMEANS, WS_TAG_LOSS = 7, 8, 9, 10, 11
 
 
 def lib():
@@ -130,6 +137,26 @@ def _vec_stride(t):
     return t.stride(0)
 
 
+def workspace_bytes(op, *dims):
+    """hidvae_query_workspace: bytes the `workspace` argument of entry point `op` needs at these dimensions (host-only call)"""
+    arr = (ctypes.c_int64 * len(dims))(*[int(d) for d in dims])
+    out = ctypes.c_int64(0)
+    _check(lib().hidvae_query_workspace(int(op), arr, len(dims), ctypes.byref(out)), "hidvae_query_workspace")
+    return int(out.value)
+
+
+def _ws(op, device, *dims):
+    """fp32 workspace tensor of the size the library asks for (None when it needs none)"""
+    n = workspace_bytes(op, *dims)
+    return torch.empty((n // 4,), device=device, dtype=torch.float32) if n else None
+
+
+def census_scratch(B, device):
+    """A fresh, zero-filled id-census table for batches of B items (hidvae_id_stats / hidvae_bottleneck_fwd).  The CALLER owns it:
+    its address is baked into any HIP graph that captured a launch using it, so it must live as long as that graph does."""
+    return torch.zeros((workspace_bytes(WS_ID_CENSUS, B) // 8,), device=device, dtype=torch.int64)
+
+
 def _host_ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
@@ -153,11 +180,7 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
         raise RuntimeError(f"gemm: inner dimensions differ ({K} vs {K2})")  # the reference's shape assert (encoder.py:35)
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=torch.float32)
-    ws = None
-    if split_k > 1 and ((M + 31) // 32) * ((N + 31) // 32) >= 2048:  # only the LDS-tiled (large-batch) path uses slabs
-        ws = torch.empty((split_k * M * N,), device=A.device, dtype=torch.float32)
-    elif split_k == 0 and K >= 4096:  # deep-K problems (weight gradients at large batch) may be cut into up to 16 slabs
-        ws = torch.empty((16 * M * N,), device=A.device, dtype=torch.float32)
+    ws = _ws(WS_GEMM, A.device, M, N, K, split_k)  # slabs of the LDS-tiled (large-batch) path / deep-K weight gradients
     ldaux = _row_stride(aux, "aux") if aux is not None else 0
     ldmask = _row_stride(mask, "mask") if mask is not None else 0
     _check(lib().hidvae_gemm_f32(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(out), _row_stride(out, "C"),
@@ -179,15 +202,10 @@ def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accu
     elif tuple(dW.shape) != (n_out, n_in) or not dW.is_contiguous():
         raise RuntimeError(f"linear_bwd: dW slot has shape {tuple(dW.shape)}, expected {(n_out, n_in)} contiguous")
     dX = torch.empty((B, n_in), device=g.device, dtype=torch.float32) if need_dx else None
-    ws_floats = 0
-    if bias:
-        if db is None:
-            db = torch.empty((n_out,), device=g.device, dtype=torch.float32)
-            accumulate_db = False
-        ws_floats = (B + 63) // 64 * n_out
-    if B >= 4096:  # the unpaired dW product may be cut into up to 16 K-slabs
-        ws_floats = max(ws_floats, 16 * n_out * n_in)
-    ws = torch.empty((ws_floats,), device=g.device, dtype=torch.float32) if ws_floats else None
+    if bias and db is None:
+        db = torch.empty((n_out,), device=g.device, dtype=torch.float32)
+        accumulate_db = False
+    ws = _ws(WS_LINEAR_BWD, g.device, B, n_out, n_in, int(bool(bias)))
     _check(lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
                                    _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, int(bool(accumulate)), _p(dX), n_in,
                                    int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, _p(db if bias else None),
@@ -202,7 +220,7 @@ def colsum(X, out=None, accumulate=False):
     M, N = X.shape
     if out is None:
         out = torch.empty((N,), device=X.device, dtype=torch.float32)
-    ws = torch.empty(((M + 63) // 64 * N,), device=X.device, dtype=torch.float32)
+    ws = _ws(WS_COLSUM, X.device, M, N)
     _check(lib().hidvae_colsum(_p(X), M, N, _row_stride(X, "X"), _p(out), int(accumulate), _p(ws), _stream()), "hidvae_colsum")
     return out
 
@@ -278,16 +296,14 @@ def bottleneck_eligible(B, K2, N2, Nd0, Nd1, L, K):
             and lds <= 160 * 1024 - 1024)
 
 
-_CENSUS_SCRATCH = {}
-
-
 def census_eligible(L, K):
     """can the fused middle launch carry the id census (10 bits per level in a 40-bit slot field)?"""
     return L <= 4 and K <= 1024
 
 
-def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1, id_stats=False):
-    """-> dict of every tensor the launch writes (see include/hidvae.h); id_stats: also embs_norm [B,L] and p_unique"""
+def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1, id_stats=False, scratch=None):
+    """-> dict of every tensor the launch writes (see include/hidvae.h); id_stats: also embs_norm [B,L] and p_unique, through the
+    caller-owned census table `scratch` (census_scratch(B, device))"""
     _f32(h1, "h1")
     B, K2 = h1.shape
     N2, Nd0, Nd1 = W2.shape[0], Wd0.shape[0], Wd1.shape[0]
@@ -304,19 +320,15 @@ def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1
     if id_stats:
         if not census_eligible(L, K):
             raise RuntimeError(f"bottleneck_fwd: the fused id census needs L <= 4 and K <= 1024 (got {L}, {K})")
-        key = (dev.index, B)
-        scratch = _CENSUS_SCRATCH.get(key)
-        if scratch is None:  # zero-filled once; the kernel keeps it consistent between calls (include/hidvae.h)
-            if len(_CENSUS_SCRATCH) > 64:
-                _CENSUS_SCRATCH.clear()
-            scratch = _CENSUS_SCRATCH[key] = torch.zeros((4 * B + 3,), device=dev, dtype=torch.int64)
+        if scratch is None or scratch.numel() * 8 != workspace_bytes(WS_ID_CENSUS, B) or scratch.dtype != torch.int64:
+            raise RuntimeError("bottleneck_fwd: id_stats needs the caller's census table for this batch size (_C.census_scratch(B, device))")
         o["embs_norm"] = f(B, L)
         o["p_unique"] = torch.empty((), device=dev, dtype=torch.float32)
     _check(lib().hidvae_bottleneck_fwd(_p(h1), B, K2, N2, _p(W2), _p(W3), _p(o["pre2"]), _p(o["h2"]), _p(o["y"]), int(bool(normalize_input)),
                                        _p(cb_eff), _p(cc), L, K, int(mode), float(beta), _p(o["z"]), _p(o["ids"]), _p(o["emb_cat"]),
                                        L * EMBED_DIM, _p(o["emb_sum"]), _p(o["qloss"]), Nd0, Nd1, _p(Wd0), _p(Wd1), _p(o["pre_d0"]),
                                        _p(o["d0"]), _p(o["pre_d1"]), _p(o["d1"]), _p(o.get("embs_norm")), _p(o.get("p_unique")),
-                                       _p(scratch), _stream()), "hidvae_bottleneck_fwd")
+                                       _p(scratch if id_stats else None), _stream()), "hidvae_bottleneck_fwd")
     return o
 
 
@@ -339,7 +351,7 @@ def codebook_grad(ids, dE_rows, tables, cb_eff, normalize_flags, grads=None, acc
     if grads is None:
         grads = [torch.empty_like(t) for t in tables]
     flags = (ctypes.c_int32 * L)(*[int(bool(f)) for f in normalize_flags])
-    ws = torch.empty((L * K * ((B + 2047) // 2048) * EMBED_DIM,), device=ids.device, dtype=torch.float32) if B > 2048 else None
+    ws = _ws(WS_CODEBOOK_GRAD, ids.device, B, L, K)
     _check(lib().hidvae_codebook_grad(_p(ids), _p(dE_rows), B, L, K, _host_ptr_array(tables), _p(cb_eff), flags,
                                       _host_ptr_array(grads), int(accumulate), _p(ws), _stream()), "hidvae_codebook_grad")
     return grads
@@ -381,18 +393,14 @@ def l2norm_bwd(g, out, norms, eps=1e-12, gx=None, accumulate=False):
     return gx
 
 
-_ID_SCRATCH = {}
-
-
-def id_stats(emb_cat, ids, want_norms=True):
+def id_stats(emb_cat, ids, want_norms=True, scratch=None):
+    """scratch: the caller's census table for this batch size (census_scratch(B, device)); None allocates a fresh one for this call"""
     B, L = ids.shape
     dev = ids.device
-    key = (dev.index, B)
-    scratch = _ID_SCRATCH.get(key)
-    if scratch is None:  # zero-filled once; the kernel keeps it consistent between calls (include/hidvae.h)
-        if len(_ID_SCRATCH) > 64:
-            _ID_SCRATCH.clear()
-        scratch = _ID_SCRATCH[key] = torch.zeros((4 * B + 3,), device=dev, dtype=torch.int64)
+    if scratch is None:
+        scratch = census_scratch(B, dev)
+    elif scratch.numel() * 8 != workspace_bytes(WS_ID_CENSUS, B) or scratch.dtype != torch.int64:
+        raise RuntimeError("id_stats: the census table does not match this batch size")
     norms = torch.empty((B, L), device=dev, dtype=torch.float32) if want_norms else None
     pu = torch.empty((), device=dev, dtype=torch.float32)
     ld = _row_stride(emb_cat, "emb_cat") if emb_cat is not None else 0
@@ -529,7 +537,7 @@ def layernorm_param_grad(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale)
     M, N = x.shape
     gg = torch.empty((N,), device=x.device, dtype=torch.float32)
     gb = torch.empty((N,), device=x.device, dtype=torch.float32)
-    ws = torch.empty((2 * ((M + 127) // 128) * N,), device=x.device, dtype=torch.float32)
+    ws = _ws(WS_LAYERNORM_PARAM_GRAD, x.device, M, N)
     _check(lib().hidvae_layernorm_param_grad(_p(gy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), M, N, int(relu), _p(mask),
                                              float(mask_scale), _p(gg), _p(gb), 0, _p(ws), _stream()), "hidvae_layernorm_param_grad")
     return gg, gb
@@ -543,7 +551,7 @@ def layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, ne
         gg = torch.empty((N,), device=x.device, dtype=torch.float32)
         gb = torch.empty((N,), device=x.device, dtype=torch.float32)
         accumulate = False
-    ws = torch.empty((2 * ((M + 3) // 4) * N,), device=x.device, dtype=torch.float32)
+    ws = _ws(WS_LAYERNORM_BWD_ALL, x.device, M, N)
     _check(lib().hidvae_layernorm_bwd_all(_p(gy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), M, N, int(relu), _p(mask),
                                           float(mask_scale), _p(gx), _p(gg), _p(gb), int(bool(accumulate)), _p(ws), _stream()),
            "hidvae_layernorm_bwd_all")
@@ -555,7 +563,7 @@ def batchnorm_fwd(x, gamma, beta, eps, momentum, training, running_mean, running
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
     sm = torch.empty((N,), device=x.device, dtype=torch.float32) if training else None
     sr = torch.empty((N,), device=x.device, dtype=torch.float32) if training else None
-    ws = torch.empty((3 * ((M + 63) // 64) * N,), device=x.device, dtype=torch.float32) if training else None
+    ws = _ws(WS_BATCHNORM_FWD, x.device, M, N) if training else None
     _check(lib().hidvae_batchnorm_fwd(_p(x), _row_stride(x, "x"), M, N, _p(gamma), _p(beta), float(eps), float(momentum), int(training),
                                       _p(running_mean), _p(running_var), _p(num_batches), _p(y), _p(sm), _p(sr), int(relu), _p(mask),
                                       float(mask_scale), _p(ws), _stream()), "hidvae_batchnorm_fwd")
@@ -567,7 +575,7 @@ def batchnorm_bwd(gy, x, gamma, beta, save_mean, save_rstd, relu, mask, mask_sca
     gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if need_gx else None
     gg = torch.empty((N,), device=x.device, dtype=torch.float32)
     gb = torch.empty((N,), device=x.device, dtype=torch.float32)
-    ws = torch.empty((2 * ((M + 63) // 64) * N,), device=x.device, dtype=torch.float32)
+    ws = _ws(WS_BATCHNORM_BWD, x.device, M, N)
     _check(lib().hidvae_batchnorm_bwd(_p(gy), _p(x), _row_stride(x, "x"), _p(gamma), _p(beta), _p(save_mean), _p(save_rstd), M, N,
                                       int(relu), _p(mask), float(mask_scale), _p(gx), _p(gg), _p(gb), 0, _p(ws), _stream()), "hidvae_batchnorm_bwd")
     return gx, gg, gb
@@ -661,6 +669,47 @@ def gumbel_rows_bwd(P, gP, temperature):
 def gumbel_finish(g_x, x, emb, g_xx, g_l, beta, g_cb, cb, gS_colsum):
     _check(lib().hidvae_gumbel_finish(_p(g_x), _p(x), _p(emb), _p(g_xx), _p(g_l), _vec_stride(g_l), float(beta), x.shape[0], _p(g_cb), _p(cb),
                                       _p(gS_colsum), cb.shape[0], _stream()), "hidvae_gumbel_finish")
+
+
+# ------------------------------------------------------------------------------------------------ stand-alone loss / sampling modules
+def sqdiff_rows(a, b, extra=0.0):
+    """s = sum_j (a-b)^2 over the last dim; out[m] = s + extra*s (2-D views with a contiguous last dim)"""
+    _f32(a, "a"), _f32(b, "b")
+    if a.shape != b.shape:
+        raise RuntimeError(f"sqdiff_rows: shapes differ ({tuple(a.shape)} vs {tuple(b.shape)})")
+    M, N = a.shape
+    out = torch.empty((M,), device=a.device, dtype=torch.float32)
+    _check(lib().hidvae_sqdiff_rows(_p(a), _row_stride(a, "a"), _p(b), _row_stride(b, "b"), M, N, float(extra), _p(out), _stream()),
+           "hidvae_sqdiff_rows")
+    return out
+
+
+def sqdiff_rows_bwd(g, a, b, scale_a, scale_b, want_a=True, want_b=True):
+    M, N = a.shape
+    ga = torch.empty((M, N), device=a.device, dtype=torch.float32) if want_a else None
+    gb = torch.empty((M, N), device=a.device, dtype=torch.float32) if want_b else None
+    _check(lib().hidvae_sqdiff_rows_bwd(_p(g), _vec_stride(g), _p(a), _row_stride(a, "a"), _p(b), _row_stride(b, "b"), M, N, float(scale_a),
+                                        float(scale_b), _p(ga), _p(gb), _stream()), "hidvae_sqdiff_rows_bwd")
+    return ga, gb
+
+
+def gumbel_noise(U, eps=1e-20):
+    _f32(U, "U")
+    U = U.contiguous()
+    out = torch.empty_like(U)
+    _check(lib().hidvae_gumbel_noise(_p(U), U.numel(), float(eps), _p(out), _stream()), "hidvae_gumbel_noise")
+    return out
+
+
+def gumbel_softmax_rows(logits, U, temperature):
+    _f32(logits, "logits"), _f32(U, "U")
+    if logits.shape != U.shape or not logits.is_contiguous() or not U.is_contiguous():
+        raise RuntimeError("gumbel_softmax_rows: logits and U must be contiguous and of one shape")
+    K = logits.shape[-1]
+    out = torch.empty_like(logits)
+    _check(lib().hidvae_gumbel_softmax_rows(_p(logits), _p(U), logits.numel() // K, K, float(temperature), _p(out), _stream()),
+           "hidvae_gumbel_softmax_rows")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ jagged copy (stage-2 op)

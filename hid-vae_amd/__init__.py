@@ -7,23 +7,54 @@ import sys
 
 from . import _C  # noqa: F401
 
+# reference module name -> mirror module in this package.  Only LEAF modules are replaced: the reference's own parent packages
+# (`modules`, `data`, `init`, `ops`, ...) stay what they are, so everything that is not mirrored (modules.utils, modules.model,
+# modules.transformer.*, data.tags_processed, ...) still resolves to the reference's files.
 _DROPIN = {
-    "modules": "modules", "modules.h_rqvae": "modules.h_rqvae", "modules.rqvae": "modules.rqvae", "modules.encoder": "modules.encoder",
+    "modules.h_rqvae": "modules.h_rqvae", "modules.rqvae": "modules.rqvae", "modules.encoder": "modules.encoder",
     "modules.quantize": "modules.quantize", "modules.loss": "modules.loss", "modules.normalize": "modules.normalize",
-    "modules.tokenizer": "modules.tokenizer", "modules.tokenizer.h_semids": "modules.tokenizer.h_semids",
-    "init": "init", "init.kmeans": "init.kmeans", "data.schemas": "data.schemas", "data.utils": "data.utils",
-    "ops": "ops_hip", "ops.triton": "ops_hip", "ops.triton.jagged": "ops_hip.jagged",  # (stage-2 imports padded_to_jagged_tensor)
+    "modules.tokenizer.h_semids": "modules.tokenizer.h_semids",
+    "init.kmeans": "init.kmeans", "data.schemas": "data.schemas", "data.utils": "data.utils",
+    "distributions.gumbel": "distributions.gumbel",
+    "ops.triton.jagged": "ops_hip.jagged",  # (stage-2 imports padded_to_jagged_tensor)
 }
+# parent package -> the mirror package that stands in for it when the reference tree is NOT importable (then nothing
+# un-mirrored could be resolved anyway)
+_PARENT_FALLBACK = {"modules": "modules", "modules.tokenizer": "modules.tokenizer", "init": "init", "data": "data",
+                    "distributions": "distributions", "ops": "ops_hip", "ops.triton": "ops_hip"}
+
+
+def _dropin_parent(name):
+    """the package object that `name` resolves to: the reference's own package when it is importable, else our mirror"""
+    if name in sys.modules:
+        return sys.modules[name]
+    try:
+        return importlib.import_module(name)
+    except ModuleNotFoundError:
+        pkg = importlib.import_module(f"hidvae_amd.{_PARENT_FALLBACK[name]}")
+        sys.modules[name] = pkg
+        if "." in name:
+            up, _, attr = name.rpartition(".")
+            setattr(_dropin_parent(up), attr, pkg)
+        return pkg
 
 
 def install_dropin(force=False):
-    """Alias the reference's module names (modules.h_rqvae, data.schemas, ...) to this package's mirrors in sys.modules, so
-    the reference's own scripts and gin files pick up the HIP implementation without edits.
-    `data` itself is left alone (its ingestion modules are not mirrored); only data.schemas / data.utils are aliased."""
-    for theirs, ours in _DROPIN.items():
+    """Make the reference's module names (modules.h_rqvae, modules.quantize, data.schemas, ...) resolve to this package's
+    mirrors, so the reference's own scripts and gin files pick up the HIP implementation without edits (INTEGRATION.md,
+    section A).  Call it BEFORE importing the reference's scripts.  Only the mirrored leaf modules are replaced (sys.modules entry
+    + attribute on the parent package); their parent packages remain the reference's, so `from modules.utils import parse_config`,
+    `modules.model`, `modules.transformer.*` keep working."""
+    for theirs in _DROPIN:
         if theirs in sys.modules and not force and not getattr(sys.modules[theirs], "__name__", "").startswith("hidvae_amd"):
             raise RuntimeError(f"{theirs} is already imported from elsewhere; call install_dropin() before importing the reference")
-        sys.modules[theirs] = importlib.import_module(f"hidvae_amd.{ours}")
+    for theirs, ours in _DROPIN.items():
+        mirror = importlib.import_module(f"hidvae_amd.{ours}")
+        up, _, attr = theirs.rpartition(".")
+        parent = _dropin_parent(up)
+        sys.modules[theirs] = mirror
+        if parent is not mirror:
+            setattr(parent, attr, mirror)
     return sorted(_DROPIN)
 
 

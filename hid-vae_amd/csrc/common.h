@@ -66,13 +66,14 @@ struct HvAdamPrepare {
     float *hyper;
 };
 __device__ __forceinline__ void hv_adamw_prepare(const HvAdamPrepare &a) {
-    const int64_t t1 = *a.step + 1;  // torch counts the step being taken from 1
+    const int64_t t1 = a.step[0] + 1;  // torch counts the step being taken from 1
+    const int64_t ts = t1 - 1 + a.step[1];  // scheduler steps taken so far: the optimizer's own + those of a run resumed without its state
     for (int t = threadIdx.x; t < a.n; t += blockDim.x) {
         double lr = (double)a.base_lr[t];
         if (a.T_max > 0)  // CosineAnnealingLR after (t1 - 1) scheduler steps, closed form
-            lr = (double)a.eta_min + (lr - (double)a.eta_min) * (1.0 + cos(M_PI * (double)(t1 - 1) / (double)a.T_max)) * 0.5;
+            lr = (double)a.eta_min + (lr - (double)a.eta_min) * (1.0 + cos(M_PI * (double)ts / (double)a.T_max)) * 0.5;
         else if (a.step_size > 0)  // StepLR after (t1 - 1) scheduler steps: base * gamma^floor((t1-1)/step_size)
-            lr = lr * pow((double)a.gamma, (double)((t1 - 1) / a.step_size));
+            lr = lr * pow((double)a.gamma, (double)(ts / a.step_size));
         const double bc1 = 1.0 - pow((double)a.beta1, (double)t1);
         const double bc2 = 1.0 - pow((double)a.beta2, (double)t1);
         a.hyper[3 * t + 0] = (float)(1.0 - lr * (double)a.wd[t]);
@@ -80,7 +81,7 @@ __device__ __forceinline__ void hv_adamw_prepare(const HvAdamPrepare &a) {
         a.hyper[3 * t + 2] = (float)sqrt(bc2);
     }
     __syncthreads();
-    if (threadIdx.x == 0) *a.step = t1;
+    if (threadIdx.x == 0) a.step[0] = t1;
 }
 
 __device__ __forceinline__ float hv_wave_sum(float v) {

@@ -1,0 +1,1 @@
+"""Mirror of the reference's distributions/ package (distributions/gumbel.py)."""

@@ -2,16 +2,24 @@
 the reference's constructor arguments and the attributes train_hidvae.py pokes (loss.py:96-102 knobs)."""
 from torch import nn
 
-from ..ops import ReconFn
+from ..ops import ReconFn, SqDiffRowsFn
+
+
+def _rows(t):
+    """[..., N] -> a 2-D view [M, N] with a contiguous last dim (the row kernels take a row stride)"""
+    t = t.float()
+    t = t.reshape(-1, t.shape[-1])
+    return t if t.stride(-1) == 1 else t.contiguous()
 
 
 class ReconstructionLoss(nn.Module):
-    """sum_j (x_hat - x)^2 per item (reference loss.py:7-12).  `x_hat_pre` is the decoder output BEFORE its trailing
-    L2 normalisation when called through `fused`, which folds the normalisation into the same kernel."""
+    """sum_j (x_hat - x)^2 per item (reference loss.py:7-12): one launch forward, one backward (hidvae_sqdiff_rows[_bwd]).
+    HRqVae.forward itself uses `fused`, which takes the decoder output BEFORE its trailing L2 normalisation and folds the
+    normalisation into the same kernel."""
 
     def forward(self, x_hat, x):
-        raise NotImplementedError("ReconstructionLoss on an already-normalised x_hat is not on the hot path; "
-                                  "HRqVae.forward uses ReconstructionLoss.fused(decoder_body_out, x)")
+        out = SqDiffRowsFn.apply(_rows(x_hat), _rows(x), 1.0, 1.0, 0.0)
+        return out.reshape(x_hat.shape[:-1])
 
     @staticmethod
     def fused(decoder_body_out, x):
@@ -19,11 +27,17 @@ class ReconstructionLoss(nn.Module):
 
 
 class QuantizeLoss(nn.Module):
-    """|sg(q) - v|^2 + beta |q - sg(v)|^2 (reference loss.py:36-44); evaluated inside the fused RQ kernel."""
+    """|sg(q) - v|^2 + beta |q - sg(v)|^2 (reference loss.py:36-44).  Inside HRqVae the fused RQ kernel evaluates it; called on its
+    own it is one launch each way: both terms have the value s = sum_j (q-v)^2, the stop-gradients only route the gradient
+    (query gets beta * 2(q-v), value gets 2(v-q))."""
 
     def __init__(self, commitment_weight: float = 1.0):
         super().__init__()
         self.commitment_weight = commitment_weight
+
+    def forward(self, query, value):
+        cw = float(self.commitment_weight)
+        return SqDiffRowsFn.apply(_rows(query), _rows(value), cw, 1.0, cw).reshape(query.shape[:-1])
 
 
 class TagAlignmentLoss(nn.Module):

@@ -51,7 +51,8 @@ class RqVae(HRqVae):
         self.rand = None
 
     def load_pretrained(self, path: str) -> None:
-        state = torch.load(path, map_location=self.device, weights_only=False)
+        from ..checkpoint import load_checkpoint
+        state = load_checkpoint(path, map_location=self.device)
         self.load_state_dict(state["model"])
         print(f"---Loaded RQVAE Iter {state['iter']}---")
 

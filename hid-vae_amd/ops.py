@@ -163,20 +163,22 @@ class MLPBackFn(Function):
 class BottleneckFn(Function):
     """encoder[-2:] + all L quantisation levels + decoder[:2] in one launch (csrc/rq.hip bottleneck_fwd_kernel); the backward is
     the same sequence of launches as the unfused path (paired Linear backward x4, rq_backward, codebook_grad).
-    inputs : pre1 / h1 (the cut pair), W2, W3, Wd0, Wd1, config, prepared codebooks or None, the L raw tables
+    inputs : pre1 / h1 (the cut pair), W2, W3, Wd0, Wd1, config, prepared codebooks or None, `scratch` (a callable returning the
+             caller-owned id-census table for this batch size, or None = no census in this launch), the L raw tables
     outputs: z, ids, emb_cat, emb_sum (non-differentiable here: its gradient is produced inside), qloss, pre_d1 / d1 (cut pair),
              embs_norm, p_unique (the debug statistics of h_rqvae.py:643-648 when the launch can carry the id census, else None)"""
 
     @staticmethod
-    def forward(ctx, pre1, h1, W2, W3, Wd0, Wd1, normalize_input, mode, beta, normalize_flags, prepared, *tables):
+    def forward(ctx, pre1, h1, W2, W3, Wd0, Wd1, normalize_input, mode, beta, normalize_flags, prepared, scratch, *tables):
         ctx.set_materialize_grads(False)
         if prepared is not None:
             cb, cc = prepared
             join_side()
         else:
             cb, cc = _C.codebook_prepare([t.detach() for t in tables], normalize_flags)
-        census = _C.census_eligible(cb.shape[0], cb.shape[1]) and os.environ.get("HIDVAE_FUSED_CENSUS", "1") != "0"
-        o = _C.bottleneck_fwd(h1, W2.detach(), W3.detach(), cb, cc, normalize_input, mode, beta, Wd0.detach(), Wd1.detach(), id_stats=census)
+        census = scratch is not None and _C.census_eligible(cb.shape[0], cb.shape[1]) and os.environ.get("HIDVAE_FUSED_CENSUS", "1") != "0"
+        o = _C.bottleneck_fwd(h1, W2.detach(), W3.detach(), cb, cc, normalize_input, mode, beta, Wd0.detach(), Wd1.detach(), id_stats=census,
+                              scratch=scratch() if census else None)
         ctx.cfg = (normalize_input, mode, beta, tuple(normalize_flags))
         ctx.params = (W2, W3, Wd0, Wd1)
         ctx.tables = tables
@@ -221,7 +223,7 @@ class BottleneckFn(Function):
         gW2, g_pre1 = _C.linear_bwd(g_pre2, h1, W2, ctx.needs_input_grad[0], _C.EPI_DSILU, pre1, dW=dst, accumulate=acc)
         if dst is not None:
             gW2 = None
-        return (g_pre1, None, gW2, gW3, gWd0, gWd1, None, None, None, None, None) + tuple(gE)
+        return (g_pre1, None, gW2, gW3, gWd0, gWd1, None, None, None, None, None, None) + tuple(gE)
 
 
 class L2NormFn(Function):
@@ -390,6 +392,59 @@ class StepLossFn(Function):
         per_item = scal[0].expand(B)  # stride-0 view: the kernels downstream read one device scalar
         tags = (scal[1],) * n_tag + (scal[2],) * n_tag + (None,) * n_tag
         return (g_y, None, per_item, g_z, None, None, None, None, None, None, None, None) + tags
+
+
+class UniqLossFn(Function):
+    """SemanticIdUniquenessLoss.forward(sem_ids [n,m], encoded_features) with the reference's literal semantics (h_rqvae.py:41-105):
+    rows of the id matrix that agree everywhere are pushed apart.  Differentiable w.r.t. encoded_features: the gradient lands on
+    rows [0, n) -- the same rule hidvae_total_loss_bwd applies inside the fused step."""
+
+    @staticmethod
+    def forward(ctx, ids_t, z, weight, margin):
+        ctx.set_materialize_grads(False)
+        want = ctx.needs_input_grad[1]
+        m, n = ids_t.shape  # n id vectors of length m
+        if n > _C.MAX_LEVELS:
+            raise NotImplementedError(f"SemanticIdUniquenessLoss on the HIP path compares at most {_C.MAX_LEVELS} id vectors (got {n}): "
+                                      "HRqVae.forward calls it with one vector per LEVEL (the [L,B] ids of h_rqvae.py:630-631)")
+        if z.shape[0] < n:
+            raise IndexError(f"encoded_features has {z.shape[0]} rows, the id matrix {n}")  # the reference's encoded_features[b] would raise
+        if m < n:  # the kernel takes the id-vector length as the number of feature rows available: repeat the vectors' entries
+            ids_t = ids_t.repeat((n + m - 1) // m, 1).contiguous()  # (equality of whole vectors is unchanged)
+        loss, g_rows = _C.uniq_loss(ids_t, z.detach().contiguous(), weight, margin, want_grad=want)
+        ctx.shape = tuple(z.shape)
+        if want:
+            ctx.save_for_backward(g_rows)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None or not ctx.saved_tensors:
+            return None, None, None, None
+        (g_rows,) = ctx.saved_tensors
+        B, L = ctx.shape[0], g_rows.shape[0]
+        _, g_z = _C.total_loss_bwd(g.contiguous(), B, L, 0.0, 0.0, 1.0, g_rows, want_gz=True)  # g * g_rows on rows < L, 0 elsewhere
+        return None, g_z, None, None
+
+
+class SqDiffRowsFn(Function):
+    """out[m] = sum_j (a-b)^2 with independently scaled gradients for the two operands: ReconstructionLoss (scales 1, 1) and the
+    stop-gradient halves of QuantizeLoss (reference loss.py:7-12, 36-44)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale_a, scale_b, extra):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(a, b)
+        ctx.scales = (scale_a, scale_b)
+        return _C.sqdiff_rows(a, b, extra)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None, None
+        a, b = ctx.saved_tensors
+        ga, gb = _C.sqdiff_rows_bwd(g.contiguous(), a, b, ctx.scales[0], ctx.scales[1], ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return ga, gb, None, None, None
 
 
 class LinearFn(Function):

@@ -41,8 +41,8 @@ class HidvaeAdamW(torch.optim.Optimizer):
             for p in g["params"]:
                 if not p.requires_grad:
                     continue
-                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError("HidvaeAdamW needs contiguous float32 device parameters")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("HidvaeAdamW needs contiguous float32 parameters")  # (step() additionally needs them on the GPU)
                 ps.append(p)
                 lrs.append(g["lr"])
                 wds.append(g["weight_decay"])
@@ -67,7 +67,8 @@ class HidvaeAdamW(torch.optim.Optimizer):
                           v=i64(vptr), numel=i64([p.numel() for p in ps]), lr=torch.tensor(lrs, dtype=torch.float32, device=dev),
                           wd=torch.tensor(wds, dtype=torch.float32, device=dev), n=len(ps), max_numel=max(p.numel() for p in ps))
         self._zero = torch.zeros(max(p.numel() for p in ps), device=dev)  # stands in for parameters without a gradient
-        self.step_dev = torch.tensor([self._start_step], dtype=torch.int64, device=dev)
+        # int64[2]: {optimizer steps taken, scheduler steps taken before step 0} (include/hidvae.h, hidvae_adamw_prepare)
+        self.step_dev = torch.tensor([self._start_step, 0], dtype=torch.int64, device=dev)
         self._desc["hyper"] = torch.zeros(3 * len(ps), dtype=torch.float32, device=dev)
         self._prepared = False
 
@@ -108,6 +109,8 @@ class HidvaeAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         self.prepare()
+        if not self._params[0].is_cuda:
+            raise RuntimeError("HidvaeAdamW.step needs device parameters (the update is a HIP kernel; there is no CPU fallback)")
         from .ops import join_side
         if not self._prepared:
             self._prepare_step_async()
@@ -127,22 +130,129 @@ class HidvaeAdamW(torch.optim.Optimizer):
         _C.adamw_step(self._desc, self.betas[0], self.betas[1], self.eps, self.grad_scale)
         self._prepared = False
 
+    # ---- checkpoint interchange: the "optimizer" entry of a checkpoint is a genuine torch.optim.AdamW state_dict (reference
+    # train_hidvae.py:1166 writes optimizer.state_dict(), :625 feeds it to optimizer.load_state_dict) -----------------------------
+    def _slots(self):
+        """{id(param): (offset, numel)} into the flat moment buffers"""
+        out, off = {}, 0
+        for p in self._params:
+            out[id(p)] = (off, p.numel())
+            off += p.numel()
+        return out
+
+    def state_dict(self):
+        """torch.optim.AdamW.state_dict() layout: state[i] = {step, exp_avg, exp_avg_sq} per parameter (indexed over the groups in
+        order), param_groups with torch's own hyper-parameter keys; `lr` is the CURRENT scheduled rate and `initial_lr` the base
+        rate, as an attached torch scheduler leaves them (the reference resumes its scheduler with last_epoch = iter - 1, which
+        needs `initial_lr`)."""
+        self.prepare()
+        step, offset = (int(v) for v in self.step_dev.tolist())
+        m, v = self._m.detach().cpu(), self._v.detach().cpu()
+        slots = self._slots()
+        defaults = dict(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))]).defaults)  # this torch version's own key set
+        state, groups, idx = {}, [], 0
+        for gi, g in enumerate(self.param_groups):
+            ids = []
+            for p in g["params"]:
+                if step > 0 and id(p) in slots:
+                    o, n = slots[id(p)]
+                    state[idx] = {"step": torch.tensor(float(step)), "exp_avg": m[o:o + n].view_as(p).clone(),
+                                  "exp_avg_sq": v[o:o + n].view_as(p).clone()}
+                ids.append(idx)
+                idx += 1
+            gg = {**defaults, **{k: val for k, val in g.items() if k != "params"}}
+            gg["betas"] = tuple(gg["betas"])
+            if self.T_max > 0 or self.step_size > 0:
+                gg["initial_lr"] = g["lr"]
+                gg["lr"] = self._lr_at(g["lr"], step + offset)
+            gg["params"] = ids
+            groups.append(gg)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        """Accepts torch.optim.AdamW.state_dict() (written here or by the reference's torch optimizer) and the round-1 private
+        layout ("hidvae_m"/"hidvae_v"/"step").  Returns True when Adam's moments were restored.  When they were not (no state in
+        the file), bias correction restarts from step 0 while the learning-rate schedule keeps its position (start_step)."""
+        self.prepare()
+        if "hidvae_m" in sd:
+            self._m.copy_(sd["hidvae_m"].to(self._m.device))
+            self._v.copy_(sd["hidvae_v"].to(self._v.device))
+            self.step_dev[0] = int(sd["step"])
+            self.step_dev[1] = 0
+            return True
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError("optimizer state is neither a torch.optim.AdamW state_dict nor a hidvae flat state")
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups) or any(len(a["params"]) != len(b["params"]) for a, b in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters per group "
+                             f"({[len(g['params']) for g in groups]} vs {[len(g['params']) for g in self.param_groups]})")
+        slots = self._slots()
+        steps, restored = [], 0
+        self._m.zero_()
+        self._v.zero_()
+        for a, b in zip(groups, self.param_groups):
+            for i, p in zip(a["params"], b["params"]):
+                st = sd["state"].get(i)
+                if st is None or id(p) not in slots:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter has {tuple(p.shape)}")
+                o, n = slots[id(p)]
+                self._m[o:o + n].copy_(st["exp_avg"].reshape(-1).to(self._m.device, torch.float32))
+                self._v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1).to(self._v.device, torch.float32))
+                steps.append(int(float(st["step"])))
+                restored += 1
+            for k in ("weight_decay", "betas", "eps"):
+                if k in a:
+                    b[k] = tuple(a[k]) if k == "betas" else a[k]
+            b["lr"] = a.get("initial_lr", a.get("lr", b["lr"]))  # the group's BASE rate; the schedule is re-derived from the step
+        self._refresh_hyper()
+        prev = int(self.step_dev[0])
+        if restored:
+            self.step_dev[0] = max(steps)
+            self.step_dev[1] = 0
+        else:  # nothing to restore: a fresh Adam (bias correction from step 0) on a schedule that continues where the run was
+            self.step_dev[0] = 0
+            self.step_dev[1] = prev
+        return bool(restored)
+
+    def _refresh_hyper(self):
+        lrs, wds = [], []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.requires_grad:
+                    lrs.append(g["lr"])
+                    wds.append(g["weight_decay"])
+        self._desc["lr"].copy_(torch.tensor(lrs, dtype=torch.float32))
+        self._desc["wd"].copy_(torch.tensor(wds, dtype=torch.float32))
+        b = {tuple(g["betas"]) for g in self.param_groups}
+        e = {g["eps"] for g in self.param_groups}
+        if len(b) != 1 or len(e) != 1:
+            raise ValueError("one (betas, eps) pair for all groups")
+        self.betas, self.eps = b.pop(), e.pop()
+
+    def restart_without_state(self, schedule_position):
+        """resume without optimizer state: zero moments, bias correction from step 0, schedule at `schedule_position`"""
+        self.prepare()
+        self._m.zero_()
+        self._v.zero_()
+        self.step_dev[0] = 0
+        self.step_dev[1] = int(schedule_position)
+
     def flat_state(self):
-        """Checkpoint payload (goes under the reference's "optimizer" key): moments, step, hyper-parameters."""
+        """round-1 private checkpoint payload, kept for files written then (load_state_dict reads both)"""
         self.prepare()
         return {"hidvae_m": self._m.detach().cpu(), "hidvae_v": self._v.detach().cpu(), "step": int(self.step_dev[0].item()),
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
                 "cosine": (self.T_max, self.eta_min), "step_lr": (self.step_size, self.gamma)}
 
-    def load_flat_state(self, state):
-        self.prepare()
-        self._m.copy_(state["hidvae_m"].to(self._m.device))
-        self._v.copy_(state["hidvae_v"].to(self._v.device))
-        self.step_dev.fill_(int(state["step"]))
+    load_flat_state = load_state_dict
+
+    def _lr_at(self, base, t):
+        if self.T_max > 0:
+            return self.eta_min + (base - self.eta_min) * (1 + math.cos(math.pi * t / self.T_max)) / 2
+        return base * self.gamma ** (t // self.step_size) if self.step_size > 0 else base
 
     def current_lr(self, group=0):
-        t = int(self.step_dev[0].item())
-        base = self.param_groups[group]["lr"]
-        if self.T_max <= 0:
-            return base * self.gamma ** (t // self.step_size) if self.step_size > 0 else base
-        return self.eta_min + (base - self.eta_min) * (1 + math.cos(math.pi * t / self.T_max)) / 2
+        t = int(self.step_dev.sum().item())  # scheduler steps taken: the optimizer's own + a resumed run's offset
+        return self._lr_at(self.param_groups[group]["lr"], t)

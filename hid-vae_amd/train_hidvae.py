@@ -152,6 +152,8 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
             log.info(f"Updated number of tag classes: {tag_class_counts}; rare tag ids saved to {rare_path}")
 
     torch.manual_seed(seed)
+    import numpy as np
+    np.random.seed(seed % (2 ** 32))  # the k-means start draws np.random.choice (init/kmeans.py:40 of the reference): make a run replayable
     model = HRqVae(input_dim=vae_input_dim, embed_dim=vae_embed_dim, hidden_dims=vae_hidden_dims, codebook_size=vae_codebook_size,
                    codebook_kmeans_init=use_kmeans_init and pretrained_hrqvae_path is None, codebook_normalize=vae_codebook_normalize,
                    codebook_sim_vq=vae_sim_vq, codebook_mode=vae_codebook_mode, n_layers=L, n_cat_features=vae_n_cat_feats,
@@ -177,14 +179,24 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
         groups = [{"params": list(model.parameters()), "lr": learning_rate, "weight_decay": weight_decay}]
     start_iter, opt_state = 0, None
     if pretrained_hrqvae_path is not None:
+        from .checkpoint import load_checkpoint
         model.load_pretrained(pretrained_hrqvae_path)
-        state = torch.load(pretrained_hrqvae_path, map_location=device, weights_only=False)
+        state = load_checkpoint(pretrained_hrqvae_path, map_location=device)
         start_iter, opt_state = state["iter"] + 1, state.get("optimizer")
     cosine = (lr_scheduler_T_max, lr_scheduler_eta_min) if (use_lr_scheduler and lr_scheduler_type == "cosine") else None
     step_lr = (lr_scheduler_step_size, lr_scheduler_gamma) if (use_lr_scheduler and lr_scheduler_type == "step") else None
     opt = HidvaeAdamW(groups, cosine=cosine, step_lr=step_lr, start_step=start_iter, flat_grads=world > 1).prepare()
-    if opt_state is not None and "hidvae_m" in opt_state:
-        opt.load_flat_state(opt_state)
+    if pretrained_hrqvae_path is not None:  # reference train_hidvae.py:625: optimizer.load_state_dict(state["optimizer"])
+        restored = False
+        if opt_state is not None:
+            try:
+                restored = opt.load_state_dict(opt_state)
+            except (ValueError, KeyError) as e:
+                log.warning(f"optimizer state of {pretrained_hrqvae_path} does not fit this model ({e})")
+        if not restored:
+            opt.restart_without_state(start_iter)
+            log.warning("resuming WITHOUT optimizer state: AdamW moments start at zero and its bias correction restarts from step 0; "
+                        f"the learning-rate schedule continues from iteration {start_iter}")
     dp = DataParallel(model, opt.grad_buffer) if world > 1 else None
     if dp is not None:
         dp.broadcast_parameters(0)
@@ -232,9 +244,10 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
                 os.makedirs(save_dir, exist_ok=True)
                 name = (f"hrqvae_model_ACC{ev['eval_tag_pred_accuracy']:.4f}_RQLOSS{ev['eval_rqvae_loss']:.4f}_"
                         f"DUPR{ev['sem_id_repetition_rate']:.4f}_{datetime.now().strftime('%Y%m%d_%H%M%S')}.pt")
-                torch.save({"iter": it + 1, "model": model.state_dict(), "model_config": model.config, "optimizer": opt.flat_state(),
-                            "accuracy": ev["eval_tag_pred_accuracy"], "rqvae_loss": ev["eval_rqvae_loss"],
-                            "sem_id_repetition_rate": ev["sem_id_repetition_rate"]}, os.path.join(save_dir, name))
+                from .checkpoint import save_checkpoint
+                save_checkpoint({"iter": it + 1, "model": model.state_dict(), "model_config": model.config, "optimizer": opt.state_dict(),
+                                 "accuracy": ev["eval_tag_pred_accuracy"], "rqvae_loss": ev["eval_rqvae_loss"],
+                                 "sem_id_repetition_rate": ev["sem_id_repetition_rate"]}, os.path.join(save_dir, name))
                 log.info(f"Model saved to: {os.path.join(save_dir, name)}")
     if main_proc:
         os.makedirs(save_dir, exist_ok=True)

@@ -55,6 +55,22 @@ extern "C" {
 const char *hidvae_version(void);
 const char *hidvae_last_error(void);
 
+/* ---- workspace sizes.  The caller owns all device memory; this tells it how many BYTES the `workspace` / `scratch`
+ * argument of an entry point must hold for a problem of dimensions dims[0..n_dims) (0 = the entry point needs none at that size
+ * and NULL may be passed).  Host-only, no GPU call.  dims per op: */
+#define HIDVAE_WS_GEMM 1                 /* M, N, K, split_k          -> hidvae_gemm_f32 workspace                      */
+#define HIDVAE_WS_LINEAR_BWD 2           /* B, n_out, n_in, has_bias  -> hidvae_linear_bwd workspace                    */
+#define HIDVAE_WS_COLSUM 3               /* M, N                      -> hidvae_colsum workspace                        */
+#define HIDVAE_WS_CODEBOOK_GRAD 4        /* B, L, K                   -> hidvae_codebook_grad workspace                 */
+#define HIDVAE_WS_LAYERNORM_PARAM_GRAD 5 /* M, N                                                                         */
+#define HIDVAE_WS_LAYERNORM_BWD_ALL 6    /* M, N                                                                         */
+#define HIDVAE_WS_BATCHNORM_FWD 7        /* M, N                                                                         */
+#define HIDVAE_WS_BATCHNORM_BWD 8        /* M, N                                                                         */
+#define HIDVAE_WS_ID_CENSUS 9            /* B  -> `scratch` of hidvae_id_stats / `census_scratch` of hidvae_bottleneck_fwd (zero-fill once) */
+#define HIDVAE_WS_KMEANS 10              /* N, K                      -> shift_scratch of hidvae_kmeans_iter             */
+#define HIDVAE_WS_TAG_LOSS 11            /* B, C                      -> row_loss + row_hit + zbuf of hidvae_tag_loss_fwd */
+int hidvae_query_workspace(int op, const int64_t *dims, int n_dims, int64_t *bytes);
+
 /* ---- a2/a3/a9/a10: Linear layers (modules/encoder.py:23-36, h_rqvae.py:132-188,322-331) ------------
  * C[M,N] (ldc) = epilogue( opA(A) opB(B) + bias[N] ) [* mask * mask_scale].  fp32 in, fp32 MFMA.
  * split_k == 1: every output element is ONE fmaf chain over k in the fixed order ORDER-G16 (16-wide k-blocks
@@ -207,6 +223,16 @@ int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, const 
 int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L, float w_a, float w_p,
                     float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, void *stream);
 
+/* ---- a14 as stand-alone modules: ReconstructionLoss.forward (loss.py:7-12) and the two halves of QuantizeLoss.forward
+ * (loss.py:36-44) are sums s[m] = sum_j (a[m,j]-b[m,j])^2 over rows (lda/ldb row strides in elements):
+ * out[m] = s + extra*s (extra = 0: the reconstruction loss; extra = commitment_weight: emb_loss + cw*query_loss, whose two terms
+ * have the same value).  bwd: ga = g[m*g_stride] * scale_a * 2(a-b), gb = g[m*g_stride] * scale_b * 2(b-a); either may be NULL.
+ * QuantizeLoss's stop-gradients make scale_a = commitment_weight (query) and scale_b = 1 (value). */
+int hidvae_sqdiff_rows(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M, int64_t N, float extra, float *out,
+                       void *stream);
+int hidvae_sqdiff_rows_bwd(const float *g, int64_t g_stride, const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M,
+                           int64_t N, float scale_a, float scale_b, float *ga, float *gb, void *stream);
+
 /* ---- a13: debug statistics (h_rqvae.py:643-648) ----------------------------------------------------
  * embs_norm[b,i] = |emb_cat[b, i*32:(i+1)*32]|; *p_unique = (#distinct id tuples)/B computed by a
  * sort-free hash census (== the reference's O(B^2 L) triu expression), one launch.
@@ -218,10 +244,12 @@ int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, in
 /* ---- a16: AdamW (torch.optim.AdamW defaults; train_hidvae.py:533-563,762-766) with the cosine schedule
  * evaluated ON DEVICE from a device step counter, so the whole step is graph-capturable.
  * hidvae_adamw_prepare: one tiny launch per optimizer step that depends on nothing (run it beside forward/backward):
- *   t = *step_dev + 1; lr_t = eta_min + (base_lr-eta_min)(1+cos(pi*(t-1)/T_max))/2 if T_max > 0 (CosineAnnealingLR),
- *   else base_lr * gamma^floor((t-1)/step_size) if step_size > 0 (StepLR, train_hidvae.py:641-642), else base_lr;
+ *   step_dev is int64[2] = {optimizer steps taken, scheduler steps taken before step 0 (non-zero only for a run resumed WITHOUT
+ *   its optimizer state: the schedule continues while Adam's bias correction restarts, train_hidvae.py:621-640)};
+ *   t = step_dev[0] + 1; s = t - 1 + step_dev[1]; lr_t = eta_min + (base_lr-eta_min)(1+cos(pi*s/T_max))/2 if T_max > 0
+ *   (CosineAnnealingLR), else base_lr * gamma^floor(s/step_size) if step_size > 0 (StepLR, train_hidvae.py:641-642), else base_lr;
  *   hyper[i] = {1 - lr_t*wd_i, lr_t/(1-beta1^t), sqrt(1-beta2^t)} (double precision, as torch does on the host);
- *   *step_dev = t.
+ *   step_dev[0] = t.
  * hidvae_adamw_step: one launch per <=128 tensors.  p/m/v/numel: DEVICE tables built once; g_host: HOST array of the
  *   n_tensors gradient device pointers (autograd hands out new buffers every step; they travel by value in the kernel
  *   arguments).  grad_scale multiplies g first (1/world_size after an all-reduce SUM). */
@@ -332,6 +360,12 @@ int hidvae_gumbel_rows_bwd(const float *P, float *gP, int64_t B, int64_t K, floa
 int hidvae_gumbel_finish(float *g_x, const float *x, const float *emb, const float *g_xx, const float *g_l,
                          int64_t gl_stride, float beta, int64_t B, float *g_cb, const float *cb, const float *gS_colsum,
                          int64_t K, void *stream);
+
+/* distributions/gumbel.py:8-18 as stand-alone functions: G = -log(-log(U+eps)+eps) elementwise; out = softmax((logits+G(U))/T)
+ * per row.  U: uniform draws in [0,1) from the caller's generator (the library holds no RNG state). */
+int hidvae_gumbel_noise(const float *U, int64_t n, float eps, float *out, void *stream);
+int hidvae_gumbel_softmax_rows(const float *logits, const float *U, int64_t B, int64_t K, float temperature, float *out,
+                               void *stream);
 
 /* ---- the stage-2 transformer's padded -> jagged copy (reference ops/triton/jagged.py:9-124, a Triton kernel
  * there).  x [B, N, D] of any element type (strides in BYTES, D contiguous, row_bytes = D * element size); offsets [B+1] = the

@@ -17,7 +17,7 @@ def case_names(kind="case"):
         n = os.path.basename(p)[:-4]
         if kind == "rqvae" and n.startswith("rqvae"):
             out.append(n)
-        elif kind == "case" and not (n.startswith("kmeans") or n.startswith("train") or n.startswith("rqvae")):
+        elif kind == "case" and not n.startswith(("kmeans", "train", "rqvae", "tokenizer")):
             out.append(n)
         elif kind == "kmeans" and n.startswith("kmeans"):
             out.append(n)
@@ -78,3 +78,33 @@ def zero_grad_keys(cfg):
         if cfg.codebook_normalize:
             ks.append(f"tag_projectors.{i}.4.bias")
     return set(ks)
+
+
+NEAR_TIE = 1e-6  # a top-2 distance gap below this is inside fp32 summation-order noise: that decision may legitimately flip
+
+
+def safe_rows(fx, thr=NEAR_TIE):
+    """[B] bool: items none of whose level decisions is a near-tie in the reference's own arithmetic.  An item with a near-tie at
+    level i is excluded from level i on (a flip there changes every later residual of that item); tests compare ids / per-item
+    floats on the safe rows bit-exactly / to tolerance and REPORT what happened on the others instead of hiding it."""
+    return (np.asarray(fx["margins"]) > thr).all(axis=1)
+
+
+def report_flips(name, got_ids, fx, thr=NEAR_TIE):
+    """-> number of near-tie items whose id tuple differs from the reference's (printed with their margins; pytest -s shows it)"""
+    safe = safe_rows(fx, thr)
+    ref = np.asarray(fx["sem_ids"]).astype(np.int64)
+    bad = np.nonzero(~safe & (np.asarray(got_ids) != ref).any(axis=1))[0]
+    for b in bad:
+        print(f"[near-tie flip] {name}: item {b} margins {np.asarray(fx['margins'])[b]} got {np.asarray(got_ids)[b]} reference {ref[b]}")
+    if (~safe).any():
+        print(f"[near-tie census] {name}: {int((~safe).sum())} item(s) with a top-2 gap <= {thr:g}; {len(bad)} flipped")
+    return len(bad)
+
+
+def grad_rtol(base, B):
+    """Relative tolerance for a GRADIENT compared across implementations at batch size B.  A parameter gradient is a sum of B
+    per-item terms of mixed sign accumulated in fp32 in an implementation-specific order; its rounding noise grows like sqrt(B).
+    `base` (2e-5 oracle-vs-reference, 3e-5 HIP-vs-reference) is the bar the fixtures up to B = 256 meet; larger batches get
+    base * sqrt(B / 256).  Losses and ids are NOT relaxed (1e-5 / bit-exact at every size)."""
+    return base * max(1.0, (B / 256.0) ** 0.5)

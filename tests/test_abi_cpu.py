@@ -35,3 +35,24 @@ def test_product_refuses_cpu_tensors():
     from hidvae_amd import _C
     with pytest.raises(RuntimeError):
         _C.gemm(_C.GEMM_NT, torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_query_workspace_is_host_only_and_matches_the_documented_formulas():
+    """hidvae_query_workspace needs no GPU: the sizes are what include/hidvae.h documents per entry point."""
+    from hidvae_amd import _C
+    q = _C.workspace_bytes
+    assert q(_C.WS_GEMM, 1024, 512, 768, 1) == 0                       # direct path: no slabs
+    assert q(_C.WS_GEMM, 65536, 512, 768, 4) == 4 * 65536 * 512 * 4   # LDS-tiled path with split_k slabs
+    assert q(_C.WS_GEMM, 512, 768, 8192, 0) == 16 * 512 * 768 * 4     # deep-K weight gradient
+    assert q(_C.WS_LINEAR_BWD, 1024, 512, 768, 1) == 16 * 512 * 4
+    assert q(_C.WS_LINEAR_BWD, 8192, 512, 768, 0) == 16 * 512 * 768 * 4
+    assert q(_C.WS_COLSUM, 1000, 48) == 16 * 48 * 4
+    assert q(_C.WS_CODEBOOK_GRAD, 2048, 3, 256) == 0 and q(_C.WS_CODEBOOK_GRAD, 8192, 3, 256) == 3 * 256 * 4 * 32 * 4
+    assert q(_C.WS_LAYERNORM_BWD_ALL, 1024, 230) == 2 * 256 * 230 * 4
+    assert q(_C.WS_BATCHNORM_FWD, 1024, 512) == 3 * 16 * 512 * 4 and q(_C.WS_BATCHNORM_BWD, 1024, 512) == 2 * 16 * 512 * 4
+    assert q(_C.WS_ID_CENSUS, 1024) == (4 * 1024 + 3) * 8
+    assert q(_C.WS_TAG_LOSS, 128, 38) == (2 * 128 + 128 * 38) * 4
+    with pytest.raises(RuntimeError):
+        q(99, 1)
+    with pytest.raises(RuntimeError):
+        q(_C.WS_GEMM, 1, 2)  # too few dimensions

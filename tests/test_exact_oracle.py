@@ -17,10 +17,10 @@ def test_exact_oracle_matches_reference(name):
     cbs = [P[f"layers.{i}.embedding.weight"].numpy() for i in range(cfg.n_layers)]
     r = exact.rq_forward(y, cbs, cfg.codebook_normalize, cfg.codebook_normalize, cfg.codebook_mode,
                          desc["training"], cfg.commitment_weight)
-    safe = fx["margins"] > 1e-6  # a decision whose top-2 gap is below fp32 noise may legitimately flip
-    assert safe.all(), "fixture has a near-tie; annotate instead of comparing"
-    assert np.array_equal(r["ids"], fx["sem_ids"].astype(np.int64))
-    assert H.rel_err(r["loss"], fx["rqvae_loss"]) <= 1e-5
+    safe = H.safe_rows(fx)  # a decision whose top-2 gap is below fp32 noise may legitimately flip: reported, not compared
+    assert np.array_equal(r["ids"][safe], fx["sem_ids"].astype(np.int64)[safe])
+    H.report_flips(name, r["ids"], fx)
+    assert H.rel_err(r["loss"][safe], fx["rqvae_loss"][safe]) <= 1e-5
     if "z" in fx:
         L = cfg.n_layers
         assert H.rel_err(r["z"], fx["z"]) <= 1e-5

@@ -109,6 +109,33 @@ def test_install_dropin_aliases_reference_module_names():
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/modules/utils.py"), reason="the reference tree only exists in the build container")
+def test_install_dropin_keeps_unmirrored_reference_modules_importable():
+    """install_dropin() replaces LEAF modules only: the reference's own packages stay in place, so the import block of its
+    train_hidvae.py (`from modules.utils import parse_config`, line 9) and the stage-2 modules still resolve to its files, while the
+    mirrored names resolve to the HIP implementation.  (`gin` is not installed here: a decorator stub stands in, as in
+    tests/golden/make_golden.py.)"""
+    import subprocess
+    import sys
+    code = ("import sys, types; sys.path.insert(0, %r); sys.path.insert(0, '/root/reference'); "
+            "g = types.ModuleType('gin'); g.configurable = lambda f=None, **k: f if f is not None else (lambda h: h); "
+            "g.constants_from_enum = lambda c: c; g.parse_config_file = lambda *a, **k: None; sys.modules['gin'] = g; "
+            "import hidvae_amd; hidvae_amd.install_dropin(); "
+            "import modules, modules.utils, modules.transformer.attention, modules.embedding.id_embedder; "
+            "from modules.utils import parse_config; "
+            "assert modules.__file__.startswith('/root/reference') and modules.utils.__file__.startswith('/root/reference'); "
+            "from modules.h_rqvae import HRqVae; from modules.quantize import QuantizeForwardMode; "
+            "from modules.tokenizer.h_semids import HSemanticIdTokenizer; from data.utils import batch_to, cycle, next_batch; "
+            "from distributions.gumbel import TemperatureScheduler, gumbel_softmax_sample; from modules.loss import ReconstructionLoss; "
+            "import modules.h_rqvae; assert modules.h_rqvae is sys.modules['modules.h_rqvae']; "
+            "assert HRqVae.__module__ == 'hidvae_amd.modules.h_rqvae' and HSemanticIdTokenizer.__module__.startswith('hidvae_amd.'); "
+            "assert gumbel_softmax_sample.__module__ == 'hidvae_amd.distributions.gumbel'; "
+            "assert ReconstructionLoss.__module__ == 'hidvae_amd.modules.loss'; print('ok')"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_reference_processed_dataset_file_loads_without_torch_geometric(tmp_path):
     """The reference writes its dataset with torch_geometric's InMemoryDataset.save: torch.save((HeteroData.to_dict(), slices,
     <class HeteroData>), legacy serialization) (data/tags_amazon.py:392-431).  The loader must read it with torch_geometric
@@ -143,3 +170,20 @@ def test_reference_processed_dataset_file_loads_without_torch_geometric(tmp_path
     plain = {"x": item["x"], "is_train": item["is_train"]}
     torch.save(plain, str(tmp_path / "plain.pt"))
     assert set(load_reference_processed(str(tmp_path / "plain.pt"))) == {"x", "is_train"}
+
+
+def test_state_dict_contract_matches_the_reference():
+    """Checkpoint interchange rests on the state-dict keys: the amazon-config mirror must expose exactly the reference's
+    146 entries -- names, order, shapes, dtypes (tests/golden/state_dict_contract.json, dumped from the reference's own HRqVae by
+    tests/golden/make_golden_tokenizer.py)."""
+    import json
+    from hidvae_amd.modules.h_rqvae import HRqVae
+    from hidvae_amd.modules.quantize import QuantizeForwardMode
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_dict_contract.json")))
+    m = HRqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=256, codebook_kmeans_init=False,
+               codebook_normalize=True, codebook_mode=QuantizeForwardMode.ROTATION_TRICK, n_layers=3, n_cat_features=0,
+               tag_class_counts=[38, 168, 348], tag_embed_dim=768, use_focal_loss=True, dropout_rate=0.4)
+    got = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+    assert len(got) == len(want["entries"]) == 146
+    assert got == want["entries"]
+    assert sum(p.numel() for p in m.parameters()) == want["n_parameters"] == 7244236

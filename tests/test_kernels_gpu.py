@@ -196,10 +196,13 @@ def test_id_stats(C):
     assert abs(float(pu) - float(O.p_unique_fast(ids.cpu()))) < 1e-7
     assert abs(float(O.p_unique(ids.cpu()[:600])) - float(C.id_stats(emb[:600], ids[:600])[1])) < 1e-7
     assert H.rel_err(norms.cpu().numpy(), emb.cpu().reshape(5000, 3, 32).norm(dim=-1).numpy()) < 1e-6
-    # the census table is shared by consecutive calls of one batch size (generation-tagged, never cleared)
+    # ONE caller-owned census table serves consecutive calls of one batch size (generation-tagged, never cleared)
+    table = C.census_scratch(5000, "cuda")
     for seed, hi in ((52, 4), (53, 200), (54, 2), (55, 12), (56, 1)):
         ids = torch.from_numpy(fill.ints((5000, 3), seed, hi)).cuda()
-        assert abs(float(C.id_stats(emb, ids)[1]) - float(O.p_unique_fast(ids.cpu()))) < 1e-7, (seed, hi)
+        assert abs(float(C.id_stats(emb, ids, scratch=table)[1]) - float(O.p_unique_fast(ids.cpu()))) < 1e-7, (seed, hi)
+    with pytest.raises(RuntimeError):
+        C.id_stats(emb[:600], ids[:600], scratch=table)  # a table of another batch size is refused
 
 
 @pytest.mark.parametrize("name", H.case_names("kmeans"))
@@ -270,14 +273,15 @@ def test_bottleneck_launch_is_bit_identical_to_the_separate_launches(C, B, mode,
         assert torch.equal(o[k], v), k
     # the same launch carrying the debug statistics (id census + |emb_out| per level) against hidvae_id_stats; repeated calls walk
     # the census table's generations, and a batch of copies has few distinct tuples
+    table = C.census_scratch(B, "cuda")  # one caller-owned table for all the calls below
     for rep in range(3):
-        oc = C.bottleneck_fwd(h1, W2, W3, cb, cc, norm, mode, 0.4, Wd0, Wd1, id_stats=True)
+        oc = C.bottleneck_fwd(h1, W2, W3, cb, cc, norm, mode, 0.4, Wd0, Wd1, id_stats=True, scratch=table)
         norms, pu = C.id_stats(oc["emb_cat"], oc["ids"])
         for k, v in want.items():
             assert torch.equal(oc[k], v), k
         assert torch.equal(oc["embs_norm"], norms) and float(oc["p_unique"]) == float(pu), rep
     hdup = h1[torch.arange(B, device="cuda") % 5].contiguous()
-    od = C.bottleneck_fwd(hdup, W2, W3, cb, cc, norm, mode, 0.4, Wd0, Wd1, id_stats=True)
+    od = C.bottleneck_fwd(hdup, W2, W3, cb, cc, norm, mode, 0.4, Wd0, Wd1, id_stats=True, scratch=table)
     distinct = len({tuple(r) for r in od["ids"].cpu().tolist()})
     assert float(od["p_unique"]) == float(torch.tensor(distinct, dtype=torch.float32) / torch.tensor(B, dtype=torch.float32))
     assert torch.equal(od["embs_norm"], C.id_stats(od["emb_cat"], od["ids"])[0])

@@ -63,19 +63,23 @@ def test_forward_backward_matches_reference_goldens(name):
     else:
         with torch.no_grad():
             out = m(batch, gumbel_t=0.2)
-    assert (fx["margins"] > 1e-6).all()
+    safe = H.safe_rows(fx)
     m.rand = InjectedRand(O.FormulaRand(**desc["rand"]))
     q = m.get_semantic_ids(m.encode(batch.x).detach(), None, None, 0.2) if "z" in fx else None
     m.rand = InjectedRand(O.FormulaRand(**desc["rand"]))  # the Gumbel draws are numbered in call order: replay them
     with torch.no_grad():
-        ids = m.get_semantic_ids(m.encode(batch.x), None, None, 0.2).sem_ids
-    assert np.array_equal(ids.cpu().numpy(), fx["sem_ids"].astype(np.int64)), "semantic ids differ from the reference"
+        ids = m.get_semantic_ids(m.encode(batch.x), None, None, 0.2).sem_ids.cpu().numpy()
+    assert np.array_equal(ids[safe], fx["sem_ids"].astype(np.int64)[safe]), "semantic ids differ from the reference"
+    flips = H.report_flips(name, ids, fx)
+    assert H.rel_err(out.rqvae_loss.detach().cpu().numpy()[safe], fx["rqvae_loss"][safe]) <= TOL
+    assert H.rel_err(out.reconstruction_loss.detach().cpu().numpy()[safe], fx["reconstruction_loss"][safe]) <= TOL
+    assert H.rel_err(out.embs_norm.cpu().numpy()[safe], fx["embs_norm"][safe]) <= TOL
+    if flips:  # only the fixture built around a 1-ulp tie may do this; batch-level sums then differ by that item's terms
+        assert name.startswith("neartie"), "a decision with a top-2 gap above 1e-6 flipped"
+        return
     for k in ("loss", "tag_align_loss", "tag_pred_loss", "tag_pred_accuracy", "p_unique_ids", "sem_id_uniqueness_loss"):
         got = float(getattr(out, k).detach())
         assert abs(got - float(fx[k])) <= TOL * max(1.0, abs(float(fx[k]))), (k, got, float(fx[k]))
-    assert H.rel_err(out.rqvae_loss.detach().cpu().numpy(), fx["rqvae_loss"]) <= TOL
-    assert H.rel_err(out.reconstruction_loss.detach().cpu().numpy(), fx["reconstruction_loss"]) <= TOL
-    assert H.rel_err(out.embs_norm.cpu().numpy(), fx["embs_norm"]) <= TOL
     for k in ("tag_align_loss_by_layer", "tag_pred_loss_by_layer", "tag_pred_accuracy_by_layer"):
         if k in fx:
             assert H.rel_err(getattr(out, k).detach().cpu().numpy(), fx[k]) <= TOL, k
@@ -89,19 +93,20 @@ def test_forward_backward_matches_reference_goldens(name):
     if desc["training"]:
         norms = json.loads(str(fx["grad_norms"]))
         params = dict(m.named_parameters())
+        rt = H.grad_rtol(3e-5, desc["B"])
         for k, n in norms.items():
             g = params[k].grad
             got = float(g.double().norm()) if g is not None else 0.0
-            assert abs(got - n) <= 3e-5 * max(n, 1e-6) + 1e-8, (k, got, n)
+            assert abs(got - n) <= rt * max(n, 1e-6) + 1e-8 * max(1.0, desc["B"] / 256), (k, got, n)
         for k in fx:
             if k.startswith("grad/"):
                 g = params[k[5:]].grad
                 g = g.cpu().numpy() if g is not None else np.zeros_like(fx[k])
-                assert H.close(g, fx[k], 3e-5, 1e-8), k
+                assert H.close(g, fx[k], rt, 1e-8), k
             if k.startswith("gsample/"):
                 g = params[k[8:]].grad
                 g = H.sample(g) if g is not None else np.zeros_like(fx[k])  # untagged step: tag heads get no gradient
-                assert H.close(g, fx[k], 3e-5, 1e-8), k
+                assert H.close(g, fx[k], rt, 1e-8), k
 
 
 @pytest.mark.parametrize("B", [1, 5, 64, 1000])

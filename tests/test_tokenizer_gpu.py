@@ -50,6 +50,37 @@ def test_corpus_ids_and_prefix_search():
         assert not got[covered:].any()
 
 
+@pytest.mark.parametrize("mode", [None, "concat", "inter"])
+def test_corpus_ids_match_the_reference_tokenizer(mode):
+    """precompute_corpus_ids against the REFERENCE's own HSemanticIdTokenizer run on the same items and weights
+    (tests/golden/tokenizer_corpus.npz, made by tests/golden/make_golden_tokenizer.py; reference h_semids.py:109-197): semantic ids
+    and, in the combined modes, the eval-mode tag predictions placed as the reference places them."""
+    from tests import helpers as H
+    fx, desc = H.load("tokenizer_corpus")
+    tok, cfg, P = make_tok(mode)
+    x, _, _ = O.formula_batch(cfg, desc["N"], seed=desc["batch_seed"], tagged=False)
+    got = tok.precompute_corpus_ids(x).cpu().numpy()
+    want = fx["corpus_ids_" + {None: "plain", "concat": "concat", "inter": "inter"}[mode]].astype(np.int64)
+    assert got.shape == want.shape and got.dtype == np.int64
+    assert np.array_equal(got, want), f"{int((got != want).any(1).sum())} of {len(want)} corpus rows differ from the reference's"
+
+
+def test_exists_prefix_matches_the_reference_truth_tables():
+    """exists_prefix (sorted-key binary search here, a [queries, corpus, width] broadcast compare in the reference,
+    h_semids.py:199-239) against the reference's own answers: every prefix width, a 3-D prefix, a prefix wider than the cache,
+    and the trailing rows % 16 rows the reference never examines."""
+    from tests import helpers as H
+    fx, desc = H.load("tokenizer_corpus")
+    tok, cfg, P = make_tok()
+    tok.cached_ids = torch.from_numpy(fx["corpus_ids_plain"].astype(np.int64)).cuda()  # the reference's cache itself
+    for key in ("w1", "w2", "w3", "3d", "wide"):
+        q = torch.from_numpy(fx["prefix_q_" + key].astype(np.int64)).cuda()
+        got = tok.exists_prefix(q)
+        assert got.dtype == torch.bool and tuple(got.shape) == tuple(fx["prefix_hit_" + key].shape)
+        assert np.array_equal(got.cpu().numpy(), fx["prefix_hit_" + key]), key
+    assert not fx["prefix_hit_w3"][64:].any() and fx["prefix_hit_w3"][:64].any()  # (the fixture does contain the skipped-rows quirk)
+
+
 def test_sequence_tokenisation_cached_and_uncached():
     tok, cfg, P = make_tok()
     x, _, _ = O.formula_batch(cfg, 64, seed=32, tagged=False)

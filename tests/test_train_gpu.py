@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("flat", [False, True], ids=["per-tensor-grads", "flat-grad-buffer"])
 @pytest.mark.parametrize("name", H.case_names("train"))
-def test_three_iterations_match_the_reference_run(name, flat):
-    """grad accumulation (2 forwards, one backward), 8 AdamW param groups with layer-specific lr / wd, cosine schedule:
+def test_training_iterations_match_the_reference_run(name, flat):
+    """(3 iterations with 2 accumulated micro-batches, and a 20-iteration loss sequence)
+    grad accumulation (several forwards, one backward), 8 AdamW param groups with layer-specific lr / wd, cosine schedule:
     losses per iteration, final codebooks and BatchNorm buffers vs the reference's own run (train_hidvae.py:533-563,698-766)."""
     from hidvae_amd.optim import HidvaeAdamW
     from hidvae_amd.rand import InjectedRand
@@ -58,7 +59,8 @@ def test_three_iterations_match_the_reference_run(name, flat):
                 assert np.median(d) <= 0.01 * lr * desc["iters"], k
     for i in range(cfg.n_layers):
         # (the projector weights feeding BatchNorm have themselves moved by Adam-amplified noise after 3 steps)
-        assert H.rel_err(sd[f"tag_projectors.{i}.1.running_mean"].cpu().numpy(), fx[f"bn_mean_{i}"]) <= 5e-5
+        # (... and the running mean contains the projector's first bias, whose gradient is mathematically zero: Adam random-walks it)
+        assert H.close(sd[f"tag_projectors.{i}.1.running_mean"].cpu().numpy(), fx[f"bn_mean_{i}"], 5e-5, 0.05 * lr * desc["iters"])
         assert H.rel_err(sd[f"tag_projectors.{i}.1.running_var"].cpu().numpy(), fx[f"bn_var_{i}"]) <= 5e-5
         assert int(sd[f"tag_projectors.{i}.1.num_batches_tracked"]) == desc["iters"] * desc["ga"]
 
