@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--also-large", type=int, default=8192, help="also time the same step at this per-GPU batch (reported as "
                     "`large_batch_step`; 0 = skip): shows the throughput-bound regime next to the latency-bound headline batch")
     ap.add_argument("--also-tagged", type=int, default=1, help="also time the tagged step (reported as `tagged_step`)")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the MEDIAN window is reported")
     return ap.parse_args()
 
 
@@ -170,6 +171,70 @@ def kernel_rooflines(args, m, device):
     return out
 
 
+def step_timeline(stepper, pool_batch, device, replays=5):
+    """In-step duration of every launch of the replayed train step.  HIP events cannot be recorded inside a captured graph on
+    ROCm, so the step is re-captured with a device-timestamp launch (hidvae_timestamp: wall_clock64, 10 ns ticks) before and after
+    every C-ABI launch, on that launch's own stream; bracket minus the empty bracket = the launch's duration plus one dependent-
+    launch gap, i.e. what it costs the step (the brackets of the untagged step sum to the un-stamped step time within 1 %).
+    -> list of dict(entry, us, M, N, K, flops) in launch order."""
+    from hidvae_amd import _C
+    inner = stepper._fwd_bwd
+
+    def stamped():
+        for _ in range(5):
+            _C.stamp_empty_bracket()
+        inner()
+
+    graphs = stepper.graphs
+    stepper.graphs, stepper._fwd_bwd = None, stamped
+    stamps = _C.stamps_begin(device)
+    try:
+        stepper([pool_batch(0)])  # captures the stamped step and replays it once
+    finally:
+        _C.stamps_end()
+        stepper._fwd_bwd = inner
+    for i in range(replays):
+        stepper([pool_batch(1 + i)])
+    torch.cuda.synchronize()
+    rows, empty = stamps.rows_with_dims()
+    stepper.graphs = graphs  # back to the un-stamped graph
+    out = []
+    for name, us, dims in rows:
+        r = dict(entry=name, us=us)
+        if dims is not None:
+            r.update(M=dims[0], N=dims[1], K=dims[2], flops=dims[3])
+        out.append(r)
+    return out, empty
+
+
+def summarize_timeline(rows):
+    """-> (per-entry-point table sorted by in-step time, the single dominant launch)"""
+    agg = {}
+    for r in rows:
+        a = agg.setdefault(r["entry"], dict(entry=r["entry"], launches=0, us=0.0, flops=0.0))
+        a["launches"] += 1
+        a["us"] += r["us"]
+        a["flops"] += r.get("flops", 0.0)
+    total = sum(r["us"] for r in rows)
+    table = sorted(agg.values(), key=lambda a: -a["us"])
+    for a in table:
+        a["share"] = a["us"] / total
+        if a["flops"]:
+            a["tflops"] = a["flops"] / a["us"] * 1e-6
+            a["mfma_f32_frac"] = a["tflops"] / MFMA_F32_PEAK_TF
+    top = max(rows, key=lambda r: r["us"])
+    return table, top, total
+
+
+def describe_launch(r):
+    if r["entry"] == "hidvae_gemm_f32":
+        return f"hidvae_gemm_f32 [{r['M']}x{r['K']}]x[{r['K']}x{r['N']}] (forward Linear, fp32 MFMA, exact ORDER-G chain)"
+    if r["entry"] == "hidvae_linear_bwd":
+        return (f"hidvae_linear_bwd B={r['M']} n_out={r['N']} n_in={r['K']} (one-launch Linear backward: dW = g^T x"
+                + (" + dX = g W" if r["flops"] > 2.5 * r["M"] * r["N"] * r["K"] else "") + ", gemm_pair kernel)")
+    return r["entry"]
+
+
 def pmc_traffic():
     """{kernel-name prefix: bytes per launch} from profiles/*_pmc_hbm_traffic.csv (FETCH_SIZE doubled as the guide prescribes for
     gfx950, + WRITE_SIZE; both in KB in the file).  The counters need their own rocprofv3 passes, so they cannot be taken live
@@ -275,22 +340,30 @@ def run_workload(args, device, rank, world, dist):
 
     for i in range(args.warmup):
         step(i)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if multi:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    # `windows` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize on both sides and reduced
+    # with MAX over ranks; the median window is the reported one (a single 5 ms sample is at the mercy of one clock ramp)
+    windows, n = [], args.warmup
+    for _ in range(max(1, getattr(args, "windows", 1))):
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(n + i)
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if multi:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        windows.append(dt)
+        n += args.steps
+    dt = sorted(windows)[len(windows) // 2]
     final_loss = float(stepper.row[0]) if stepper.row is not None else float("nan")
-    return dt, m, dict(hip_graph=bool(use_graph), final_loss=final_loss)
+    return dt, m, dict(hip_graph=bool(use_graph), final_loss=final_loss, windows_ms_per_step=[w / args.steps * 1e3 for w in windows],
+                       stepper=stepper, pool_batch=pool_batch)
 
 
 
@@ -310,20 +383,36 @@ def main():
 
     dt, m, info = run_workload(args, device, rank, world, dist)
     use_graph, final_loss = info["hip_graph"], info["final_loss"]
+    timeline = None
+    if rank == 0 and world == 1 and dist is None and use_graph and args.kernels:
+        timeline = step_timeline(info["stepper"], info["pool_batch"], device)
     tagged_extra = None
     if world == 1 and not args.tagged and args.also_tagged:
         targs = argparse.Namespace(**{**vars(args), "tagged": 1, "steps": max(20, args.steps // 4), "warmup": max(5, args.warmup // 2)})
         tdt, _, tinfo = run_workload(targs, device, rank, world, dist)
         tagged_extra = dict(value=targs.batch * targs.steps / tdt, unit="items/s", ms_per_step=tdt / targs.steps * 1e3, steps=targs.steps,
-                            hip_graph=tinfo["hip_graph"],
+                            hip_graph=tinfo["hip_graph"], windows_ms_per_step=tinfo["windows_ms_per_step"],
                             workload="same shapes + tag heads (projector, InfoNCE, predictor, focal+mixup), amazon gin hyper-parameters")
+        if tinfo["hip_graph"] and args.kernels and dist is None:
+            trows, _ = step_timeline(tinfo["stepper"], tinfo["pool_batch"], device)
+            ttable, ttop, ttotal = summarize_timeline(trows)
+            tagged_extra["launches"] = len(trows)
+            tagged_extra["in_step_by_entry_point"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()} for a in ttable[:8]]
+            tagged_extra["roofline"] = dict(bound="mfma", kernel=describe_launch(ttop), us_per_launch=ttop["us"], peak=MFMA_F32_PEAK_TF,
+                                            unit="TFLOP/s", achieved=ttop.get("flops", 0.0) / ttop["us"] * 1e-6,
+                                            frac=ttop.get("flops", 0.0) / ttop["us"] * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
+                                            note="dominant launch of the tagged step by in-step time (device timestamps around the launch inside the replayed graph)")
+        if args.cpu_seconds > 0:
+            tagged_extra["cpu_baseline"] = cpu_baseline(targs, max(4.0, args.cpu_seconds / 2))
+        del tinfo
 
     large_extra = None
     if world == 1 and dist is None and not args.tagged and args.also_large and args.kernels:
         largs = argparse.Namespace(**{**vars(args), "batch": args.also_large, "steps": max(20, args.steps // 5), "warmup": 5, "pool": 2})
         ldt, _, linfo = run_workload(largs, device, rank, world, dist)
         large_extra = dict(batch=largs.batch, value=largs.batch * largs.steps / ldt, unit="items/s", ms_per_step=ldt / largs.steps * 1e3,
-                           steps=largs.steps, hip_graph=linfo["hip_graph"])
+                           steps=largs.steps, hip_graph=linfo["hip_graph"], windows_ms_per_step=linfo["windows_ms_per_step"])
+        del linfo
 
     if rank == 0:
         if not args.kernels:  # profiling run of the step only (rocprofv3 timelines): no roofline object
@@ -335,14 +424,30 @@ def main():
                 dist.destroy_process_group()
             return
         ks = kernel_rooflines(args, m, device)
-        # dominant kernel: rocprof (profiles/) puts ~70 % of the step in gemm_direct_kernel, and the encoder's first layer is
-        # its single largest launch
-        roof = ks[0]
         pmc = pmc_traffic()
-        for k in ks:  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of exactly these launches (profiles/)
-            for key, val in pmc.items():
+        for k in ks:  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of exactly these launches (profiles/);
+            for key, val in pmc.items():  # a kernel whose name no longer matches a CSV row keeps traffic = null
                 if k["kernel"].startswith(key):
                     k["traffic"] = val
+        # `roofline` = the launch with the largest IN-STEP time (device timestamps inside the replayed graph); the stand-alone warm
+        # figure of the same shape (back-to-back launches on identical operands) is carried separately as us_warm / frac_warm
+        roof, in_step = None, None
+        if timeline is not None:
+            rows, empty_us = timeline
+            table, top, total = summarize_timeline(rows)
+            in_step = dict(launches=len(rows), sum_us=total, empty_bracket_us=empty_us,
+                           by_entry_point=[{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()} for a in table],
+                           launches_in_order=[dict(entry=r["entry"], us=round(r["us"], 2)) for r in rows])
+            ach = top.get("flops", 0.0) / top["us"] * 1e-6
+            warm = next((k for k in ks if top["entry"] == "hidvae_gemm_f32" and k.get("flops") == top.get("flops") and "encoder layer 0" in k["kernel"]), None)
+            roof = dict(kernel=describe_launch(top), bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF,
+                        traffic=None, us=top["us"], share_of_step=top["us"] / total,
+                        us_warm=warm["us"] if warm else None, frac_warm=warm["frac"] if warm else None)
+            for key, val in pmc.items():  # (only a PMC row taken of exactly this launch counts)
+                if roof["kernel"].startswith(key):
+                    roof["traffic"] = val
+        if roof is None:
+            roof = dict(ks[0])
         line = {
             "metric": "item-embeddings/sec HiD-VAE train step, 768-d in, 3x256 codebooks",
             "value": args.batch * world * args.steps / dt, "unit": "items/s", "n_gpus": world, "steps": args.steps,
@@ -352,9 +457,13 @@ def main():
                                    f"ROTATION_TRICK, {'tagged (projector+InfoNCE+predictor+focal/mixup)' if args.tagged else 'untagged core'}"
                                    f" train step = fwd+bwd+{'RCCL all-reduce+' if world > 1 else ''}AdamW(cosine)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(use_graph)},
-            "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"], "us_per_launch": roof["us"]},
+            "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"], "us_per_launch": roof["us"]}
+                        | {k: roof[k] for k in ("share_of_step", "us_warm", "frac_warm") if k in roof},
+            "windows_ms_per_step": info["windows_ms_per_step"],
             "kernels": ks, "final_loss": final_loss,
         }
+        if in_step is not None:
+            line["in_step"] = in_step
         if tagged_extra is not None:
             line["tagged_step"] = tagged_extra
         if large_extra is not None:

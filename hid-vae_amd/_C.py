@@ -71,9 +71,104 @@ _SIGNATURES = {
     "hidvae_sqdiff_rows_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _f, _f, _vp, _vp, _vp],
     "hidvae_gumbel_noise": [_vp, _i64, _f, _vp, _vp],
     "hidvae_gumbel_softmax_rows": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
+    "hidvae_timestamp": [_vp, _vp],
 }
 WS_GEMM, WS_LINEAR_BWD, WS_COLSUM, WS_CODEBOOK_GRAD, WS_LAYERNORM_PARAM_GRAD, WS_LAYERNORM_BWD_ALL = 1, 2, 3, 4, 5, 6
 WS_BATCHNORM_FWD, WS_BATCHNORM_BWD, WS_ID_CENSUS, WS_KMEANS, WS_TAG_LOSS = 7, 8, 9, 10, 11
+
+
+class LaunchStamps:
+    """In-step launch timeline: while active, EVERY C-ABI launch is bracketed by two hidvae_timestamp launches on its
+    own stream, also inside a HIP-graph capture (HIP events cannot be recorded there on ROCm).  After the step has run / the graph
+    has been replayed, rows() gives (entry point, microseconds between the two stamps).  A bracket spans stamp kernel + dependent-
+    launch gap + the launch itself + another gap; `empty_us` (a bracket around nothing, taken on every begin) measures the first
+    two, so rows() reports bracket - empty = the launch's duration plus ONE dependent-launch gap, i.e. what the launch costs the
+    step.  Measurement aid only: the stamps add two tiny launches per launch and are never part of a timed region."""
+    TICK_US = 0.01  # wall_clock64 runs at 100 MHz on gfx950
+
+    def __init__(self, device, capacity=4096):
+        self.buf = torch.zeros((2 * capacity,), dtype=torch.int64, device=device)
+        self.names, self.dims = [], []  # dims: (M, N, K, flops) of GEMM-class launches, else None
+
+    def _slot(self, name, dims=None):
+        if 2 * len(self.names) + 2 > self.buf.numel():
+            raise RuntimeError("LaunchStamps: capacity exceeded")
+        self.names.append(name)
+        self.dims.append(dims)
+        return self.buf.data_ptr() + 16 * (len(self.names) - 1)
+
+    def rows(self):
+        t = self.buf[: 2 * len(self.names)].cpu().reshape(-1, 2)
+        d = ((t[:, 1] - t[:, 0]).double() * self.TICK_US).tolist()
+        empty = [v for n, v in zip(self.names, d) if n == "(empty)"]
+        base = sorted(empty)[len(empty) // 2] if empty else 0.0
+        return [(n, v - base) for n, v in zip(self.names, d) if n != "(empty)"], base
+
+    def rows_with_dims(self):
+        rows, base = self.rows()
+        dims = [dm for n, dm in zip(self.names, self.dims) if n != "(empty)"]
+        return [(n, v, dm) for (n, v), dm in zip(rows, dims)], base
+
+
+_STAMPS = None
+_NOT_LAUNCHES = ("hidvae_last_error", "hidvae_version", "hidvae_query_workspace", "hidvae_timestamp")
+
+
+def stamps_begin(device, capacity=4096):
+    global _STAMPS
+    _STAMPS = LaunchStamps(device, capacity)
+    return _STAMPS
+
+
+def stamps_end():
+    global _STAMPS
+    st, _STAMPS = _STAMPS, None
+    return st
+
+
+def stamp_empty_bracket():
+    """a bracket around nothing on the current stream (calibration of LaunchStamps.rows)"""
+    st = _STAMPS
+    if st is not None:
+        p = st._slot("(empty)")
+        lib()._L.hidvae_timestamp(ctypes.c_void_p(p), _stream())
+        lib()._L.hidvae_timestamp(ctypes.c_void_p(p + 8), _stream())
+
+
+def _gemm_dims(name, a):
+    """(M, N, K, flops) of a GEMM-class launch from its C arguments (for the in-step roofline rows of bench.py)"""
+    if name == "hidvae_gemm_f32":
+        return (int(a[1]), int(a[2]), int(a[3]), 2.0 * a[1] * a[2] * a[3])
+    if name == "hidvae_linear_bwd":  # dW = g^T x (always) + dX = g W (when dX != NULL)
+        B, n_out, n_in = int(a[6]), int(a[7]), int(a[8])
+        return (B, n_out, n_in, (4.0 if a[12] is not None else 2.0) * B * n_out * n_in)
+    return None
+
+
+class _LibProxy:
+    """the loaded library; entry points that launch are wrapped so LaunchStamps can bracket them (every one takes the stream last)"""
+
+    def __init__(self, L):
+        self._L = L
+
+    def __getattr__(self, name):
+        fn = getattr(self._L, name)
+        if name in _NOT_LAUNCHES or not name.startswith("hidvae_"):
+            return fn
+        L = self._L
+
+        def call(*a):
+            st = _STAMPS
+            if st is None:
+                return fn(*a)
+            p = st._slot(name, _gemm_dims(name, a))
+            L.hidvae_timestamp(ctypes.c_void_p(p), a[-1])
+            rc = fn(*a)
+            L.hidvae_timestamp(ctypes.c_void_p(p + 8), a[-1])
+            return rc
+
+        setattr(self, name, call)
+        return call
 
 
 def lib():
@@ -91,7 +186,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = sig
             fn.restype = ctypes.c_int
-        _lib = L
+        _lib = _LibProxy(L)
     return _lib
 
 
@@ -316,7 +411,6 @@ def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1
         raise RuntimeError("bottleneck_fwd: operands must be contiguous")
     if tuple(W2.shape) != (N2, K2) or tuple(W3.shape) != (EMBED_DIM, N2) or tuple(Wd0.shape) != (Nd0, EMBED_DIM) or tuple(Wd1.shape) != (Nd1, Nd0):
         raise RuntimeError("bottleneck_fwd: layer shapes do not chain")
-    scratch = None
     if id_stats:
         if not census_eligible(L, K):
             raise RuntimeError(f"bottleneck_fwd: the fused id census needs L <= 4 and K <= 1024 (got {L}, {K})")

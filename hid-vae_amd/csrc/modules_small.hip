@@ -63,7 +63,19 @@ __global__ __launch_bounds__(256) void gumbel_softmax_rows_kernel(const float *l
     for (int64_t k = lane; k < K; k += 64) o[k] = expf(o[k] - mx) / sum;
 }
 
+// one lane stores the device's constant-rate wall clock (100 MHz on gfx950: 10 ns ticks)
+__global__ void timestamp_kernel(int64_t *slot) {
+    if (threadIdx.x == 0) *slot = (int64_t)wall_clock64();
+}
+
 }  // namespace
+
+extern "C" int hidvae_timestamp(int64_t *slot, void *stream) {
+    HV_REQUIRE(slot, "timestamp: null slot");
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slot);
+    HV_LAUNCH_CHECK("timestamp");
+    return HIDVAE_OK;
+}
 
 extern "C" int hidvae_sqdiff_rows(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M, int64_t N, float extra,
                                   float *out, void *stream) {

@@ -367,6 +367,11 @@ int hidvae_gumbel_noise(const float *U, int64_t n, float eps, float *out, void *
 int hidvae_gumbel_softmax_rows(const float *logits, const float *U, int64_t B, int64_t K, float temperature, float *out,
                                void *stream);
 
+/* ---- measurement aid: *slot = the device's constant-rate wall clock (wall_clock64: 100 MHz, 10 ns ticks), stored by a
+ * one-wave kernel launched on `stream`.  Launched before and after another launch INSIDE a captured step it brackets that launch's
+ * in-step duration (HIP events cannot be recorded inside a captured graph on ROCm); bench.py's per-kernel timeline uses it. */
+int hidvae_timestamp(int64_t *slot, void *stream);
+
 /* ---- the stage-2 transformer's padded -> jagged copy (reference ops/triton/jagged.py:9-124, a Triton kernel
  * there).  x [B, N, D] of any element type (strides in BYTES, D contiguous, row_bytes = D * element size); offsets [B+1] = the
  * exclusive scan of lengths (int64, device); values [offsets[B], D] receives the first lengths[b] rows of every entry back to
