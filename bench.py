@@ -131,7 +131,7 @@ def kernel_rooflines(args, m, device):
     a0 = torch.empty(B, 512, device=device)
     t = time_kernel(lambda: _C.gemm(_C.GEMM_NT, x, w0, out=o0, epilogue=_C.EPI_SILU, aux=a0))
     fl = 2.0 * B * 768 * 512
-    out.append(dict(kernel="gemm_direct_kernel<NT,1,6> encoder layer 0: [B,768]x[768,512]^T + SiLU (exact ORDER-G chain)", bound="mfma",
+    out.append(dict(entry="hidvae_gemm_f32", kernel="gemm_direct_kernel<NT,1,6> encoder layer 0: [B,768]x[768,512]^T + SiLU (exact ORDER-G chain)", bound="mfma",
                     achieved=fl / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
                     us=t, flops=fl))
     g = torch.randn(B, 512, device=device)
@@ -140,6 +140,14 @@ def kernel_rooflines(args, m, device):
     out.append(dict(kernel="gemm_direct_kernel<TN,8,3> dW encoder layer 0: [512,B]x[B,768] (in-workgroup split-K)", bound="mfma",
                     achieved=fl / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
                     us=t, flops=fl))
+    wd = m.decoder.mlp[-1].weight.detach()  # [768, 512]: the widest Linear backward of the step (decoder's last layer)
+    gd, xd = torch.randn(B, 768, device=device), torch.randn(B, 512, device=device)
+    pre = torch.randn(B, 512, device=device)
+    t = time_kernel(lambda: _C.linear_bwd(gd, xd, wd, True, _C.EPI_DSILU, pre))
+    fl2 = 4.0 * B * 768 * 512
+    out.append(dict(entry="hidvae_linear_bwd", kernel="gemm_pair32_kernel decoder layer 3 backward: dW [768,512] = g^T x and dX = (g W) * silu'(pre) in one launch",
+                    bound="mfma", achieved=fl2 / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl2 / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
+                    us=t, flops=fl2))
     # the same layer in the throughput regime (LDS-tiled kernel; corpus tokenisation and large-batch training run here)
     bigm = 1 << 16
     xb, ob, ab = torch.randn(bigm, 768, device=device), torch.empty(bigm, 512, device=device), torch.empty(bigm, 512, device=device)
@@ -222,17 +230,19 @@ def summarize_timeline(rows):
         if a["flops"]:
             a["tflops"] = a["flops"] / a["us"] * 1e-6
             a["mfma_f32_frac"] = a["tflops"] / MFMA_F32_PEAK_TF
-    top = max(rows, key=lambda r: r["us"])
+    top = dict(table[0])  # the entry point (= kernel family) with the largest share of the step, as a rocprof per-kernel stats row
+    top["us_per_launch"] = top["us"] / top["launches"]
+    shapes = sorted({(r.get("M"), r.get("N"), r.get("K")) for r in rows if r["entry"] == top["entry"] and "M" in r}, key=lambda t: -t[0] * t[1] * t[2])
+    top["shapes"] = shapes
     return table, top, total
 
 
 def describe_launch(r):
-    if r["entry"] == "hidvae_gemm_f32":
-        return f"hidvae_gemm_f32 [{r['M']}x{r['K']}]x[{r['K']}x{r['N']}] (forward Linear, fp32 MFMA, exact ORDER-G chain)"
-    if r["entry"] == "hidvae_linear_bwd":
-        return (f"hidvae_linear_bwd B={r['M']} n_out={r['N']} n_in={r['K']} (one-launch Linear backward: dW = g^T x"
-                + (" + dX = g W" if r["flops"] > 2.5 * r["M"] * r["N"] * r["K"] else "") + ", gemm_pair kernel)")
-    return r["entry"]
+    what = {"hidvae_gemm_f32": "forward Linear layers: gemm_direct16/gemm_direct kernels, fp32 MFMA, one exact ORDER-G chain per output",
+            "hidvae_linear_bwd": "one-launch Linear backward dW = g^T x + dX = g W (+ db): gemm_pair16 / gemm_pair32 kernels, fp32 MFMA",
+            "hidvae_bottleneck_fwd": "fused middle launch: encoder[-2:] + L-level RQ + decoder[:2], fp32 MFMA"}.get(r["entry"], "")
+    shapes = "; ".join(f"{m}x{n}x{k}" for m, n, k in r.get("shapes", [])[:8])
+    return f"{r['entry']} x{r['launches']} launches per step ({what}{'; MxNxK: ' + shapes if shapes else ''})"
 
 
 def pmc_traffic():
@@ -398,10 +408,11 @@ def main():
             ttable, ttop, ttotal = summarize_timeline(trows)
             tagged_extra["launches"] = len(trows)
             tagged_extra["in_step_by_entry_point"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()} for a in ttable[:8]]
-            tagged_extra["roofline"] = dict(bound="mfma", kernel=describe_launch(ttop), us_per_launch=ttop["us"], peak=MFMA_F32_PEAK_TF,
+            tagged_extra["roofline"] = dict(bound="mfma", kernel=describe_launch(ttop), us_per_launch=ttop["us_per_launch"], peak=MFMA_F32_PEAK_TF,
                                             unit="TFLOP/s", achieved=ttop.get("flops", 0.0) / ttop["us"] * 1e-6,
-                                            frac=ttop.get("flops", 0.0) / ttop["us"] * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
-                                            note="dominant launch of the tagged step by in-step time (device timestamps around the launch inside the replayed graph)")
+                                            frac=ttop.get("flops", 0.0) / ttop["us"] * 1e-6 / MFMA_F32_PEAK_TF, traffic=None, share_of_step=ttop["share"],
+                                            note="kernel family with the largest in-step time of the tagged step (device timestamps around every launch "
+                                                 "inside the replayed graph; the level branches run on 3 streams, so brackets include queueing behind each other)")
         if args.cpu_seconds > 0:
             tagged_extra["cpu_baseline"] = cpu_baseline(targs, max(4.0, args.cpu_seconds / 2))
         del tinfo
@@ -439,9 +450,9 @@ def main():
                            by_entry_point=[{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()} for a in table],
                            launches_in_order=[dict(entry=r["entry"], us=round(r["us"], 2)) for r in rows])
             ach = top.get("flops", 0.0) / top["us"] * 1e-6
-            warm = next((k for k in ks if top["entry"] == "hidvae_gemm_f32" and k.get("flops") == top.get("flops") and "encoder layer 0" in k["kernel"]), None)
+            warm = next((k for k in ks if k.get("entry") == top["entry"]), None)  # the family's largest launch, stand-alone and warm
             roof = dict(kernel=describe_launch(top), bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF,
-                        traffic=None, us=top["us"], share_of_step=top["us"] / total,
+                        traffic=None, us=top["us_per_launch"], share_of_step=top["share"],
                         us_warm=warm["us"] if warm else None, frac_warm=warm["frac"] if warm else None)
             for key, val in pmc.items():  # (only a PMC row taken of exactly this launch counts)
                 if roof["kernel"].startswith(key):

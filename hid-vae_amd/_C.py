@@ -72,6 +72,11 @@ _SIGNATURES = {
     "hidvae_gumbel_noise": [_vp, _i64, _f, _vp, _vp],
     "hidvae_gumbel_softmax_rows": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
     "hidvae_timestamp": [_vp, _vp],
+    "hidvae_gemm_group": [_vp, _i, _vp],
+    "hidvae_linear_bwd_group": [_vp, _i, _vp],
+    "hidvae_act_bwd_group": [_vp, _i, _vp],
+    "hidvae_layernorm_fwd_group": [_vp, _i, _vp],
+    "hidvae_layernorm_bwd_all_group": [_vp, _i, _vp],
 }
 WS_GEMM, WS_LINEAR_BWD, WS_COLSUM, WS_CODEBOOK_GRAD, WS_LAYERNORM_PARAM_GRAD, WS_LAYERNORM_BWD_ALL = 1, 2, 3, 4, 5, 6
 WS_BATCHNORM_FWD, WS_BATCHNORM_BWD, WS_ID_CENSUS, WS_KMEANS, WS_TAG_LOSS = 7, 8, 9, 10, 11
@@ -142,6 +147,10 @@ def _gemm_dims(name, a):
     if name == "hidvae_linear_bwd":  # dW = g^T x (always) + dX = g W (when dX != NULL)
         B, n_out, n_in = int(a[6]), int(a[7]), int(a[8])
         return (B, n_out, n_in, (4.0 if a[12] is not None else 2.0) * B * n_out * n_in)
+    if name == "hidvae_bottleneck_fwd":  # enc[-2:] + L levels of K codes + dec[:2] on B items (see include/hidvae.h for the argument order)
+        B, K2, N2, L, K, Nd0, Nd1 = int(a[1]), int(a[2]), int(a[3]), int(a[12]), int(a[13]), int(a[22]), int(a[23])
+        D = EMBED_DIM
+        return (B, N2, K2, 2.0 * B * (K2 * N2 + N2 * D + L * K * D + D * Nd0 + Nd0 * Nd1))
     return None
 
 
@@ -763,6 +772,154 @@ def gumbel_rows_bwd(P, gP, temperature):
 def gumbel_finish(g_x, x, emb, g_xx, g_l, beta, g_cb, cb, gS_colsum):
     _check(lib().hidvae_gumbel_finish(_p(g_x), _p(x), _p(emb), _p(g_xx), _p(g_l), _vec_stride(g_l), float(beta), x.shape[0], _p(g_cb), _p(cb),
                                       _p(gS_colsum), cb.shape[0], _stream()), "hidvae_gumbel_finish")
+
+
+# ------------------------------------------------------------------------------------------------ grouped launches
+class GemmProblem(ctypes.Structure):  # hidvae_gemm_problem
+    _fields_ = [("layout", _i), ("M", _i64), ("N", _i64), ("K", _i64), ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("bias", _vp),
+                ("C", _vp), ("ldc", _i64), ("epilogue", _i), ("aux", _vp), ("ldaux", _i64), ("mask", _vp), ("ldmask", _i64),
+                ("mask_scale", _f), ("accumulate", _i), ("workspace", _vp)]
+
+
+class LinearBwdProblem(ctypes.Structure):  # hidvae_linear_bwd_problem
+    _fields_ = [("g", _vp), ("ldg", _i64), ("x", _vp), ("ldx", _i64), ("W", _vp), ("ldw", _i64), ("B", _i64), ("n_out", _i64),
+                ("n_in", _i64), ("dW", _vp), ("lddw", _i64), ("accumulate_dw", _i), ("dX", _vp), ("lddx", _i64), ("dx_epilogue", _i),
+                ("aux", _vp), ("ldaux", _i64), ("db", _vp), ("accumulate_db", _i), ("workspace", _vp)]
+
+
+class ActBwdProblem(ctypes.Structure):  # hidvae_act_bwd_problem
+    _fields_ = [("g", _vp), ("ref", _vp), ("numel", _i64), ("act", _i), ("mask", _vp), ("mask_scale", _f), ("out", _vp)]
+
+
+class LayerNormProblem(ctypes.Structure):  # hidvae_layernorm_problem
+    _fields_ = [("x", _vp), ("M", _i64), ("N", _i64), ("gamma", _vp), ("beta", _vp), ("eps", _f), ("y", _vp), ("mean", _vp), ("rstd", _vp),
+                ("relu", _i), ("keep_mask", _vp), ("keep_scale", _f), ("residual", _vp), ("gy", _vp), ("gx", _vp), ("ggamma", _vp),
+                ("gbeta", _vp), ("accumulate", _i), ("workspace", _vp)]
+
+
+def _dp(t):
+    return t.data_ptr() if t is not None else None
+
+
+def gemm_group(problems):
+    """problems: list of dicts with the keyword arguments of gemm() (layout, A, B, out, bias, epilogue, aux, mask, mask_scale,
+    accumulate); ONE launch for all of them (hidvae_gemm_group).  -> list of outputs"""
+    arr = (GemmProblem * len(problems))()
+    outs = []
+    for q, pr in zip(arr, problems):
+        A, B, layout = pr["A"], pr["B"], pr.get("layout", GEMM_NT)
+        _f32(A, "A"), _f32(B, "B")
+        if layout == GEMM_NT:
+            (M, K), (N, K2) = A.shape, B.shape
+        elif layout == GEMM_NN:
+            (M, K), (K2, N) = A.shape, B.shape
+        else:
+            (K, M), (K2, N) = A.shape, B.shape
+        if K != K2:
+            raise RuntimeError(f"gemm_group: inner dimensions differ ({K} vs {K2})")
+        out = pr.get("out")
+        if out is None:
+            out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+        aux, mask = pr.get("aux"), pr.get("mask")
+        ws = _ws(WS_GEMM, A.device, M, N, K, 0)  # (only read if the call falls back to per-problem launches)
+        q.layout, q.M, q.N, q.K = layout, M, N, K
+        q.A, q.lda, q.B, q.ldb = A.data_ptr(), _row_stride(A, "A"), B.data_ptr(), _row_stride(B, "B")
+        q.bias, q.C, q.ldc, q.epilogue = _dp(pr.get("bias")), out.data_ptr(), _row_stride(out, "C"), int(pr.get("epilogue", EPI_NONE))
+        q.aux, q.ldaux = _dp(aux), (_row_stride(aux, "aux") if aux is not None else 0)
+        q.mask, q.ldmask, q.mask_scale = _dp(mask), (_row_stride(mask, "mask") if mask is not None else 0), float(pr.get("mask_scale", 1.0))
+        q.accumulate, q.workspace = int(bool(pr.get("accumulate", False))), _dp(ws)
+        outs.append((out, ws))
+    _check(lib().hidvae_gemm_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_gemm_group")
+    return [o for o, _ in outs]
+
+
+def linear_bwd_group(problems):
+    """problems: list of dicts with the arguments of linear_bwd() (g, x, w, need_dx, epilogue, aux, dW, accumulate, bias, db,
+    accumulate_db); ONE launch for every dW, dX and db of the group.  -> list of (dW, dX or None, db or None)"""
+    arr = (LinearBwdProblem * len(problems))()
+    outs, keep = [], []
+    for q, pr in zip(arr, problems):
+        g, x, w = pr["g"], pr["x"], pr["w"]
+        _f32(g, "g"), _f32(x, "x")
+        B, n_out = g.shape
+        n_in = x.shape[1]
+        need_dx = bool(pr.get("need_dx", True))
+        if x.shape[0] != B or (need_dx and tuple(w.shape) != (n_out, n_in)):
+            raise RuntimeError(f"linear_bwd_group: shapes g {tuple(g.shape)} x {tuple(x.shape)} W {tuple(w.shape)}")
+        dW, acc = pr.get("dW"), bool(pr.get("accumulate", False))
+        if dW is None:
+            dW, acc = torch.empty((n_out, n_in), device=g.device, dtype=torch.float32), False
+        dX = torch.empty((B, n_in), device=g.device, dtype=torch.float32) if need_dx else None
+        db, accb = (pr.get("db"), bool(pr.get("accumulate_db", False))) if pr.get("bias") else (None, False)
+        if pr.get("bias") and db is None:
+            db, accb = torch.empty((n_out,), device=g.device, dtype=torch.float32), False
+        aux = pr.get("aux")
+        ws = _ws(WS_LINEAR_BWD, g.device, B, n_out, n_in, int(db is not None))
+        q.g, q.ldg, q.x, q.ldx = g.data_ptr(), _row_stride(g, "g"), x.data_ptr(), _row_stride(x, "x")
+        q.W, q.ldw = (w.data_ptr(), _row_stride(w, "W")) if need_dx else (None, 0)
+        q.B, q.n_out, q.n_in = B, n_out, n_in
+        q.dW, q.lddw, q.accumulate_dw = dW.data_ptr(), n_in, int(acc)
+        q.dX, q.lddx, q.dx_epilogue = _dp(dX), n_in, int(pr.get("epilogue", EPI_NONE))
+        q.aux, q.ldaux = _dp(aux), (_row_stride(aux, "aux") if aux is not None else 0)
+        q.db, q.accumulate_db, q.workspace = _dp(db), int(accb), _dp(ws)
+        outs.append((dW, dX, db))
+        keep.append(ws)
+    _check(lib().hidvae_linear_bwd_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_linear_bwd_group")
+    return outs
+
+
+def act_bwd_group(problems):
+    """problems: list of (g, ref, act, mask, mask_scale) -> list of out (one launch)"""
+    arr = (ActBwdProblem * len(problems))()
+    outs = []
+    for q, (g, ref, act, mask, scale) in zip(arr, problems):
+        out = torch.empty_like(g)
+        q.g, q.ref, q.numel, q.act, q.mask, q.mask_scale, q.out = g.data_ptr(), _dp(ref), g.numel(), int(act), _dp(mask), float(scale), out.data_ptr()
+        outs.append(out)
+    _check(lib().hidvae_act_bwd_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_act_bwd_group")
+    return outs
+
+
+def layernorm_fwd_group(problems):
+    """problems: list of (x, gamma, beta, eps, relu, mask, mask_scale, residual) -> list of (y, mean, rstd) (one launch)"""
+    arr = (LayerNormProblem * len(problems))()
+    outs = []
+    for q, (x, gamma, beta, eps, relu, mask, scale, res) in zip(arr, problems):
+        M, N = x.shape
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        mean = torch.empty((M,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty((M,), device=x.device, dtype=torch.float32)
+        q.x, q.M, q.N, q.gamma, q.beta, q.eps = x.data_ptr(), M, N, gamma.data_ptr(), beta.data_ptr(), float(eps)
+        q.y, q.mean, q.rstd, q.relu = y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), int(relu)
+        q.keep_mask, q.keep_scale, q.residual = _dp(mask), float(scale), _dp(res)
+        outs.append((y, mean, rstd))
+    _check(lib().hidvae_layernorm_fwd_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_layernorm_fwd_group")
+    return outs
+
+
+def layernorm_bwd_all_group(problems):
+    """problems: list of dicts(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, need_gx, gg, gb, accumulate)
+    -> list of (gx or None, ggamma, gbeta); two launches for the whole group (row pass + fixed-order finish)"""
+    arr = (LayerNormProblem * len(problems))()
+    outs, keep = [], []
+    for q, pr in zip(arr, problems):
+        x = pr["x"]
+        M, N = x.shape
+        gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if pr.get("need_gx", True) else None
+        gg, gb, acc = pr.get("gg"), pr.get("gb"), bool(pr.get("accumulate", False))
+        if gg is None or gb is None:
+            gg = torch.empty((N,), device=x.device, dtype=torch.float32)
+            gb = torch.empty((N,), device=x.device, dtype=torch.float32)
+            acc = False
+        ws = _ws(WS_LAYERNORM_BWD_ALL, x.device, M, N)
+        q.gy, q.x, q.M, q.N = pr["gy"].data_ptr(), x.data_ptr(), M, N
+        q.gamma, q.beta, q.mean, q.rstd = pr["gamma"].data_ptr(), pr["beta"].data_ptr(), pr["mean"].data_ptr(), pr["rstd"].data_ptr()
+        q.relu, q.keep_mask, q.keep_scale = int(pr["relu"]), _dp(pr.get("mask")), float(pr.get("mask_scale", 1.0))
+        q.gx, q.ggamma, q.gbeta, q.accumulate, q.workspace = _dp(gx), gg.data_ptr(), gb.data_ptr(), int(acc), ws.data_ptr()
+        outs.append((gx, gg, gb))
+        keep.append(ws)
+    _check(lib().hidvae_layernorm_bwd_all_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_layernorm_bwd_all_group")
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------ stand-alone loss / sampling modules

@@ -13,6 +13,7 @@
 //   m-contiguous source (A of TN, B of NN/TN): float4 along m -> one ds_write_b128
 // Global loads for tile t+1 are issued before the MFMAs of tile t (register prefetch, two LDS buffers, one
 // barrier per k-tile).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -77,10 +78,12 @@ __device__ __forceinline__ void xcd_tile(int nbx, int nby, bool row_bands, int &
 
 // Load a [ROWS x BK] operand tile (ROWS = 32*W along m or n) into registers.  KCONTIG: element (row, k) is at
 // P[row*ld + k]; otherwise at P[k*ld + row].  Out-of-range elements read as 0.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte global load that only promises dword alignment
+
 template <int ROWS, int NT, bool KCONTIG>
 struct TileLoader {
     static constexpr int NV = (ROWS * BK / 4 + NT - 1) / NT;  // float4 slots per thread
-    float4 v[NV];
+    float4 v[1][NV];
     const float *base[NV];  // this thread's slot at k0 = 0 (nullptr: outside the matrix, reads as 0)
     int64_t kstride;        // elements to advance per unit of k0
     bool fast;              // every slot is either outside or a legal 16-byte load for any FULL k-tile
@@ -109,13 +112,20 @@ struct TileLoader {
         }
     }
 
-    __device__ __forceinline__ void load_full(int64_t k0) {  // a k-tile that lies completely inside [0, K)
+    // (global 16-byte loads only need dword alignment on gfx950: rows of odd width -- the tag heads' 230 / 460 / 691 -- take them too)
+    __device__ __forceinline__ void load_full(int sl, int64_t k0) {  // a k-tile that lies completely inside [0, K)
 #pragma unroll
-        for (int s = 0; s < NV; s++)
-            v[s] = base[s] != nullptr ? *reinterpret_cast<const float4 *>(base[s] + k0 * kstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < NV; s++) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (base[s] != nullptr) {
+                const f4u t = *reinterpret_cast<const f4u *>(base[s] + k0 * kstride);
+                x = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            v[sl][s] = x;
+        }
     }
 
-    __device__ __forceinline__ void load(const float *P, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+    __device__ __forceinline__ void load(int sl, const float *P, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
                                          int64_t kend, bool vec, int tid) {
 #pragma unroll
         for (int s = 0; s < NV; s++) {
@@ -128,7 +138,8 @@ struct TileLoader {
                     if (row < nrows) {
                         const float *p = P + row * ld + k;
                         if (vec && k + 4 <= kend) {
-                            x = *reinterpret_cast<const float4 *>(p);
+                            const f4u t = *reinterpret_cast<const f4u *>(p);
+                            x = make_float4(t[0], t[1], t[2], t[3]);
                         } else {
                             if (k + 0 < kend) x.x = p[0];
                             if (k + 1 < kend) x.y = p[1];
@@ -142,7 +153,8 @@ struct TileLoader {
                     if (kk < kend) {
                         const float *p = P + kk * ld + row;
                         if (vec && row + 4 <= nrows) {
-                            x = *reinterpret_cast<const float4 *>(p);
+                            const f4u t = *reinterpret_cast<const f4u *>(p);
+                            x = make_float4(t[0], t[1], t[2], t[3]);
                         } else {
                             if (row + 0 < nrows) x.x = p[0];
                             if (row + 1 < nrows) x.y = p[1];
@@ -152,12 +164,12 @@ struct TileLoader {
                     }
                 }
             }
-            v[s] = x;
+            v[sl][s] = x;
         }
     }
 
     // LDS image: T[k][ROWS + 4]
-    __device__ __forceinline__ void store(float *T, int tid) const {
+    __device__ __forceinline__ void store(int sl, float *T, int tid) const {
         constexpr int LD = ROWS + 4;
 #pragma unroll
         for (int s = 0; s < NV; s++) {
@@ -165,36 +177,37 @@ struct TileLoader {
             if (idx < ROWS * BK / 4) {
                 if (KCONTIG) {
                     const int r = idx / (BK / 4), k4 = idx % (BK / 4);
-                    T[(4 * k4 + 0) * LD + r] = v[s].x;
-                    T[(4 * k4 + 1) * LD + r] = v[s].y;
-                    T[(4 * k4 + 2) * LD + r] = v[s].z;
-                    T[(4 * k4 + 3) * LD + r] = v[s].w;
+                    T[(4 * k4 + 0) * LD + r] = v[sl][s].x;
+                    T[(4 * k4 + 1) * LD + r] = v[sl][s].y;
+                    T[(4 * k4 + 2) * LD + r] = v[sl][s].z;
+                    T[(4 * k4 + 3) * LD + r] = v[sl][s].w;
                 } else {
                     const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
-                    *reinterpret_cast<float4 *>(T + k * LD + 4 * r4) = v[s];
+                    *reinterpret_cast<float4 *>(T + k * LD + 4 * r4) = v[sl][s];
                 }
             }
         }
     }
 };
 
+// body of the LDS-tiled kernel for workgroup tile (bx, by) of an nbx x nby grid, K slab bz; As / Bs: the workgroup's two operand
+// buffers, 2 * BK * (32*WM + 4) and 2 * BK * (32*WN + 4) floats
 template <int WM, int WN, int LAYOUT>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void tile_body(const GemmArgs &g, int bx, int by, int nbx, int nby, int bz, float *As_, float *Bs_) {
     constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN;
     constexpr bool A_KC = (LAYOUT != HIDVAE_GEMM_TN);  // A[M,K] row-major
     constexpr bool B_KC = (LAYOUT == HIDVAE_GEMM_NT);  // B[N,K] row-major
     constexpr int LDA = BM + 4, LDB = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    float (*As)[BK * LDA] = reinterpret_cast<float (*)[BK * LDA]>(As_);
+    float (*Bs)[BK * LDB] = reinterpret_cast<float (*)[BK * LDB]>(Bs_);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     // (PMC at 65,536 x 768 x 512 before this mapping: 1.6 GB fetched for 203 MB of operands -- the 8 column tiles that share a
     //  row block are neighbours in dispatch order, i.e. on 8 different XCDs, and every one pulled the block from HBM itself)
-    int bx = blockIdx.x, by = blockIdx.y;
-    xcd_tile(gridDim.x, gridDim.y, g.M >= g.N, bx, by);
+    xcd_tile(nbx, nby, g.M >= g.N, bx, by);
     const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+    const int64_t kbeg = (int64_t)bz * g.k_per_split;
     const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
 
     TileLoader<BM, NT, A_KC> la;
@@ -203,27 +216,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
-    la.init(g.A, g.lda, m0, g.M, g.vecA, tid);
-    lb.init(g.B, g.ldb, n0, g.N, g.vecB, tid);
+    la.init(g.A, g.lda, m0, g.M, true, tid);
+    lb.init(g.B, g.ldb, n0, g.N, true, tid);
     const bool fast = la.fast && lb.fast;  // (uniform per workgroup only for la/lb separately; evaluated per thread, both paths legal)
-    auto fetch = [&](int64_t k0) {
+    auto fetch = [&](int sl, int64_t k0) {  // (a k0 at or past kend loads nothing)
+        if (k0 >= kend) return;
         if (fast && k0 + BK <= kend) {
-            la.load_full(k0);
-            lb.load_full(k0);
+            la.load_full(sl, k0);
+            lb.load_full(sl, k0);
         } else {
-            la.load(g.A, g.lda, m0, g.M, k0, kend, g.vecA, tid);
-            lb.load(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, tid);
+            la.load(sl, g.A, g.lda, m0, g.M, k0, kend, true, tid);
+            lb.load(sl, g.B, g.ldb, n0, g.N, k0, kend, true, tid);
         }
     };
-    fetch(kbeg);
-    la.store(As[0], tid);
-    lb.store(Bs[0], tid);
+    // (tried: a three-deep register ring so that a tile's loads have two tiles of MFMAs to arrive -- no gain at 1-2 workgroups per
+    //  CU and 3 % slower at batch 8192: the kernel is not waiting on load latency)
+    fetch(0, kbeg);
+    la.store(0, As[0], tid);
+    lb.store(0, Bs[0], tid);
     __syncthreads();
     int buf = 0;
     const int i32 = lane & 31, h = lane >> 5;
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
-        if (more) fetch(k0 + BK);
+        if (more) fetch(0, k0 + BK);
         const float *ap = As[buf] + wm * 32 + i32, *bp = Bs[buf] + wn * 32 + i32;
 #pragma unroll
         for (int s = 0; s < BK / 2; s++) {
@@ -233,8 +249,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         if (more) {
-            la.store(As[buf ^ 1], tid);
-            lb.store(Bs[buf ^ 1], tid);
+            la.store(0, As[buf ^ 1], tid);
+            lb.store(0, Bs[buf ^ 1], tid);
         }
         __syncthreads();
         buf ^= 1;
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
         const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row >= g.M) continue;
         if (g.partial != nullptr) {
-            g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = acc[r];
+            g.partial[((int64_t)bz * g.M + row) * g.N + col] = acc[r];
         } else {
             float v = acc[r] + bias;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE)
@@ -260,6 +276,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
             *dst = g.accumulate ? *dst + v : v;
         }
     }
+}
+
+template <int WM, int WN, int LAYOUT>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2 * BK * (32 * WM + 4)];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * (32 * WN + 4)];
+    tile_body<WM, WN, LAYOUT>(g, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, (int)blockIdx.z, As, Bs);
 }
 
 // fixed-order reduction of the split-K slabs + the same epilogue
@@ -847,6 +870,157 @@ inline int pick_split16(int64_t M, int64_t N, int64_t K, int split_k) {
     return sp16;
 }
 
+// ---- grouped launch: up to GROUP_MAX independent sub-problems (forward Linear layers of the three tag-head levels; or their
+// backward: dW, dX and the bias column sums of every level) in ONE grid.  A sub-problem runs the same device bodies as
+// gemm_pair16/32_kernel (16x16 or 32x32 tiles chosen by use_direct16, K shared out over `split` <= 8 waves of an 8-wave workgroup,
+// partials added in ascending wave order), so every sub-problem is deterministic; the point of the group is that the small
+// problems' launch / drain latencies hide under the big problems' arithmetic instead of being paid one after the other.
+constexpr int GROUP_MAX = 12;
+constexpr int GROUP_WAVES = 8;
+struct GroupSub {
+    GemmArgs g;    // kind 2 (column sums): A = X [M rows, N cols] at lda, C = out [N], accumulate
+    int kind;      // 0: 16x16-tile GEMM, 1: 32x32-tile GEMM, 2: column sums
+    int layout, split, deep, nbx;
+    int64_t nt;    // tiles
+    int nb;        // workgroups
+};
+struct GroupArgs {
+    int n;
+    GroupSub s[GROUP_MAX];
+};
+
+__device__ __forceinline__ void colsum_group_body(const GemmArgs &g, int64_t c0, float *part) {
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5, nrg = (int)(blockDim.x >> 5);
+    const int64_t c = c0 + col;
+    float acc = 0.0f;
+    if (c < g.N)
+        for (int64_t r0 = rg; r0 < g.M; r0 += 8 * (int64_t)nrg) {  // eight loads in flight, ascending order of additions
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = r0 + (int64_t)nrg * j < g.M ? g.A[(r0 + (int64_t)nrg * j) * g.lda + c] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += v[j];
+        }
+    part[rg * 32 + col] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < g.N) {
+        float v = part[col];
+        for (int j = 1; j < nrg; j++) v += part[j * 32 + col];
+        g.C[c] = g.accumulate ? g.C[c] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(64 * GROUP_WAVES) void gemm_group_kernel(GroupArgs a) {
+    __shared__ float part[GROUP_WAVES * 1024];
+    int bid = blockIdx.x, p = 0;
+    while (p + 1 < a.n && bid >= a.s[p].nb) {
+        bid -= a.s[p].nb;
+        p++;
+    }
+    const GroupSub &s = a.s[p];
+    if (s.kind == 2) {
+        colsum_group_body(s.g, (int64_t)bid * 32, part);
+        return;
+    }
+    const int64_t tile0 = (int64_t)xcd_slot(bid, s.nb) * (GROUP_WAVES / s.split);
+    if (s.kind == 0) {
+        if (s.layout == HIDVAE_GEMM_NT) {
+            if (s.deep) direct16_body<HIDVAE_GEMM_NT, 6>(s.g, s.split, tile0, s.nt, s.nbx, part);
+            else direct16_body<HIDVAE_GEMM_NT, 3>(s.g, s.split, tile0, s.nt, s.nbx, part);
+        } else if (s.layout == HIDVAE_GEMM_NN) direct16_body<HIDVAE_GEMM_NN, 3>(s.g, s.split, tile0, s.nt, s.nbx, part);
+        else direct16_body<HIDVAE_GEMM_TN, 3>(s.g, s.split, tile0, s.nt, s.nbx, part);
+    } else {
+        if (s.layout == HIDVAE_GEMM_NT) {
+            if (s.deep) direct32_body<HIDVAE_GEMM_NT, 6>(s.g, s.split, tile0, s.nt, s.nbx, part);
+            else direct32_body<HIDVAE_GEMM_NT, 3>(s.g, s.split, tile0, s.nt, s.nbx, part);
+        } else if (s.layout == HIDVAE_GEMM_NN) {
+            if (s.deep) direct32_body<HIDVAE_GEMM_NN, 6>(s.g, s.split, tile0, s.nt, s.nbx, part);
+            else direct32_body<HIDVAE_GEMM_NN, 3>(s.g, s.split, tile0, s.nt, s.nbx, part);
+        } else direct32_body<HIDVAE_GEMM_TN, 3>(s.g, s.split, tile0, s.nt, s.nbx, part);
+    }
+}
+
+// The same group on the LDS-tiled kernel (64x64 workgroup tiles, one unsplit ORDER-G chain per output): chosen when the group as a
+// whole has enough 64x64 tiles to occupy the chip -- a single problem of a tag head does not (1024 x 768 outputs are 192 tiles for
+// 256 CUs, which is why hidvae_gemm_f32 keeps such problems on the direct kernels), three levels together do.  Sub-problem fields
+// reused: nbx = column tiles, nt = tiles, nb = workgroups (= tiles); kind 2 = column sums as above.
+__global__ __launch_bounds__(256) void gemm_group_tiled_kernel(GroupArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2 * BK * 68];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * 68];
+    int bid = blockIdx.x, p = 0;
+    while (p + 1 < a.n && bid >= a.s[p].nb) {
+        bid -= a.s[p].nb;
+        p++;
+    }
+    const GroupSub &s = a.s[p];
+    if (s.kind == 2) {
+        colsum_group_body(s.g, (int64_t)bid * 32, As);
+        return;
+    }
+    const int nby = (int)(s.nt / s.nbx);
+    const int bx = bid % s.nbx, by = bid / s.nbx;
+    if (s.layout == HIDVAE_GEMM_NT) tile_body<2, 2, HIDVAE_GEMM_NT>(s.g, bx, by, s.nbx, nby, 0, As, Bs);
+    else if (s.layout == HIDVAE_GEMM_NN) tile_body<2, 2, HIDVAE_GEMM_NN>(s.g, bx, by, s.nbx, nby, 0, As, Bs);
+    else tile_body<2, 2, HIDVAE_GEMM_TN>(s.g, bx, by, s.nbx, nby, 0, As, Bs);
+}
+
+inline void group_tiled_sub(GroupSub &s, int layout, const GemmArgs &g) {
+    s.g = g;
+    s.g.k_per_split = hv_cdiv(g.K, BK) * BK;
+    s.g.partial = nullptr;
+    s.g.vecA = (g.lda % 4 == 0) && aligned16(g.A);
+    s.g.vecB = (g.ldb % 4 == 0) && aligned16(g.B);
+    s.layout = layout;
+    s.kind = 3;
+    s.split = 1;
+    s.deep = 0;
+    s.nbx = (int)hv_cdiv(g.N, 64);
+    s.nt = (int64_t)s.nbx * hv_cdiv(g.M, 64);
+    s.nb = (int)s.nt;
+}
+
+// fill one GEMM sub-problem with the group's dispatch rule; false: the problem is outside the direct kernels' regime
+inline bool group_gemm_sub(GroupSub &s, int layout, const GemmArgs &g) {
+    if (!fits32bit(layout, g.M, g.N, g.K, g.lda, g.ldb) || hv_cdiv(g.M, 32) * hv_cdiv(g.N, 32) >= 2048) return false;
+    s.g = g;
+    s.layout = layout;
+    const bool f16 = use_direct16(g.M, g.N, g.K);
+    s.kind = f16 ? 0 : 1;
+    int sp = f16 ? pick_split16(g.M, g.N, g.K, 0) : pick_split32(g.M, g.N, g.K, 0);
+    static const int cap = getenv("HIDVAE_GROUP_SPLIT_CAP") ? atoi(getenv("HIDVAE_GROUP_SPLIT_CAP")) : 4;
+    if (sp > GROUP_WAVES) sp = GROUP_WAVES;
+    while (sp > cap && sp > 1) sp /= 2;
+    s.split = sp;
+    s.deep = g.K / (16 * sp) >= 12;
+    const int T = f16 ? 16 : 32;
+    s.nbx = (int)hv_cdiv(g.N, T);
+    s.nt = (int64_t)s.nbx * hv_cdiv(g.M, T);
+    s.nb = (int)hv_cdiv(s.nt, GROUP_WAVES / sp);
+    return true;
+}
+
+inline int launch_group(GroupArgs &a, hipStream_t s) {
+    // 64x64 tiles of the whole group: at >= GROUP_TILED_MIN of them the LDS-tiled form keeps every CU busy with long unsplit chains
+    int64_t t64 = 0;
+    for (int i = 0; i < a.n; i++)
+        if (a.s[i].kind != 2) t64 += hv_cdiv(a.s[i].g.M, 64) * hv_cdiv(a.s[i].g.N, 64);
+    static const int64_t tiled_min = getenv("HIDVAE_GROUP_TILED_MIN") ? atoll(getenv("HIDVAE_GROUP_TILED_MIN")) : 1000000;
+    const bool tiled = t64 >= tiled_min;
+    if (tiled)
+        for (int i = 0; i < a.n; i++)
+            if (a.s[i].kind != 2) {
+                const GemmArgs g = a.s[i].g;
+                group_tiled_sub(a.s[i], a.s[i].layout, g);
+            }
+    int64_t blocks = 0;
+    for (int i = 0; i < a.n; i++) blocks += a.s[i].nb;
+    if (blocks == 0) return HIDVAE_OK;
+    if (tiled) hipLaunchKernelGGL(gemm_group_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gemm_group_kernel, dim3((unsigned)blocks), dim3(64 * GROUP_WAVES), 0, s, a);
+    HV_LAUNCH_CHECK("gemm_group");
+    return HIDVAE_OK;
+}
+
 }  // namespace
 
 extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
@@ -1004,4 +1178,79 @@ extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, 
                        accumulate);
     HV_LAUNCH_CHECK("colsum_final");
     return HIDVAE_OK;
+}
+
+
+// ---- grouped entry points (see gemm_group_kernel) -----------------------------------------------------------------------------
+extern "C" int hidvae_gemm_group(const hidvae_gemm_problem *pr, int n, void *stream) {
+    HV_REQUIRE(pr != nullptr && n >= 1, "gemm_group: bad arguments");
+    GroupArgs a{};
+    bool ok = n <= GROUP_MAX;
+    for (int i = 0; i < n && ok; i++) {
+        const hidvae_gemm_problem &q = pr[i];
+        HV_REQUIRE(q.layout >= 0 && q.layout <= 2 && q.M >= 1 && q.N >= 1 && q.K >= 1 && q.A && q.B && q.C, "gemm_group: problem %d is malformed", i);
+        const int64_t a_min = (q.layout == HIDVAE_GEMM_TN) ? q.M : q.K, b_min = (q.layout == HIDVAE_GEMM_NT) ? q.K : q.N;
+        HV_REQUIRE(q.lda >= a_min && q.ldb >= b_min && q.ldc >= q.N, "gemm_group: problem %d: leading dimension too small", i);
+        HV_REQUIRE(q.epilogue < HIDVAE_EPI_DSILU || (q.aux != nullptr && q.ldaux >= q.N), "gemm_group: problem %d: backward epilogue needs aux", i);
+        HV_REQUIRE(q.mask == nullptr || q.ldmask >= q.N, "gemm_group: problem %d: ldmask", i);
+        GemmArgs g{};
+        g.M = q.M; g.N = q.N; g.K = q.K; g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.bias = q.bias; g.C = q.C; g.ldc = q.ldc;
+        g.epilogue = q.epilogue; g.aux = q.aux; g.ldaux = q.aux ? q.ldaux : 0; g.accumulate = q.accumulate;
+        g.mask = q.mask; g.ldmask = q.ldmask; g.mask_scale = q.mask_scale;
+        ok = group_gemm_sub(a.s[i], q.layout, g);
+    }
+    if (!ok) {  // outside the grouped regime (large batch, or too many problems): one launch per problem, same results as always
+        for (int i = 0; i < n; i++) {
+            const hidvae_gemm_problem &q = pr[i];
+            const int rc = hidvae_gemm_f32(q.layout, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.bias, q.C, q.ldc, q.epilogue, q.aux, q.ldaux, q.mask,
+                                           q.ldmask, q.mask_scale, 0, q.workspace, q.accumulate, stream);
+            if (rc != HIDVAE_OK) return rc;
+        }
+        return HIDVAE_OK;
+    }
+    a.n = n;
+    return launch_group(a, (hipStream_t)stream);
+}
+
+extern "C" int hidvae_linear_bwd_group(const hidvae_linear_bwd_problem *pr, int n, void *stream) {
+    HV_REQUIRE(pr != nullptr && n >= 1, "linear_bwd_group: bad arguments");
+    GroupArgs a{};
+    int k = 0;
+    bool ok = true;
+    for (int i = 0; i < n && ok; i++) {
+        const hidvae_linear_bwd_problem &q = pr[i];
+        HV_REQUIRE(q.g && q.x && q.dW && q.B >= 1 && q.n_out >= 1 && q.n_in >= 1, "linear_bwd_group: problem %d is malformed", i);
+        HV_REQUIRE(q.ldg >= q.n_out && q.ldx >= q.n_in && q.lddw >= q.n_in, "linear_bwd_group: problem %d: leading dimension too small", i);
+        HV_REQUIRE(q.dX == nullptr || (q.W != nullptr && q.ldw >= q.n_in && q.lddx >= q.n_in), "linear_bwd_group: problem %d: dX needs W", i);
+        HV_REQUIRE(q.dX == nullptr || q.dx_epilogue == HIDVAE_EPI_NONE || (q.dx_epilogue >= HIDVAE_EPI_DSILU && q.aux != nullptr && q.ldaux >= q.n_in),
+                   "linear_bwd_group: problem %d: dX epilogue %d", i, q.dx_epilogue);
+        if (k + 3 > GROUP_MAX) { ok = false; break; }
+        GemmArgs g0{};  // dW [n_out, n_in] = g^T x : TN with M = n_out, N = n_in, K = B
+        g0.M = q.n_out; g0.N = q.n_in; g0.K = q.B; g0.A = q.g; g0.lda = q.ldg; g0.B = q.x; g0.ldb = q.ldx; g0.C = q.dW; g0.ldc = q.lddw;
+        g0.epilogue = HIDVAE_EPI_NONE; g0.mask_scale = 1.0f; g0.accumulate = q.accumulate_dw;
+        ok = group_gemm_sub(a.s[k++], HIDVAE_GEMM_TN, g0);
+        if (ok && q.dX != nullptr) {  // dX [B, n_in] = g W : NN with M = B, N = n_in, K = n_out
+            GemmArgs g1{};
+            g1.M = q.B; g1.N = q.n_in; g1.K = q.n_out; g1.A = q.g; g1.lda = q.ldg; g1.B = q.W; g1.ldb = q.ldw; g1.C = q.dX; g1.ldc = q.lddx;
+            g1.epilogue = q.dx_epilogue; g1.aux = q.aux; g1.ldaux = q.aux ? q.ldaux : 0; g1.mask_scale = 1.0f;
+            ok = group_gemm_sub(a.s[k++], HIDVAE_GEMM_NN, g1);
+        }
+        if (ok && q.db != nullptr) {
+            GroupSub &c = a.s[k++];
+            c.kind = 2;
+            c.g.A = q.g; c.g.lda = q.ldg; c.g.M = q.B; c.g.N = q.n_out; c.g.C = q.db; c.g.accumulate = q.accumulate_db;
+            c.nb = (int)hv_cdiv(q.n_out, 32);
+        }
+    }
+    if (!ok) {
+        for (int i = 0; i < n; i++) {
+            const hidvae_linear_bwd_problem &q = pr[i];
+            const int rc = hidvae_linear_bwd(q.g, q.ldg, q.x, q.ldx, q.W, q.ldw, q.B, q.n_out, q.n_in, q.dW, q.lddw, q.accumulate_dw, q.dX, q.lddx,
+                                             q.dx_epilogue, q.aux, q.ldaux, q.db, q.accumulate_db, q.workspace, stream);
+            if (rc != HIDVAE_OK) return rc;
+        }
+        return HIDVAE_OK;
+    }
+    a.n = k;
+    return launch_group(a, (hipStream_t)stream);
 }

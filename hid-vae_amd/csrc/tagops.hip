@@ -30,6 +30,34 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const floa
     }
 }
 
+struct ActGroupArgs {
+    int n;
+    int nb[4];
+    hidvae_act_bwd_problem p[4];
+};
+__global__ __launch_bounds__(256) void act_bwd_group_kernel(ActGroupArgs a) {
+    int bid = blockIdx.x, p = 0;
+    while (p + 1 < a.n && bid >= a.nb[p]) {
+        bid -= a.nb[p];
+        p++;
+    }
+    const hidvae_act_bwd_problem &q = a.p[p];
+    const int nb = a.nb[p];
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < q.numel; i += (int64_t)nb * 256) {
+        float v = q.g[i];
+        const float r = q.ref != nullptr ? q.ref[i] : 0.0f;
+        const float ms = q.mask != nullptr ? q.mask[i] * q.mask_scale : 1.0f;
+        switch (q.act) {
+            case HIDVAE_EPI_RELU: v = r > 0.0f ? v * (q.mask != nullptr ? q.mask_scale : 1.0f) : 0.0f; break;
+            case HIDVAE_EPI_GELU: v = v * hv_dgelu(r) * ms; break;
+            case HIDVAE_EPI_SIGMOID: v = v * (r * (1.0f - r)) * ms; break;
+            case HIDVAE_EPI_SILU: v = v * hv_dsilu(r) * ms; break;
+            default: v = v * ms; break;
+        }
+        q.out[i] = v;
+    }
+}
+
 // out = a * b  (op 0)  or  a + b  (op 1), elementwise, row strides allowed
 __global__ __launch_bounds__(256) void mul_kernel(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M, int64_t N,
                                                   float *out, int64_t ldo, int op) {
@@ -66,11 +94,11 @@ __global__ __launch_bounds__(256) void sum_prefix_slices_kernel(SliceArgs a) {
 // LayerNorm (biased variance) + optional ReLU + dropout mask + residual:  y = drop(relu(LN(x))) + res
 // ------------------------------------------------------------------------------------------------
 template <bool RESIDENT>  // RESIDENT: N <= 1024, the row is read once and kept in registers between the three passes
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *x, int64_t M, int64_t N, const float *gamma,
-                                                            const float *beta, float eps, float *y, float *mean, float *rstd,
-                                                            int relu, const float *mask, float scale, const float *res) {
+__device__ __forceinline__ void layernorm_fwd_body(int64_t blk, const float *x, int64_t M, int64_t N, const float *gamma,
+                                                   const float *beta, float eps, float *y, float *mean, float *rstd,
+                                                   int relu, const float *mask, float scale, const float *res) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = blk * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float *xr = x + row * N;
     float xv[RESIDENT ? 16 : 1];
@@ -120,6 +148,34 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *x, int6
         }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <bool RESIDENT>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *x, int64_t M, int64_t N, const float *gamma,
+                                                            const float *beta, float eps, float *y, float *mean, float *rstd,
+                                                            int relu, const float *mask, float scale, const float *res) {
+    layernorm_fwd_body<RESIDENT>((int64_t)blockIdx.x, x, M, N, gamma, beta, eps, y, mean, rstd, relu, mask, scale, res);
+}
+
+// grouped launches (the same LayerNorm of several tag-head levels in one grid): sub-problem p owns nb[p] consecutive workgroups
+constexpr int TAG_GROUP_MAX = 4;
+struct LnGroupArgs {
+    int n;
+    int nb[TAG_GROUP_MAX];
+    hidvae_layernorm_problem p[TAG_GROUP_MAX];
+};
+__device__ __forceinline__ int group_find(const int *nb, int n, int &bid) {
+    int p = 0;
+    while (p + 1 < n && bid >= nb[p]) {
+        bid -= nb[p];
+        p++;
+    }
+    return p;
+}
+__global__ __launch_bounds__(256) void layernorm_fwd_group_kernel(LnGroupArgs a) {
+    int bid = blockIdx.x;
+    const hidvae_layernorm_problem &q = a.p[group_find(a.nb, a.n, bid)];
+    layernorm_fwd_body<true>((int64_t)bid, q.x, q.M, q.N, q.gamma, q.beta, q.eps, q.y, q.mean, q.rstd, q.relu, q.keep_mask, q.keep_scale, q.residual);
 }
 
 // gh = gy * mask*scale * (h > 0 if relu), h = xhat*gamma+beta;  dy = gh*gamma
@@ -193,10 +249,10 @@ __global__ __launch_bounds__(256) void layernorm_param_partial_kernel(const floa
 // the four waves' sums are combined in LDS and written as one partial per workgroup (summed by layernorm_param_final_kernel in
 // ascending order).  N <= 64*LNF_NV.
 constexpr int LNF_ROWS = 4, LNF_NV = 16;  // one row per wave: rows in flight, not in sequence, hide the two dependent phases
-__global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *gy, const float *x, const float *gamma, const float *beta,
-                                                                  const float *mean, const float *rstd, int64_t M, int64_t N, int relu,
-                                                                  const float *mask, float scale, float *gx, float *part) {
-    __shared__ float red[2][3][64 * LNF_NV];
+__device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*red)[3][64 * LNF_NV], const float *gy, const float *x,
+                                                         const float *gamma, const float *beta, const float *mean, const float *rstd,
+                                                         int64_t M, int64_t N, int relu, const float *mask, float scale, float *gx,
+                                                         float *part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ga[LNF_NV], be[LNF_NV], sg[LNF_NV], sb[LNF_NV];
 #pragma unroll
@@ -208,7 +264,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *g
         sb[j] = 0.0f;
     }
     for (int rr = wave; rr < LNF_ROWS; rr += 4) {
-        const int64_t row = (int64_t)blockIdx.x * LNF_ROWS + rr;
+        const int64_t row = blk * LNF_ROWS + rr;
         if (row >= M) break;
         const float mu = mean[row], rs = rstd[row];
         float g[LNF_NV], xh[LNF_NV];
@@ -254,20 +310,33 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *g
         for (int j = 0; j < LNF_NV; j++) {
             const int64_t c = lane + 64 * j;
             if (c < N) {
-                part[((int64_t)blockIdx.x * 2 + 0) * N + c] = (sg[j] + red[0][0][c]) + (red[0][1][c] + red[0][2][c]);
-                part[((int64_t)blockIdx.x * 2 + 1) * N + c] = (sb[j] + red[1][0][c]) + (red[1][1][c] + red[1][2][c]);
+                part[(blk * 2 + 0) * N + c] = (sg[j] + red[0][0][c]) + (red[0][1][c] + red[0][2][c]);
+                part[(blk * 2 + 1) * N + c] = (sb[j] + red[1][0][c]) + (red[1][1][c] + red[1][2][c]);
             }
         }
     }
 }
 
+__global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *gy, const float *x, const float *gamma, const float *beta,
+                                                                  const float *mean, const float *rstd, int64_t M, int64_t N, int relu,
+                                                                  const float *mask, float scale, float *gx, float *part) {
+    __shared__ float red[2][3][64 * LNF_NV];
+    layernorm_bwd_fused_body((int64_t)blockIdx.x, red, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, part);
+}
+__global__ __launch_bounds__(256) void layernorm_bwd_fused_group_kernel(LnGroupArgs a) {
+    __shared__ float red[2][3][64 * LNF_NV];
+    int bid = blockIdx.x;
+    const hidvae_layernorm_problem &q = a.p[group_find(a.nb, a.n, bid)];
+    layernorm_bwd_fused_body((int64_t)bid, red, q.gy, q.x, q.gamma, q.beta, q.mean, q.rstd, q.M, q.N, q.relu, q.keep_mask, q.keep_scale, q.gx,
+                             q.workspace);
+}
+
 // 32 columns x 32 chunk groups per workgroup: group q adds chunks q, q+32, ... in ascending order, then the groups are added
 // in ascending order (the fused backward leaves one partial per 4 rows, so depth matters more than work here)
-__global__ __launch_bounds__(1024) void layernorm_param_final_kernel(const float *part, int64_t chunks, int64_t N, float *ggamma,
-                                                                     float *gbeta, int accumulate) {
-    __shared__ float red[2][32][33];
+__device__ __forceinline__ void layernorm_param_final_body(int64_t blk, float (*red)[32][33], const float *part, int64_t chunks, int64_t N,
+                                                           float *ggamma, float *gbeta, int accumulate) {
     const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
-    const int64_t n = (int64_t)blockIdx.x * 32 + c;
+    const int64_t n = blk * 32 + c;
     float a = 0.0f, b = 0.0f;
     if (n < N)
         for (int64_t k0 = q; k0 < chunks; k0 += 8 * 32) {  // eight chunks' loads in flight, added in the same ascending order
@@ -290,6 +359,18 @@ __global__ __launch_bounds__(1024) void layernorm_param_final_kernel(const float
         float *dst = q == 0 ? ggamma : gbeta;
         dst[n] = accumulate ? dst[n] + v : v;
     }
+}
+
+__global__ __launch_bounds__(1024) void layernorm_param_final_kernel(const float *part, int64_t chunks, int64_t N, float *ggamma,
+                                                                     float *gbeta, int accumulate) {
+    __shared__ float red[2][32][33];
+    layernorm_param_final_body((int64_t)blockIdx.x, red, part, chunks, N, ggamma, gbeta, accumulate);
+}
+__global__ __launch_bounds__(1024) void layernorm_param_final_group_kernel(LnGroupArgs a) {
+    __shared__ float red[2][32][33];
+    int bid = blockIdx.x;
+    const hidvae_layernorm_problem &q = a.p[group_find(a.nb, a.n, bid)];
+    layernorm_param_final_body((int64_t)bid, red, q.workspace, (q.M + LNF_ROWS - 1) / LNF_ROWS, q.N, q.ggamma, q.gbeta, q.accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1152,5 +1233,85 @@ extern "C" int hidvae_tag_loss_bwd(const float *dmix, const float *dkl, const in
     hipLaunchKernelGGL(tag_loss_bwd_kernel, dim3(ew_grid(B * C)), dim3(256), 0, (hipStream_t)stream, dmix, dkl, target, inverse, lam_dev, B,
                        C, g_dev, n_valid, g_logits);
     HV_LAUNCH_CHECK("tag_loss_bwd");
+    return HIDVAE_OK;
+}
+
+
+// ---- grouped entry points: the same op of several tag-head levels in one launch (see include/hidvae.h) ------------------------------
+extern "C" int hidvae_act_bwd_group(const hidvae_act_bwd_problem *pr, int n, void *stream) {
+    HV_REQUIRE(pr != nullptr && n >= 1 && n <= 4, "act_bwd_group: 1..4 problems");
+    ActGroupArgs a{};
+    a.n = n;
+    unsigned blocks = 0;
+    for (int i = 0; i < n; i++) {
+        HV_REQUIRE(pr[i].g && pr[i].out && pr[i].numel >= 1, "act_bwd_group: problem %d is malformed", i);
+        a.p[i] = pr[i];
+        a.nb[i] = (int)ew_grid(pr[i].numel);
+        blocks += (unsigned)a.nb[i];
+    }
+    hipLaunchKernelGGL(act_bwd_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("act_bwd_group");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_layernorm_fwd_group(const hidvae_layernorm_problem *pr, int n, void *stream) {
+    HV_REQUIRE(pr != nullptr && n >= 1 && n <= TAG_GROUP_MAX, "layernorm_fwd_group: 1..4 problems");
+    LnGroupArgs a{};
+    a.n = n;
+    unsigned blocks = 0;
+    bool resident = true;
+    for (int i = 0; i < n; i++) {
+        const hidvae_layernorm_problem &q = pr[i];
+        HV_REQUIRE(q.x && q.gamma && q.beta && q.y && q.mean && q.rstd && q.M >= 1 && q.N >= 1, "layernorm_fwd_group: problem %d is malformed", i);
+        resident = resident && q.N <= 1024;
+        a.p[i] = q;
+        a.nb[i] = (int)hv_cdiv(q.M, 4);
+        blocks += (unsigned)a.nb[i];
+    }
+    if (!resident) {  // rows too wide for the register-resident form: one launch per problem
+        for (int i = 0; i < n; i++) {
+            const hidvae_layernorm_problem &q = pr[i];
+            const int rc = hidvae_layernorm_fwd(q.x, q.M, q.N, q.gamma, q.beta, q.eps, q.y, q.mean, q.rstd, q.relu, q.keep_mask, q.keep_scale,
+                                                q.residual, stream);
+            if (rc != HIDVAE_OK) return rc;
+        }
+        return HIDVAE_OK;
+    }
+    hipLaunchKernelGGL(layernorm_fwd_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("layernorm_fwd_group");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_layernorm_bwd_all_group(const hidvae_layernorm_problem *pr, int n, void *stream) {
+    HV_REQUIRE(pr != nullptr && n >= 1 && n <= TAG_GROUP_MAX, "layernorm_bwd_all_group: 1..4 problems");
+    LnGroupArgs a{}, f{};
+    a.n = f.n = n;
+    unsigned blocks = 0, fblocks = 0;
+    bool resident = true;
+    for (int i = 0; i < n; i++) {
+        const hidvae_layernorm_problem &q = pr[i];
+        HV_REQUIRE(q.gy && q.x && q.gamma && q.beta && q.mean && q.rstd && q.ggamma && q.gbeta && q.workspace && q.M >= 1 && q.N >= 1,
+                   "layernorm_bwd_all_group: problem %d is malformed", i);
+        resident = resident && q.N <= 64 * LNF_NV;
+        a.p[i] = f.p[i] = q;
+        a.nb[i] = (int)hv_cdiv(q.M, LNF_ROWS);
+        f.nb[i] = (int)hv_cdiv(q.N, 32);
+        blocks += (unsigned)a.nb[i];
+        fblocks += (unsigned)f.nb[i];
+    }
+    if (!resident) {
+        for (int i = 0; i < n; i++) {
+            const hidvae_layernorm_problem &q = pr[i];
+            const int rc = hidvae_layernorm_bwd_all(q.gy, q.x, q.gamma, q.beta, q.mean, q.rstd, q.M, q.N, q.relu, q.keep_mask, q.keep_scale, q.gx,
+                                                    q.ggamma, q.gbeta, q.accumulate, q.workspace, stream);
+            if (rc != HIDVAE_OK) return rc;
+        }
+        return HIDVAE_OK;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(layernorm_bwd_fused_group_kernel, dim3(blocks), dim3(256), 0, s, a);
+    HV_LAUNCH_CHECK("layernorm_bwd_fused_group");
+    hipLaunchKernelGGL(layernorm_param_final_group_kernel, dim3(fblocks), dim3(1024), 0, s, f);
+    HV_LAUNCH_CHECK("layernorm_param_final_group");
     return HIDVAE_OK;
 }

@@ -169,6 +169,116 @@ class TagPredLossFn(Function):
         return (_C.tag_loss_bwd(dmix, dkl, target, inverse, lam, g.contiguous(), nv),) + (None,) * 9
 
 
+class GroupLinearFn(Function):
+    """The same Linear layer of several heads in ONE launch each way (hidvae_gemm_group / hidvae_linear_bwd_group).
+    apply(cfgs, *flat) with cfgs = [(act, keep_scale)] per problem and flat = (x, w, b, keep_mask) per problem -> tuple of y.
+    Per problem exactly LinearFn's arithmetic: y = act(x W^T + b) [* mask * scale]; backward g' = g * act'(.) * mask*scale (one
+    grouped elementwise launch for the problems that need it), then every dW / dX / db of the group from one grid."""
+
+    @staticmethod
+    def forward(ctx, cfgs, *flat):
+        ctx.set_materialize_grads(False)
+        n = len(cfgs)
+        probs, pres = [], []
+        for i, (act, scale) in enumerate(cfgs):
+            x, w, b, mask = flat[4 * i: 4 * i + 4]
+            need = any(ctx.needs_input_grad[1 + 4 * i: 1 + 4 * i + 3])
+            pre = None
+            if need and act in (_C.EPI_SILU, _C.EPI_GELU):
+                pre = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32)
+            pres.append(pre)
+            probs.append(dict(layout=_C.GEMM_NT, A=x, B=w, bias=b, epilogue=act, aux=pre, mask=mask, mask_scale=scale))
+        ys = _C.gemm_group(probs)
+        ctx.cfgs = cfgs
+        ctx.params = [(flat[4 * i + 1], flat[4 * i + 2]) for i in range(n)]  # (the objects: a flat-gradient slot hangs off the Parameter)
+        ctx.need_x = [ctx.needs_input_grad[1 + 4 * i] for i in range(n)]
+        saved = []
+        for i in range(n):
+            x, w, b, mask = flat[4 * i: 4 * i + 4]
+            saved += [x, w, pres[i] if pres[i] is not None else ys[i], mask]
+        ctx.save_for_backward(*saved)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        from .ops import grad_sink
+        n = len(ctx.cfgs)
+        saved = ctx.saved_tensors
+        live = [i for i in range(n) if gs[i] is not None]
+        g = {i: gs[i].contiguous() for i in live}
+        todo = [i for i in live if ctx.cfgs[i][0] != _C.EPI_NONE or saved[4 * i + 3] is not None]
+        if todo:
+            outs = _C.act_bwd_group([(g[i], saved[4 * i + 2], ctx.cfgs[i][0], saved[4 * i + 3], ctx.cfgs[i][1]) for i in todo])
+            for i, o in zip(todo, outs):
+                g[i] = o
+        probs, sinks = [], []
+        for i in live:
+            x, w = saved[4 * i], saved[4 * i + 1]
+            wp, bp = ctx.params[i]
+            dst, acc = grad_sink(wp)
+            pr = dict(g=g[i], x=x, w=w, need_dx=ctx.need_x[i], dW=dst, accumulate=acc)
+            bdst = None
+            if bp is not None:
+                bdst, bacc = grad_sink(bp)
+                pr.update(bias=True, db=bdst, accumulate_db=bacc)
+            probs.append(pr)
+            sinks.append((dst is not None, bdst is not None))
+        res = _C.linear_bwd_group(probs) if probs else []
+        out = [None] * (1 + 4 * n)
+        for i, (dW, dX, db), (wsunk, bsunk) in zip(live, res, sinks):
+            out[1 + 4 * i] = dX
+            out[2 + 4 * i] = None if wsunk else dW
+            out[3 + 4 * i] = None if (bsunk or ctx.params[i][1] is None) else db
+        return tuple(out)
+
+
+class GroupLayerNormFn(Function):
+    """LayerNormFn for several heads at once: y = dropout(relu?(LN(x))) + residual, one launch forward, two backward.
+    apply(cfgs, *flat): cfgs = [(eps, relu, mask_scale)], flat = (x, gamma, beta, keep_mask, residual) per problem."""
+
+    @staticmethod
+    def forward(ctx, cfgs, *flat):
+        ctx.set_materialize_grads(False)
+        n = len(cfgs)
+        outs = _C.layernorm_fwd_group([(flat[5 * i], flat[5 * i + 1], flat[5 * i + 2], cfgs[i][0], cfgs[i][1], flat[5 * i + 3], cfgs[i][2],
+                                        flat[5 * i + 4]) for i in range(n)])
+        saved = []
+        for i in range(n):
+            saved += [flat[5 * i], flat[5 * i + 1], flat[5 * i + 2], outs[i][1], outs[i][2], flat[5 * i + 3]]
+        ctx.save_for_backward(*saved)
+        ctx.cfgs = cfgs
+        ctx.params = [(flat[5 * i + 1], flat[5 * i + 2]) for i in range(n)]
+        ctx.has_res = [flat[5 * i + 4] is not None for i in range(n)]
+        ctx.need_x = [ctx.needs_input_grad[1 + 5 * i] for i in range(n)]
+        return tuple(o[0] for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        from .ops import grad_sink
+        n = len(ctx.cfgs)
+        saved = ctx.saved_tensors
+        live = [i for i in range(n) if gys[i] is not None]
+        probs, sunk, gyc = [], [], {}
+        for i in live:
+            x, gamma, beta, mean, rstd, mask = saved[6 * i: 6 * i + 6]
+            gyc[i] = gys[i].contiguous()
+            gdst, gacc = grad_sink(ctx.params[i][0])
+            bdst, bacc = grad_sink(ctx.params[i][1])
+            if gdst is None or bdst is None or gacc != bacc:
+                gdst = bdst = None
+            probs.append(dict(gy=gyc[i], x=x, gamma=gamma, beta=beta, mean=mean, rstd=rstd, relu=ctx.cfgs[i][1], mask=mask,
+                              mask_scale=ctx.cfgs[i][2], need_gx=ctx.need_x[i], gg=gdst, gb=bdst, accumulate=gacc))
+            sunk.append(gdst is not None)
+        res = _C.layernorm_bwd_all_group(probs) if probs else []
+        out = [None] * (1 + 5 * n)
+        for i, (gx, gg, gb), sk in zip(live, res, sunk):
+            out[1 + 5 * i] = gx
+            out[2 + 5 * i] = None if sk else gg
+            out[3 + 5 * i] = None if sk else gb
+            out[5 + 5 * i] = gyc[i] if ctx.has_res[i] else None
+        return tuple(out)
+
+
 # ------------------------------------------------------------------------------------------------ compositions
 def _lin(x, m, act=_C.EPI_NONE, mask=None, scale=1.0):
     return LinearFn.apply(x, m.weight, m.bias, act, mask, scale)
@@ -265,8 +375,113 @@ def _tag_streams(device, n):
     return st
 
 
+def _glin(xs, mods, act=_C.EPI_NONE, masks=None, scales=None):
+    """the same Linear of every head in one launch: xs / mods / masks lists over the heads"""
+    n = len(xs)
+    masks = masks or [None] * n
+    scales = scales or [1.0] * n
+    flat = []
+    for x, m, k in zip(xs, mods, masks):
+        flat += [x, m.weight, m.bias, k]
+    return list(GroupLinearFn.apply([(act, sc) for sc in scales], *flat))
+
+
+def _glin_norm_relu_drop(xs, lins, norms, masks, scales):
+    """Linear -> (LayerNorm) -> ReLU -> Dropout of every head: two grouped launches (GEMM+bias, LN+ReLU+mask) or one"""
+    if isinstance(norms[0], nn.LayerNorm):
+        hs = _glin(xs, lins)
+        flat = []
+        for h, nm, k in zip(hs, norms, masks):
+            flat += [h, nm.weight, nm.bias, k, None]
+        return list(GroupLayerNormFn.apply([(nm.eps, True, sc) for nm, sc in zip(norms, scales)], *flat))
+    return _glin(xs, lins, _C.EPI_RELU, masks, scales)
+
+
+def tag_heads_forward_grouped(model, emb_cat, tags_emb, tags_indices):
+    """tag_heads_forward with the L levels advanced in LOCKSTEP on one stream: every layer position is ONE grouped launch for all
+    levels (hidvae_gemm_group / hidvae_linear_bwd_group / hidvae_layernorm_*_group) instead of one launch per level.  The levels'
+    heads are structurally identical chains of different widths (h_rqvae.py:108-227, 322-331), small problems whose launch and
+    drain latencies then hide under the widest level's arithmetic.  Random draws are requested level by level in the reference's
+    order first (dropout masks in forward order, then the mixup pairing), so injected / replayed randomness is unchanged."""
+    L, D = model.n_layers, model.embed_dim
+    rand = model._rand()
+    training = model.training
+    B = emb_cat.shape[0]
+    dev = emb_cat.device
+    views = ConcatViewsFn.apply(emb_cat, L, D, 3)
+    te = tags_emb.reshape(B, -1)
+    E = model.tag_embed_dim
+    lm = model.tag_prediction_loss
+    preds_m, projs_m = list(model.tag_predictors), list(model.tag_projectors)
+    if training and torch.is_grad_enabled() and lm.use_mixup and B > 1 and hasattr(rand, "prepare_mixup"):
+        rand.prepare_mixup(tags_indices[:, :L], dev)
+    # ---- the step's random draws, level by level in the reference's order
+    plan = []
+    for i in range(L):
+        pj, pd = projs_m[i], preds_m[i]
+        p = pd.dropout_p
+        mid, hid, half = pd.residual_block1[0].out_features, pd.feature_extractor[0].out_features, pd.classifier[4].out_features
+        sites = [("proj", pj[0].out_features, pj[3].p), ("fe", hid, p), ("rb1a", mid, p), ("rb1b", hid, p), ("rb2a", mid, p), ("rb2b", hid, p),
+                 ("cla", mid, p), ("clb", half, p * 0.5)]
+        plan.append({name: _mask(rand, (B, width), pp, dev, training) for name, width, pp in sites})
+    mk = lambda name: ([plan[i][name][0] for i in range(L)], [plan[i][name][1] for i in range(L)])
+    # ---- projectors (Linear -> BatchNorm1d -> ReLU -> Dropout -> Linear -> LayerNorm)
+    tes = [te[:, i * E:(i + 1) * E] for i in range(L)]
+    masks, scales = mk("proj")
+    if isinstance(projs_m[0][1], nn.BatchNorm1d):
+        hs = _glin(tes, [pj[0] for pj in projs_m])
+        hs = [BatchNormFn.apply(h, pj[1].weight, pj[1].bias, pj[1].running_mean, pj[1].running_var, pj[1].num_batches_tracked, pj[1].momentum,
+                                pj[1].eps, training, True, k, sc) for h, pj, k, sc in zip(hs, projs_m, masks, scales)]
+    else:
+        hs = _glin(tes, [pj[0] for pj in projs_m], _C.EPI_RELU, masks, scales)
+    hs = _glin(hs, [pj[4] for pj in projs_m])
+    if isinstance(projs_m[0][5], nn.LayerNorm):
+        flat = []
+        for h, pj in zip(hs, projs_m):
+            flat += [h, pj[5].weight, pj[5].bias, None, None]
+        hs = list(GroupLayerNormFn.apply([(pj[5].eps, False, 1.0) for pj in projs_m], *flat))
+    aligns = [model.tag_alignment_loss(views[3 * i], hs[i], i) for i in range(L)]
+    # ---- predictors
+    for pd in preds_m:
+        if views[0].dim() != 2:
+            raise RuntimeError("TagPredictor expects [batch, embed_dim]")
+    c_att = [views[3 * i + 1] for i in range(L)]
+    a = _glin(c_att, [pd.attention[0] for pd in preds_m], _C.EPI_RELU)
+    a = _glin(a, [pd.attention[2] for pd in preds_m], _C.EPI_GELU)
+    a = _glin(a, [pd.attention[4] for pd in preds_m], _C.EPI_SIGMOID)
+    hh = [MulFn.apply(views[3 * i + 2], a[i]) for i in range(L)]
+    hh = [L2NormFn.apply(h, 1e-12) if pd.apply_norm else h for h, pd in zip(hh, preds_m)]
+    f = _glin_norm_relu_drop(hh, [pd.feature_extractor[0] for pd in preds_m], [pd.feature_extractor[1] for pd in preds_m], *mk("fe"))
+    for rb_name, ka, kb in (("residual_block1", "rb1a", "rb1b"), ("residual_block2", "rb2a", "rb2b")):
+        rbs = [getattr(pd, rb_name) for pd in preds_m]
+        r = _glin_norm_relu_drop(f, [rb[0] for rb in rbs], [rb[1] for rb in rbs], *mk(ka))
+        r = _glin(r, [rb[4] for rb in rbs], _C.EPI_RELU, *mk(kb))
+        if isinstance(rbs[0][7], nn.LayerNorm):
+            flat = []
+            for ri, rb, fi in zip(r, rbs, f):
+                flat += [ri, rb[7].weight, rb[7].bias, None, fi]  # LN(r) + f in one launch
+            f = list(GroupLayerNormFn.apply([(rb[7].eps, False, 1.0) for rb in rbs], *flat))
+        else:
+            f = [AddFn.apply(fi, ri) for fi, ri in zip(f, r)]
+    cls = [pd.classifier for pd in preds_m]
+    c = _glin_norm_relu_drop(f, [cl[0] for cl in cls], [cl[1] for cl in cls], *mk("cla"))
+    c = _glin(c, [cl[4] for cl in cls], _C.EPI_RELU, *mk("clb"))
+    logits = _glin(c, [cl[7] for cl in cls])
+    preds, accs = [], []
+    for i in range(L):
+        loss, acc = tag_prediction_loss(lm, logits[i], tags_indices[:, i].contiguous(), 0, rand, level=i)
+        preds.append(loss)
+        accs.append(acc)
+    return tuple(aligns) + tuple(preds) + tuple(accs)
+
+
 def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
     """-> tuple (A_0..A_{L-1}, P_0..P_{L-1}, acc_0..acc_{L-1}) of 0-d device tensors."""
+    # HIDVAE_TAG_GROUPED=1: the lockstep form with grouped launches (119 launches per amazon-shaped step instead of 211).  Measured on
+    # MI355X it is NOT faster than the per-level branches below (B=1024: 2.00 vs 1.97 ms; B=2048: 3.24 vs 3.16 ms): these GEMMs are
+    # bound by L2->CU operand traffic (4.5-6 TB/s in every variant, see DESIGN.md), not by launch latency, so it stays opt-in.
+    if os.environ.get("HIDVAE_TAG_GROUPED", "0") == "1" and 1 < model.n_layers <= 4:
+        return tag_heads_forward_grouped(model, emb_cat, tags_emb, tags_indices)
     L, D = model.n_layers, model.embed_dim
     rand = model._rand()
     training = model.training

@@ -104,6 +104,42 @@ int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, 
                       int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
                       void *stream);
 
+/* ---- grouped launches: the SAME layer of several independent heads in one grid (the three tag-head levels of h_rqvae.py:526-549
+ * run structurally identical Linear / LayerNorm chains of different widths).  problems_host: HOST array of n descriptors whose
+ * fields mean exactly what the arguments of hidvae_gemm_f32 (split_k = 0) / hidvae_linear_bwd mean; up to 12 GEMM-class
+ * sub-problems per launch (a backward descriptor counts dW, dX and db separately).  Every sub-problem keeps a fixed summation order
+ * (K shared out over <= 8 waves, partials added in ascending wave order), so results are bit-reproducible run to run; small
+ * problems' launch and drain latencies hide under the large ones' arithmetic.  Outside the direct kernels' regime (a problem with
+ * >= 2048 output tiles, or more sub-problems than fit) the call falls back to one hidvae_gemm_f32 / hidvae_linear_bwd per problem
+ * (`workspace`, optional, is only used there). */
+typedef struct {
+    int layout;
+    int64_t M, N, K;
+    const float *A; int64_t lda;
+    const float *B; int64_t ldb;
+    const float *bias;
+    float *C; int64_t ldc;
+    int epilogue;
+    float *aux; int64_t ldaux;
+    const float *mask; int64_t ldmask; float mask_scale;
+    int accumulate;
+    float *workspace;
+} hidvae_gemm_problem;
+typedef struct {
+    const float *g; int64_t ldg;
+    const float *x; int64_t ldx;
+    const float *W; int64_t ldw;
+    int64_t B, n_out, n_in;
+    float *dW; int64_t lddw; int accumulate_dw;
+    float *dX; int64_t lddx;
+    int dx_epilogue;
+    float *aux; int64_t ldaux;
+    float *db; int accumulate_db;
+    float *workspace;
+} hidvae_linear_bwd_problem;
+int hidvae_gemm_group(const hidvae_gemm_problem *problems_host, int n, void *stream);
+int hidvae_linear_bwd_group(const hidvae_linear_bwd_problem *problems_host, int n, void *stream);
+
 /* out[n] (+)= sum_m X[m,n]   (bias gradients; fixed summation order, bit-reproducible).  One launch for M <= 16384 (no
  * workspace needed, may be NULL); above that two fixed-order passes through workspace >= ceil(M/64)*N floats. */
 int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate,
@@ -298,6 +334,32 @@ int hidvae_layernorm_param_grad(const float *gy, const float *x, const float *ga
 int hidvae_layernorm_bwd_all(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
                              const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask, float keep_scale,
                              float *gx, float *ggamma, float *gbeta, int accumulate, float *workspace, void *stream);
+/* grouped forms of the three ops above (up to 4 problems per launch; fields as the arguments of hidvae_act_bwd /
+ * hidvae_layernorm_fwd / hidvae_layernorm_bwd_all; `workspace` per problem as hidvae_layernorm_bwd_all wants it).  Same arithmetic
+ * and summation order per problem as the single-problem entry points: bit-identical results. */
+typedef struct {
+    const float *g, *ref;
+    int64_t numel;
+    int act;
+    const float *mask; float mask_scale;
+    float *out;
+} hidvae_act_bwd_problem;
+typedef struct {
+    const float *x; int64_t M, N;
+    const float *gamma, *beta; float eps;
+    float *y, *mean, *rstd;          /* forward outputs (mean / rstd are inputs of the backward) */
+    int relu;
+    const float *keep_mask; float keep_scale;
+    const float *residual;           /* forward only */
+    const float *gy;                 /* backward only from here on */
+    float *gx, *ggamma, *gbeta;
+    int accumulate;
+    float *workspace;
+} hidvae_layernorm_problem;
+int hidvae_act_bwd_group(const hidvae_act_bwd_problem *problems_host, int n, void *stream);
+int hidvae_layernorm_fwd_group(const hidvae_layernorm_problem *problems_host, int n, void *stream);
+int hidvae_layernorm_bwd_all_group(const hidvae_layernorm_problem *problems_host, int n, void *stream);
+
 /* BatchNorm1d (h_rqvae.py:325): y = dropout(relu?(BN(x))).  training != 0: batch statistics (biased variance for the
  * normalisation, unbiased for the running update with `momentum`), saved mean / rstd for the backward;
  * training == 0: running statistics.  num_batches_tracked (optional int64 device scalar) is incremented in training.
