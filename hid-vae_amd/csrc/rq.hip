@@ -199,7 +199,12 @@ __device__ __forceinline__ void stage_codes(float *Cs, const FwdArgs &a, int lvl
 // search per wave; results are bit-identical to the unsplit kernel.
 // The level loop for one 16-item tile held as r[8] per lane (see the geometry note at the top): argmin per level, output,
 // loss, residual update, stores of ids / emb_cat / res_cat.  r is consumed; esum and loss are returned in registers.
-template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT, int SW = 4>  // SW: waves that share the codes of one 16-item tile
+// STREAM (code-split, codebooks too large to stay in LDS -- 4 x 1024 x 32 fp32 is 512 KB): no LDS copy of the codes at all.  A code
+// tile is the MFMA A operand, and lane (it, q) needs floats [8q, 8q+8) of code row t+it: two 16-byte loads from the row-major table,
+// 2 KB per 16 codes and wave, fully coalesced, so every wave streams ITS share of the level's codes from L2 straight into MFMA
+// registers (next 32 codes in flight behind the current 16 MFMAs).  16 items per workgroup, i.e. B/16 workgroups instead of B/64
+// staging 131 KB per level each: at B = 4096 the launch fills 256 CUs instead of 64.  Same arithmetic, same merge order: bit-identical.
+template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT, int SW = 4, bool STREAM = false>  // SW: waves that share the codes of one 16-item tile
 __device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, float (*cand_d)[SW][16], int (*cand_i)[SW][16], int &phase,
                                               int wave, int it, int q, int64_t item, bool valid, float (&r)[8], float (&esum)[8],
                                               float &loss, unsigned long long &tuple) {
@@ -212,6 +217,68 @@ __device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, floa
         const float xx = dotQ(r, r);
         float best = INFINITY;
         int bidx = 0;
+        if (STREAM) {
+            const float *cbl = a.cb_eff + (int64_t)i * a.K * D + 8 * q;
+            const float *ccl = a.cc + (int64_t)i * a.K;
+            const int Kp = (int)((a.K + 31) / 32 * 32);
+            const int share = ((Kp / 32 + SW - 1) / SW) * 32;  // codes per wave, a multiple of 32
+            const int t_lo = wave * share, t_hi = (t_lo + share < Kp) ? t_lo + share : Kp;
+            // 128 codes (4 x 32) per step, the NEXT step's 16 row loads in flight behind this step's 64 MFMAs: with one workgroup per
+            // CU nothing else hides the L2 round trip (one 32-code step ahead: 46 us at 4096 x 4 x 1024; this form: see DESIGN.md)
+            float cur[4][2][8], nxt[4][2][8];
+            auto fetch = [&](int t, float (&x)[4][2][8]) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        const int k = t + 32 * u + 16 * hh + it;
+                        if (t + 32 * u < t_hi && k < a.K) load8(cbl + (int64_t)k * D, x[u][hh]);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) x[u][hh][j] = 0.0f;
+                        }
+                    }
+            };
+            fetch(t_lo, cur);
+            for (int t0 = t_lo; t0 < t_hi; t0 += 128) {
+                fetch(t0 + 128, nxt);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + 32 * u;
+                    if (t < t_hi) {
+                        float cc0[4], cc1[4];
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const int k0 = t + 4 * q + g, k1 = t + 16 + 4 * q + g;
+                            cc0[g] = k0 < a.K ? ccl[k0] : INFINITY;
+                            cc1[g] = k1 < a.K ? ccl[k1] : INFINITY;
+                        }
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u][0][j], r[j], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u][1][j], r[j], acc1, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {  // ascending code index inside the lane: strict < keeps the first min
+                            const float d0 = fmaf(-2.0f, acc0[g], xx + cc0[g]);
+                            if (d0 < best) { best = d0; bidx = t + 4 * q + g; }
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const float d1 = fmaf(-2.0f, acc1[g], xx + cc1[g]);
+                            if (d1 < best) { best = d1; bidx = t + 16 + 4 * q + g; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++) cur[u][hh][j] = nxt[u][hh][j];
+            }
+        } else
         for (int c = 0; c < a.nchunks; c++) {
             const float *Cs;
             if (RESIDENT) {
@@ -320,7 +387,7 @@ __device__ __forceinline__ void rq_level_loop(const FwdArgs &a, float *lds, floa
     }
 }
 
-template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT, int NW>
+template <int MODE, bool TRAIN, bool RESIDENT, bool CSPLIT, int NW, bool STREAM = false>
 __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float cand_d[2][4][16];
@@ -354,7 +421,7 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
         float loss;
         float esum[8];
         unsigned long long tuple;
-        rq_level_loop<MODE, TRAIN, RESIDENT, CSPLIT>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss, tuple);
+        rq_level_loop<MODE, TRAIN, RESIDENT, CSPLIT, 4, STREAM>(a, lds, cand_d, cand_i, phase, wave, it, q, item, valid, r, esum, loss, tuple);
         if (valid) {
             if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
             if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
@@ -1452,7 +1519,10 @@ int launch_fwd(const FwdArgs &a, bool resident, bool csplit, int nw, int grid, s
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, s, a);                                                     \
     }
-    if (resident && csplit) HV_GO(true, true, 4)
+    if (!resident && csplit) {  // streamed code-split variant (no LDS copy of the codes)
+        auto kern = rq_forward_kernel<MODE, TRAIN, false, true, 4, true>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, a);
+    } else if (resident && csplit) HV_GO(true, true, 4)
     else if (resident && nw == 16) HV_GO(true, false, 16)
     else if (resident && nw == 8) HV_GO(true, false, 8)
     else if (resident) HV_GO(true, false, 4)
@@ -1536,14 +1606,18 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     const bool resident = a.nchunks == 1 && per_level * (size_t)L <= 152 * 1024;
     const size_t lds = resident ? per_level * (size_t)L : per_level;
     // small batches: split the codes over the 4 waves of a workgroup (16 items per workgroup) to cut the serial search
-    const bool csplit = resident && a.KC % 128 == 0 && B <= 4096;
+    // (codebooks that do not fit LDS -- 4 x 1024: the streamed code-split kernel up to 16384 items, 16 per workgroup; above that the
+    //  staged kernel amortises a level's codes over 128 items per workgroup)
+    static const int stream_env = getenv("HIDVAE_RQ_STREAM") ? atoi(getenv("HIDVAE_RQ_STREAM")) : 1;
+    const bool csplit = (resident && a.KC % 128 == 0 && B <= 4096) || (!resident && stream_env && B <= 16384);
     // large batches: 8 or 16 waves per workgroup (two / four per SIMD) share one LDS copy of the codebooks, so one wave's per-level VALU
     // work (rotation, loss, argmin merge) overlaps the other's MFMAs; LDS allows only one workgroup per CU either way
     // (measured at 1,048,576 items, 3x256: 4 waves 1050 us, 8 waves 787 us, 16 waves 704 us; 85 VGPRs, so 4 waves per SIMD fit)
     int nw = (!csplit && B >= 256 * 128) ? 8 : 4;
     if (!csplit && resident && B >= 256 * 256) nw = 16;
     const int64_t ntiles = hv_cdiv(B, csplit ? ITEMS_PER_WAVE : ITEMS_PER_WAVE * nw);
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU (LDS-limited), grid-stride over tiles
+    const int64_t gcap = (csplit && !resident) ? 2048 : 256;  // one workgroup per CU when LDS-limited; the streamed kernel holds no codes in LDS
+    const int grid = (int)(ntiles < gcap ? ntiles : gcap);  // grid-stride over tiles
     hipStream_t s = (hipStream_t)stream;
     // large batches whose codebooks fit as bf16 hi/lo images: split-bf16 prefilter + exact confirmation (bit-identical results)
     // HIDVAE_RQ_PREFILTER: 0 = exact kernel only, 16 = the 16-item prefilter only, 32 = the 32-item kernel from 65536 items on
