@@ -50,6 +50,9 @@ _SIGNATURES = {
     "hidvae_batchnorm_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp],
     "hidvae_infonce_rows": [_vp, _i64, _f, _f, _vp, _vp, _vp],
     "hidvae_infonce_dlogits": [_vp, _i64, _f, _f, _vp, _vp],
+    "hidvae_infonce_lse_chunk": [_vp, _i64, _i64, _i64, _i64, _f, _vp, _vp, _vp, _i, _vp],
+    "hidvae_infonce_lse_finish": [_vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp],
+    "hidvae_infonce_dlogits_chunk": [_vp, _i64, _i64, _i64, _i64, _f, _f, _vp, _vp, _vp],
     "hidvae_mixup_plan": [_vp, _i64, _i, _i64, _vp, _f, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_fwd": [_vp, _i64, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
@@ -695,6 +698,29 @@ def infonce_rows(S, tau, scale):
 def infonce_dlogits(P, tau, scale, g):
     _check(lib().hidvae_infonce_dlogits(_p(P), P.shape[0], float(tau), float(scale), _p(g), _stream()), "hidvae_infonce_dlogits")
     return P
+
+
+def infonce_lse_chunk(Sc, col0, tau, m, l, diag, first):
+    B, C = Sc.shape
+    _check(lib().hidvae_infonce_lse_chunk(_p(Sc), B, C, _row_stride(Sc, "Sc"), int(col0), float(tau), _p(m), _p(l), _p(diag), int(bool(first)),
+                                          _stream()), "hidvae_infonce_lse_chunk")
+
+
+def infonce_lse_finish(m, l, diag, tau, scale):
+    B = m.shape[0]
+    row_loss = torch.empty((B,), device=m.device, dtype=torch.float32)
+    lse = torch.empty((B,), device=m.device, dtype=torch.float32)
+    loss = torch.empty((), device=m.device, dtype=torch.float32)
+    _check(lib().hidvae_infonce_lse_finish(_p(m), _p(l), _p(diag), B, float(tau), float(scale), _p(row_loss), _p(lse), _p(loss), _stream()),
+           "hidvae_infonce_lse_finish")
+    return loss, lse
+
+
+def infonce_dlogits_chunk(Sc, col0, tau, scale, lse, g):
+    B, C = Sc.shape
+    _check(lib().hidvae_infonce_dlogits_chunk(_p(Sc), B, C, _row_stride(Sc, "Sc"), int(col0), float(tau), float(scale), _p(lse), _p(g), _stream()),
+           "hidvae_infonce_dlogits_chunk")
+    return Sc
 
 
 MIXUP_PLAN_MAX_B = 4096

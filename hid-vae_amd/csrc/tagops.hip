@@ -721,6 +721,51 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(float *S, int64_t B, 
     if (lane == 0) row_loss[row] = lse - diag;
 }
 
+// ---- InfoNCE without the B x B matrix (large batches; the 20,000-item k-means warm-up forward would hold 3 x 1.6 GB of softmax) ----
+// The similarity matrix is produced in column chunks Sc [B, C] = cn tn[col0:col0+C]^T and consumed at once: an online
+// logsumexp per row (running maximum m and sum l, rescaled when the maximum moves; chunks in ascending column order, so the result
+// is a fixed function of the chunk width), the diagonal logit captured when its column passes by.
+__global__ __launch_bounds__(256) void infonce_lse_chunk_kernel(const float *Sc, int64_t B, int64_t C, int64_t ldc, int64_t col0,
+                                                                float inv_tau, float *m, float *l, float *diag, int first) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float *s = Sc + row * ldc;
+    float mx = -INFINITY;
+    for (int64_t j = lane; j < C; j += 64) mx = fmaxf(mx, s[j] * inv_tau);
+    mx = hv_wave_max(mx);
+    const float m_old = first ? -INFINITY : m[row];
+    const float m_new = fmaxf(m_old, mx);
+    float sum = 0.0f;
+    for (int64_t j = lane; j < C; j += 64) sum += expf(s[j] * inv_tau - m_new);
+    sum = hv_wave_sum(sum);
+    if (lane == 0) {
+        const float l_old = first ? 0.0f : l[row] * expf(m_old - m_new);
+        m[row] = m_new;
+        l[row] = l_old + sum;
+        if (row >= col0 && row < col0 + C) diag[row] = s[row - col0];
+    }
+}
+__global__ __launch_bounds__(256) void infonce_lse_finish_kernel(const float *m, const float *l, const float *diag, int64_t B, float inv_tau,
+                                                                 float *row_loss, float *lse) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float v = m[i] + logf(l[i]);
+    lse[i] = v;
+    row_loss[i] = v - diag[i] * inv_tau;
+}
+// backward of a chunk: Sc -> dS = (g * coef) * (softmax - I) restricted to columns [col0, col0+C), softmax = exp(Sc/tau - lse)
+__global__ __launch_bounds__(256) void infonce_dlogits_chunk_kernel(float *Sc, int64_t B, int64_t C, int64_t ldc, int64_t col0, float inv_tau,
+                                                                    const float *lse, const float *g, float coef) {
+    const float k = *g * coef;
+    const int64_t n = B * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C, c = i - r * C;
+        const float p = expf(Sc[r * ldc + c] * inv_tau - lse[r]);
+        Sc[r * ldc + c] = k * (p - (r == col0 + c ? 1.0f : 0.0f));
+    }
+}
+
 // out[0] = scale * mean(v)   (single workgroup, fixed order)
 __global__ __launch_bounds__(256) void vec_mean_kernel(const float *v, int64_t n, float scale, float *out) {
     __shared__ float red[4];
@@ -1093,6 +1138,35 @@ extern "C" int hidvae_infonce_rows(float *S, int64_t B, float tau, float scale, 
     HV_LAUNCH_CHECK("infonce_rows");
     hipLaunchKernelGGL(vec_mean_kernel, dim3(1), dim3(256), 0, s, row_loss, B, scale, loss);
     HV_LAUNCH_CHECK("infonce mean");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_infonce_lse_chunk(const float *Sc, int64_t B, int64_t C, int64_t ldc, int64_t col0, float tau, float *m, float *l,
+                                        float *diag, int first, void *stream) {
+    HV_REQUIRE(Sc && m && l && diag && B >= 1 && C >= 1 && ldc >= C && col0 >= 0 && col0 + C <= B && tau > 0.0f, "infonce_lse_chunk: bad arguments");
+    hipLaunchKernelGGL(infonce_lse_chunk_kernel, dim3((unsigned)hv_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, Sc, B, C, ldc, col0,
+                       1.0f / tau, m, l, diag, first);
+    HV_LAUNCH_CHECK("infonce_lse_chunk");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_infonce_lse_finish(const float *m, const float *l, const float *diag, int64_t B, float tau, float scale, float *row_loss,
+                                         float *lse, float *loss, void *stream) {
+    HV_REQUIRE(m && l && diag && row_loss && lse && loss && B >= 1 && tau > 0.0f, "infonce_lse_finish: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(infonce_lse_finish_kernel, dim3((unsigned)hv_cdiv(B, 256)), dim3(256), 0, s, m, l, diag, B, 1.0f / tau, row_loss, lse);
+    HV_LAUNCH_CHECK("infonce_lse_finish");
+    hipLaunchKernelGGL(vec_mean_kernel, dim3(1), dim3(256), 0, s, row_loss, B, scale, loss);
+    HV_LAUNCH_CHECK("infonce mean");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_infonce_dlogits_chunk(float *Sc, int64_t B, int64_t C, int64_t ldc, int64_t col0, float tau, float scale,
+                                            const float *lse, const float *g_dev, void *stream) {
+    HV_REQUIRE(Sc && lse && g_dev && B >= 1 && C >= 1 && ldc >= C && col0 >= 0 && col0 + C <= B && tau > 0.0f, "infonce_dlogits_chunk: bad arguments");
+    hipLaunchKernelGGL(infonce_dlogits_chunk_kernel, dim3(ew_grid(B * C)), dim3(256), 0, (hipStream_t)stream, Sc, B, C, ldc, col0, 1.0f / tau,
+                       lse, g_dev, scale / ((float)B * tau));
+    HV_LAUNCH_CHECK("infonce_dlogits_chunk");
     return HIDVAE_OK;
 }
 

@@ -122,28 +122,71 @@ class BatchNormFn(Function):
         return (gx, gg, gb) + (None,) * 9
 
 
+INFONCE_CHUNK_FROM = 4096  # batches from here on never materialise the B x B similarity matrix
+INFONCE_CHUNK_COLS = 2048
+
+
 class InfoNCEFn(Function):
-    """scale * CE(normalize(c) normalize(t)^T / tau, arange(B))   (reference loss.py:54-85)."""
+    """scale * CE(normalize(c) normalize(t)^T / tau, arange(B))   (reference loss.py:54-85).
+    B < 4096: the similarity matrix S [B,B] is one GEMM and softmax(S/tau) is kept for the backward.  From 4096 items on S is produced
+    in chunks of 2048 columns and consumed at once by an online logsumexp (hidvae_infonce_lse_chunk); the backward recomputes each
+    chunk.  Peak extra memory B x 2048 floats (164 MB at the 20,000-item k-means warm-up forward, where three levels of saved softmax
+    were 4.8 GB)."""
 
     @staticmethod
     def forward(ctx, c, t, tau, scale):
         ctx.set_materialize_grads(False)
         cn, nc = _C.l2norm_fwd(c)
         tn, nt = _C.l2norm_fwd(t)
+        B = cn.shape[0]
+        ctx.cfg = (tau, scale)
+        if B >= INFONCE_CHUNK_FROM:
+            f = lambda: torch.empty((B,), device=cn.device, dtype=torch.float32)
+            m, l, diag = f(), f(), f()
+            Sc = torch.empty((B, min(B, INFONCE_CHUNK_COLS)), device=cn.device, dtype=torch.float32)
+            for col0 in range(0, B, INFONCE_CHUNK_COLS):
+                C = min(INFONCE_CHUNK_COLS, B - col0)
+                S = _C.gemm(_C.GEMM_NT, cn, tn[col0:col0 + C], out=Sc[:, :C])
+                _C.infonce_lse_chunk(S, col0, tau, m, l, diag, col0 == 0)
+            loss, lse = _C.infonce_lse_finish(m, l, diag, tau, scale)
+            ctx.save_for_backward(cn, nc, tn, nt, lse)
+            ctx.chunked = True
+            return loss
         S = _C.gemm(_C.GEMM_NT, cn, tn)
         loss = _C.infonce_rows(S, tau, scale)  # S now holds softmax(S / tau)
         ctx.save_for_backward(cn, nc, tn, nt, S)
-        ctx.cfg = (tau, scale)
+        ctx.chunked = False
         return loss
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
             return None, None, None, None
-        cn, nc, tn, nt, P = ctx.saved_tensors
         tau, scale = ctx.cfg
-        dS = _C.infonce_dlogits(P, tau, scale, g.contiguous())
         gc = gt = None
+        if ctx.chunked:
+            cn, nc, tn, nt, lse = ctx.saved_tensors
+            B, w = cn.shape
+            g = g.contiguous()
+            want_c, want_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+            gcn = torch.empty((B, w), device=cn.device, dtype=torch.float32) if want_c else None
+            gtn = torch.empty((B, w), device=cn.device, dtype=torch.float32) if want_t else None
+            Sc = torch.empty((B, min(B, INFONCE_CHUNK_COLS)), device=cn.device, dtype=torch.float32)
+            for col0 in range(0, B, INFONCE_CHUNK_COLS):
+                C = min(INFONCE_CHUNK_COLS, B - col0)
+                S = _C.gemm(_C.GEMM_NT, cn, tn[col0:col0 + C], out=Sc[:, :C])
+                dS = _C.infonce_dlogits_chunk(S, col0, tau, scale, lse, g)
+                if want_c:  # d cn += dS tn[chunk]   (chunks in ascending order: a fixed summation order)
+                    _C.gemm(_C.GEMM_NN, dS, tn[col0:col0 + C], out=gcn, split_k=0, accumulate=col0 > 0)
+                if want_t:  # d tn[chunk] = dS^T cn
+                    _C.gemm(_C.GEMM_TN, dS, cn, out=gtn[col0:col0 + C], split_k=0)
+            if want_c:
+                gc = _C.l2norm_bwd(gcn, cn, nc)
+            if want_t:
+                gt = _C.l2norm_bwd(gtn, tn, nt)
+            return gc, gt, None, None
+        cn, nc, tn, nt, P = ctx.saved_tensors
+        dS = _C.infonce_dlogits(P, tau, scale, g.contiguous())
         if ctx.needs_input_grad[0]:
             gc = _C.l2norm_bwd(_C.gemm(_C.GEMM_NN, dS, tn, split_k=0), cn, nc)
         if ctx.needs_input_grad[1]:

@@ -222,7 +222,10 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
         if it == 0 and use_kmeans_init:
             # the reference's warm-up: one full training-mode forward on the first min(20000, N) items whose only wanted effect
             # is the k-means codebook initialisation (train_hidvae.py:692-696; BatchNorm buffers see this batch too)
-            model(train_set[torch.arange(min(20000, len(train_set)), device=device)], t)
+            # (no autograd tape: nothing is differentiated here, and at 20,000 tagged items the saved activations of the three heads
+            #  would be gigabytes; the InfoNCE term itself never materialises its B x B matrix from 4096 items on)
+            with torch.no_grad():
+                model(train_set[torch.arange(min(20000, len(train_set)), device=device)], t)
             if dp is not None:  # rank 0's codebooks win (the reference lets them diverge)
                 dp.broadcast_codebooks([layer.embedding.weight for layer in model.layers], 0)
             log.info("K-means initialization complete")

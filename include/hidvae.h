@@ -377,6 +377,18 @@ int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx, const flo
  * rows: loss = scale * mean_b( logsumexp_j(S_bj/tau) - S_bb/tau ), S overwritten by softmax(S/tau);
  * dlogits: P <- (g*scale/(B*tau)) (P - I) in place, g a device scalar -- feed it to two GEMMs for d c / d t. */
 int hidvae_infonce_rows(float *S, int64_t B, float tau, float scale, float *row_loss, float *loss, void *stream);
+/* The same loss WITHOUT the B x B matrix (B >= 4096; the 20,000-item warm-up forward of train_hidvae.py:692-696 would hold 1.6 GB of
+ * softmax per level): the caller produces S in column chunks Sc [B, C] = n(c) n(t)[col0:col0+C]^T and hands each one over at once.
+ *   lse_chunk   : online logsumexp per row (running maximum m [B] and sum l [B], chunks in ascending column order, first != 0 on the
+ *                 first one), diag [B] captures S[b,b] when its column passes;
+ *   lse_finish  : lse[b] = m + log l (kept for the backward), row_loss = lse - diag/tau, *loss = scale * mean;
+ *   dlogits_chunk (backward, on a RECOMPUTED chunk): Sc <- (g*scale/(B*tau)) (exp(Sc/tau - lse) - I[:, col0:col0+C]) in place. */
+int hidvae_infonce_lse_chunk(const float *Sc, int64_t B, int64_t C, int64_t ldc, int64_t col0, float tau, float *m, float *l, float *diag,
+                             int first, void *stream);
+int hidvae_infonce_lse_finish(const float *m, const float *l, const float *diag, int64_t B, float tau, float scale, float *row_loss,
+                              float *lse, float *loss, void *stream);
+int hidvae_infonce_dlogits_chunk(float *Sc, int64_t B, int64_t C, int64_t ldc, int64_t col0, float tau, float scale, const float *lse,
+                                 const float *g_dev, void *stream);
 int hidvae_infonce_dlogits(float *P, int64_t B, float tau, float scale, const float *g_dev, void *stream);
 /* The mixup plan of one training step for all L levels (loss.py:139-147: perm = randperm(n_valid), lam ~ Beta(alpha, alpha)):
  * targets [B, ld>=L] int64 (-1 = invalid row); uniforms [L, B+64] in [0,1) from the caller's generator (B sort keys + 64 spare

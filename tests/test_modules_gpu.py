@@ -126,3 +126,54 @@ def test_reference_checkpoint_loads_through_load_pretrained(tmp_path):
     one_step(m2, opt2)
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("B,w", [(5000, 64), (4096, 96)])
+def test_chunked_infonce_equals_the_materialised_form(B, w, monkeypatch):
+    """From 4096 items on InfoNCE (reference loss.py:54-85) runs on column chunks of the similarity matrix with an online
+    logsumexp and a recomputing backward; it must agree with the form that materialises softmax(S / tau): loss to 1e-6, gradients to
+    1e-5 of their maximum (different summation order of the softmax denominators)."""
+    import hidvae_amd  # noqa: F401
+    from hidvae_amd import tagpath
+    c0, t0 = fill.gauss((B, w), 61), fill.gauss((B, w), 62)
+
+    def run(chunk_from):
+        monkeypatch.setattr(tagpath, "INFONCE_CHUNK_FROM", chunk_from)
+        c, t = dev(c0, True), dev(t0, True)
+        loss = tagpath.InfoNCEFn.apply(c, t, 0.1, 0.15)
+        (loss * 3.0).backward()
+        return float(loss.detach()), c.grad.cpu().numpy(), t.grad.cpu().numpy()
+
+    l1, gc1, gt1 = run(1)          # chunked
+    l0, gc0, gt0 = run(10 ** 9)    # materialised
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert H.close(gc1, gc0, 1e-5, 1e-10) and H.close(gt1, gt0, 1e-5, 1e-10)
+    # and against the reference's expression in float64
+    cn = torch.nn.functional.normalize(torch.from_numpy(c0).double(), dim=-1)
+    tn = torch.nn.functional.normalize(torch.from_numpy(t0).double(), dim=-1)
+    ref = 0.15 * torch.nn.functional.cross_entropy(cn @ tn.T / 0.1, torch.arange(B))
+    assert abs(l1 - float(ref)) <= 2e-6 * abs(float(ref))
+
+
+def test_warm_up_forward_at_20000_tagged_items_stays_under_a_gigabyte():
+    """train_hidvae.py:692-696: the k-means warm-up is one training-mode forward over min(20000, N) items.  With the tag heads that
+    used to materialise three B x B softmax matrices (1.6 GB each); now the whole pass peaks below 1 GB beyond its inputs."""
+    import types
+    from oracle import torch_oracle as O
+    from tests.test_model_gpu import build_model
+    cfg = O.Cfg(commitment_weight=0.4, tag_class_counts=[38, 168, 348])
+    m = build_model(cfg, O.formula_params(cfg, seed=100, with_tags=True)).train()
+    B = 20000
+    g = torch.Generator(device="cuda").manual_seed(0)
+    batch = types.SimpleNamespace(x=torch.nn.functional.normalize(torch.randn(B, 768, device="cuda", generator=g), dim=-1),
+                                  tags_emb=torch.randn(B, 3, 768, device="cuda", generator=g),
+                                  tags_indices=torch.randint(0, 38, (B, 3), device="cuda", generator=g))
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        out = m(batch, gumbel_t=0.2)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert torch.isfinite(out.loss) and float(out.tag_align_loss) > 0
+    assert peak < 1 << 30, f"warm-up forward peaked {peak / 2**20:.0f} MiB above its inputs"
