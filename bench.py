@@ -315,7 +315,8 @@ def run_workload(args, device, rank, world, dist):
     from hidvae_amd.optim import HidvaeAdamW
     m = build_model(args, device)
     multi = dist is not None  # the data-parallel path (also taken with one rank under --dist 1)
-    opt = HidvaeAdamW(param_groups(m, tagged=bool(args.tagged)), cosine=(400000, 7e-8), flat_grads=multi).prepare()
+    opt = HidvaeAdamW(param_groups(m, tagged=bool(args.tagged)), cosine=(400000, 7e-8), flat_grads=multi,
+                      first_bucket=m.dp_first_bucket(args.batch) if multi else None).prepare()
     dp = None
     if multi:
         from hidvae_amd.parallel import DataParallel

@@ -160,6 +160,32 @@ class HRqVae(nn.Module, _HubMixin):
             t = tabs[key] = _C.census_scratch(B, device)
         return t
 
+    def _cut_here(self, t):
+        """identity, or -- while a split backward is being recorded -- a fresh leaf standing in for `t`: the first backward pass
+        stops there (leaving d loss / d t in the leaf's .grad), backward_rest() resumes from `t` with that gradient"""
+        if not getattr(self, "_cutting", False) or t is None or not t.requires_grad:
+            return t
+        leaf = t.detach().requires_grad_()
+        self._cut_pairs.append((t, leaf))
+        return leaf
+
+    def backward_rest(self):
+        """second half of a split backward: everything upstream of the cuts of the last forward, in ONE autograd pass"""
+        pairs = [(t, leaf.grad) for t, leaf in (self._cut_pairs or []) if leaf.grad is not None]
+        self._cut_pairs = None
+        if pairs:
+            torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+
+    def dp_first_bucket(self, batch_size):
+        """the parameters whose gradients the FIRST half of a split backward completes (the decoder's last two layers when the fused
+        middle launch runs, else the whole decoder): data-parallel runs put them first in the flat gradient buffer"""
+        Wd = self.decoder.weights()
+        We = self.encoder.weights()
+        fused = (len(We) >= 3 and len(Wd) >= 3 and self.codebook_mode.value in (QuantizeForwardMode.STE.value, QuantizeForwardMode.ROTATION_TRICK.value)
+                 and getattr(self, "fuse_bottleneck", True)
+                 and _C.bottleneck_eligible(batch_size, We[-2].shape[1], We[-2].shape[0], Wd[0].shape[0], Wd[1].shape[0], self.n_layers, self.codebook_size))
+        return list(Wd[2:]) if fused else list(Wd)
+
     def _rand(self):
         if self.rand is not None:
             return self.rand
@@ -317,6 +343,11 @@ class HRqVae(nn.Module, _HubMixin):
             if hasattr(r, "begin_step"):
                 r.begin_step(x.device)  # all dropout keep-masks of the step from one launch (rand.DeviceRand)
         self._prepared = self._prepare_codebooks_async()  # effective codebooks + |c|^2 on the helper stream, beside the encoder
+        # data-parallel overlap (step.GraphedTrainStep): with `dp_cut` set the backward is split in two at the inputs of the decoder's
+        # tail and of the loss launch, so the gradients of the decoder's last layers -- final first -- go on the wire while the rest of
+        # the backward still runs (see _cut_here / backward_rest)
+        self._cutting = bool(getattr(self, "dp_cut", False)) and self.training and torch.is_grad_enabled()
+        self._cut_pairs = [] if self._cutting else None
         y_dec = None
         embs_norm = p_unique = None  # (the fused middle launch produces them itself when it can)
         if self._bottleneck_ok(x):
@@ -328,15 +359,21 @@ class HRqVae(nn.Module, _HubMixin):
             z, ids, emb_cat, emb_sum, qloss, pre_d1, d1, embs_norm, p_unique = BottleneckFn.apply(
                 pre1, h1, We[-2], We[-1], Wd[0], Wd[1], self.codebook_normalize, self._fused_mode(), self.commitment_weight,
                 self._normalize_flags(), self._prepared, (lambda: self._census("fused", x.shape[0], x.device)), *self._tables())
-            y_dec = MLPBackFn.apply(pre_d1, d1, *Wd[2:])
+            dec_in = self._cut_here(pre_d1)
+            y_dec = MLPBackFn.apply(dec_in, d1, *Wd[2:])
         else:
             y = self.encoder.body(x)  # the encoder's l2norm (codebook_normalize) happens in the RQ prologue
             z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)
+            y_dec = self.decoder.body(self._cut_here(emb_sum))
         self._prepared = None
 
         tag_scalars = ()
         if tagged:
             tag_scalars = self._tag_heads(emb_cat, tags_emb.float(), tags_indices)  # (A_0.., P_0.., acc_0..) device scalars
+        if getattr(self, "_cutting", False):  # everything else the loss launch differentiates is cut too (see _cut_here)
+            n_t = len(tag_scalars) // 3
+            qloss, z = self._cut_here(qloss), self._cut_here(z)
+            tag_scalars = tuple(self._cut_here(t) for t in tag_scalars[:2 * n_t]) + tuple(tag_scalars[2 * n_t:])
 
         # debug statistics of h_rqvae.py:643-648 (embs_norm, p_unique_ids): ready as soon as the ids are, so they run on the
         # helper stream beside the decoder instead of after it
@@ -353,7 +390,7 @@ class HRqVae(nn.Module, _HubMixin):
         # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0) and the total loss in one launch
         # the alignment / uniqueness weights enter once inside their loss modules and once more here
         n_tag = len(tag_scalars) // 3
-        loss, recon, uniq, stats, summary = StepLossFn.apply(y_dec if y_dec is not None else self.decoder.body(emb_sum), x, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
+        loss, recon, uniq, stats, summary = StepLossFn.apply(y_dec, x, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
                                                     self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight,
                                                     self.tag_prediction_weight, self.sem_id_uniqueness_weight, n_tag,
                                                     float(self.n_layers), *tag_scalars)

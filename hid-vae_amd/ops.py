@@ -183,9 +183,9 @@ class BottleneckFn(Function):
         ctx.params = (W2, W3, Wd0, Wd1)
         ctx.tables = tables
         ctx.save_for_backward(pre1, h1, o["pre2"], o["h2"], o["y"], o["z"], o["ids"], o["emb_sum"], o["pre_d0"], o["d0"], cb, cc)
-        ctx.mark_non_differentiable(o["ids"], o["emb_sum"], o["d1"])
-        if census:
-            ctx.mark_non_differentiable(o["embs_norm"], o["p_unique"])
+        # (ONE call: a second mark_non_differentiable would replace the first set, and emb_sum / d1 would silently keep an edge to this
+        #  node -- which is what a split backward, HRqVae.dp_cut, trips over)
+        ctx.mark_non_differentiable(*([o["ids"], o["emb_sum"], o["d1"]] + ([o["embs_norm"], o["p_unique"]] if census else [])))
         return o["z"], o["ids"], o["emb_cat"], o["emb_sum"], o["qloss"], o["pre_d1"], o["d1"], o.get("embs_norm"), o.get("p_unique")
 
     @staticmethod
@@ -267,10 +267,9 @@ class RQFn(Function):
         #  graph, AccumulateGrad nodes included, alive until the garbage collector runs; those stale nodes sit on the stream of that
         #  forward and break a later HIP-graph capture)
         ctx.save_for_backward(y, z, ids, cb, cc)
-        ctx.mark_non_differentiable(ids)
         if res is None:
             res = torch.empty(0, device=y.device)
-        ctx.mark_non_differentiable(res)
+        ctx.mark_non_differentiable(ids, res)  # (one call: a second one would replace the first set)
         return z, ids, emb_cat, emb_sum, qloss, res
 
     @staticmethod

@@ -18,7 +18,7 @@ class HidvaeAdamW(torch.optim.Optimizer):
     in place), which is what the data-parallel path all-reduces in a single RCCL collective."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, cosine=None, start_step=0,
-                 flat_grads=False, step_lr=None):
+                 flat_grads=False, step_lr=None, first_bucket=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         b = {tuple(g["betas"]) for g in self.param_groups}
         e = {g["eps"] for g in self.param_groups}
@@ -34,18 +34,25 @@ class HidvaeAdamW(torch.optim.Optimizer):
         self._start_step = start_step
         self.flat_grads = flat_grads
         self.grad_scale = 1.0
+        # parameters whose gradients are final first in the backward (data-parallel overlap): they lead the flat gradient buffer, so
+        # that bucket is one contiguous range that can go on the wire while the rest of the backward runs
+        self.first_bucket = list(first_bucket) if first_bucket else []
+        self.n_first = 0
 
     def _build(self):
-        ps, lrs, wds = [], [], []
+        rows = []
         for g in self.param_groups:
             for p in g["params"]:
                 if not p.requires_grad:
                     continue
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("HidvaeAdamW needs contiguous float32 parameters")  # (step() additionally needs them on the GPU)
-                ps.append(p)
-                lrs.append(g["lr"])
-                wds.append(g["weight_decay"])
+                rows.append((p, g["lr"], g["weight_decay"]))
+        lead = {id(p): i for i, p in enumerate(self.first_bucket)}
+        first = sorted([r for r in rows if id(r[0]) in lead], key=lambda r: lead[id(r[0])])
+        rows = first + [r for r in rows if id(r[0]) not in lead]
+        self.n_first = len(first)
+        ps, lrs, wds = [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows]
         dev = ps[0].device
         self._params = ps
         total = sum(p.numel() for p in ps)
@@ -217,12 +224,12 @@ class HidvaeAdamW(torch.optim.Optimizer):
         return bool(restored)
 
     def _refresh_hyper(self):
-        lrs, wds = [], []
+        of = {}
         for g in self.param_groups:
             for p in g["params"]:
-                if p.requires_grad:
-                    lrs.append(g["lr"])
-                    wds.append(g["weight_decay"])
+                of[id(p)] = (g["lr"], g["weight_decay"])
+        lrs = [of[id(p)][0] for p in self._params]  # (the flat order, which may lead with the first bucket)
+        wds = [of[id(p)][1] for p in self._params]
         self._desc["lr"].copy_(torch.tensor(lrs, dtype=torch.float32))
         self._desc["wd"].copy_(torch.tensor(wds, dtype=torch.float32))
         b = {tuple(g["betas"]) for g in self.param_groups}

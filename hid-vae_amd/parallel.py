@@ -38,6 +38,7 @@ class FlatGradBuffer:
             p._hv_written = False
             off += n
         self._sealed = False
+        self._sealed_upto = 0
         self.zero()
 
     def zero(self):
@@ -45,12 +46,17 @@ class FlatGradBuffer:
             p.grad = None
             p._hv_written = False
         self._sealed = False
+        self._sealed_upto = 0
 
     @torch.no_grad()
-    def seal(self):
+    def seal(self, upto=None):
+        """complete the buffer; upto = n: only the first n parameters (the first bucket of an overlapped exchange) -- the rest is
+        sealed by a later call"""
         if self._sealed:
             return
-        for p, v in zip(self.params, self.views):
+        n = len(self.params) if upto is None else upto
+        for i in range(self._sealed_upto, n):
+            p, v = self.params[i], self.views[i]
             if p._hv_written:
                 if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                     v.add_(p.grad)  # a second, protocol-unaware producer of the same parameter
@@ -60,11 +66,16 @@ class FlatGradBuffer:
                 v.copy_(p.grad)
             p.grad = v
             p._hv_written = True  # a further backward before the next zero() accumulates
-        self._sealed = True
+        self._sealed_upto = max(self._sealed_upto, n)
+        self._sealed = self._sealed_upto == len(self.params)
+
+    def numel_of_first(self, n):
+        return sum(p.numel() for p in self.params[:n])
 
     def unseal(self):
         """call before another backward of the same optimizer step (gradient accumulation)"""
         self._sealed = False
+        self._sealed_upto = 0
 
 
 class DataParallel:
@@ -97,6 +108,14 @@ class DataParallel:
             return 1.0, None
         work = dist.all_reduce(self.buf.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return 1.0 / self.world, work
+
+    def allreduce_part(self, lo, hi):
+        """asynchronous SUM of flat[lo:hi] over the ranks (one bucket of an overlapped exchange).  -> work handle or None; the caller
+        has sealed those slots.  The collective is ordered after everything queued on the current stream so far and runs on the
+        backend's own stream, i.e. beside what the caller queues next; work.wait() makes the current stream wait for it."""
+        if (self.world == 1 and not self.always) or hi <= lo:
+            return None
+        return dist.all_reduce(self.buf.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def shard_seed(self, base_seed=0):
         """per-rank sampler seed: ranks must not draw the same items"""

@@ -6,8 +6,16 @@ microseconds long.  Issued one by one from Python the step is host-bound (0.80 m
 once and replayed it is 0.28 / 2.3 ms.  Nothing in the step synchronises with the host (losses, the mixup weight, the AdamW step
 counter and the learning-rate schedule live on the device), which is what makes the capture legal.
 
-Data parallel: collectives stay outside the graphs, so the step is  graph[zero_grad, forward, backward, seal]  ->  one RCCL
-all-reduce of the flat gradient buffer  ->  graph[AdamW]."""
+Data parallel: collectives stay outside the graphs.  The backward is split in two at the inputs of the decoder's tail and of the
+loss launch (HRqVae.dp_cut), and the flat gradient buffer leads with the parameters the first half completes, so the exchange
+overlaps the rest of the backward:
+
+    graph[zero_grad, forward, backward part 1]  ->  all-reduce(bucket 1) on RCCL's stream  ||  graph[backward part 2]
+                                                ->  all-reduce(bucket 2)  ->  graph[AdamW]
+
+(DDP gives the reference the same thing by bucketing gradients in reverse registration order, train_hidvae.py:630-632,709.)  With
+gradient accumulation, or an optimizer built without a first bucket, the exchange is ONE all-reduce between graph[forward, backward]
+and graph[AdamW]."""
 import types
 
 import torch
@@ -36,6 +44,10 @@ class GraphedTrainStep:
         self.graphs = None
 
     # -- the step, as plain code (this is what gets captured)
+    def _overlapped(self):
+        return (self.dp is not None and self.ga == 1 and self.opt.flat_grads and getattr(self.opt, "n_first", 0) > 0
+                and hasattr(self.model, "backward_rest"))
+
     def _fwd_bwd(self):
         self.opt.zero_grad()
         total = None
@@ -49,14 +61,55 @@ class GraphedTrainStep:
         summary = self.model.last_summary
         self.row = summary if self.ga == 1 else torch.cat([total.detach().reshape(1), summary[1:]])
 
+    def _part1(self):  # forward + the half of the backward that completes the first bucket (the decoder's tail)
+        self.opt.zero_grad()
+        self.model.dp_cut = True
+        try:
+            out = self.model(self.static[0], gumbel_t=self.t)
+        finally:
+            self.model.dp_cut = False
+        out.loss.backward(gradient=self.one)
+        self.opt.grad_buffer.seal(upto=self.opt.n_first)
+        self.row = self.model.last_summary
+
+    def _part2(self):  # the rest of the backward
+        self.model.backward_rest()
+        self.opt.grad_buffer.seal()
+
+    def _exchange_overlapped(self, run1, run2):
+        buf = self.opt.grad_buffer
+        n1 = buf.numel_of_first(self.opt.n_first)
+        run1()
+        w1 = self.dp.allreduce_part(0, n1)            # on the wire while part 2 runs
+        run2()
+        w2 = self.dp.allreduce_part(n1, buf.flat.numel())
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()                               # (stream-side wait: the host does not block)
+        return 1.0 / self.dp.world
+
     def _eager(self):
+        if self._overlapped():
+            self.opt.grad_scale = self._exchange_overlapped(self._part1, self._part2)
+            self.opt.step()
+            return
         self._fwd_bwd()
         if self.dp is not None:
             self.opt.grad_scale, _ = self.dp.allreduce()
         self.opt.step()
 
     def _capture(self):
-        if self.dp is not None:
+        if self._overlapped():
+            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._part1()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._part2()
+            self.opt.grad_scale = 1.0 / self.dp.world
+            with torch.cuda.graph(g3, pool=g1.pool()):
+                self.opt.step()
+            self.graphs = (g1, g2, g3)
+        elif self.dp is not None:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self._fwd_bwd()
@@ -90,6 +143,10 @@ class GraphedTrainStep:
         if self.graphs is None:
             torch.cuda.synchronize()
             self._capture()  # (a capture only records: replay it for this call's batch)
+        if len(self.graphs) == 3:
+            self._exchange_overlapped(self.graphs[0].replay, self.graphs[1].replay)
+            self.graphs[2].replay()
+            return self.row
         self.graphs[0].replay()
         if len(self.graphs) == 2:
             self.dp.allreduce()

@@ -117,7 +117,9 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 and not torch.distributed.is_initialized():
-        torch.distributed.init_process_group("nccl", device_id=device)  # RCCL
+        # "nccl" IS RCCL on ROCm; HIDVAE_DIST_BACKEND=gloo lets several ranks share one GPU (tests), where RCCL refuses duplicates
+        backend = os.environ.get("HIDVAE_DIST_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
     main_proc = rank == 0
 
     save_dir = os.path.join(save_dir_root, datetime.now().strftime("%Y%m%d_%H%M%S"))
@@ -185,7 +187,8 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
         start_iter, opt_state = state["iter"] + 1, state.get("optimizer")
     cosine = (lr_scheduler_T_max, lr_scheduler_eta_min) if (use_lr_scheduler and lr_scheduler_type == "cosine") else None
     step_lr = (lr_scheduler_step_size, lr_scheduler_gamma) if (use_lr_scheduler and lr_scheduler_type == "step") else None
-    opt = HidvaeAdamW(groups, cosine=cosine, step_lr=step_lr, start_step=start_iter, flat_grads=world > 1).prepare()
+    opt = HidvaeAdamW(groups, cosine=cosine, step_lr=step_lr, start_step=start_iter, flat_grads=world > 1,
+                      first_bucket=model.dp_first_bucket(batch_size) if world > 1 else None).prepare()
     if pretrained_hrqvae_path is not None:  # reference train_hidvae.py:625: optimizer.load_state_dict(state["optimizer"])
         restored = False
         if opt_state is not None:

@@ -1,0 +1,149 @@
+"""GPU: the PRODUCT's data-parallel step (hidvae_amd.step.GraphedTrainStep with hidvae_amd.parallel.DataParallel).
+
+* one rank, RCCL: the three-graph overlapped exchange (graph[fwd + backward part 1] -> all-reduce(bucket 1) || graph[backward part 2]
+  -> all-reduce(bucket 2) -> graph[AdamW]) must equal the plain single-GPU step bit for bit -- the split backward, the bucket-first
+  flat gradient buffer and the in-place gradient writes change no arithmetic;
+* two ranks sharing this box's one GPU (backend gloo, which moves device tensors through the host; RCCL refuses two ranks on one
+  device): after several graphed steps on different per-rank batches the replicas are bit-identical, and equal to ONE process
+  stepping on the concatenated batch (mean of per-rank gradients == gradient of the per-item-mean loss over the union)."""
+import os
+import socket
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from tests.test_model_gpu import build_model
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(commitment_weight=0.4, tag_alignment_weight=0.15, tag_prediction_weight=0.55, tag_class_counts=[38, 168, 348], use_focal_loss=True,
+           focal_loss_params={"gamma_0": 2.7, "alpha_0": 0.24}, dropout_rate=0.4, sem_id_uniqueness_weight=1.5, sem_id_uniqueness_margin=0.0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _groups(m, tagged):
+    g = [{"params": list(m.encoder.parameters()) + list(m.decoder.parameters()), "lr": 2.8e-4, "weight_decay": 0.015},
+         {"params": [p for layer in m.layers for p in layer.parameters()], "lr": 2.8e-4, "weight_decay": 0.015}]
+    if tagged:
+        for i in range(m.n_layers):
+            g.append({"params": list(m.tag_predictors[i].parameters()), "lr": 2.8e-4 * (1 + 0.1 * i), "weight_decay": 0.015 / (1 + 0.2 * i)})
+            g.append({"params": list(m.tag_projectors[i].parameters()), "lr": 2.8e-4 * (1 + 0.1 * i), "weight_decay": 0.015 / (1 + 0.2 * i)})
+    return g
+
+
+def _batch(cfg, B, seed, tagged):
+    x, te, ti = O.formula_batch(cfg, B, seed=seed, tagged=tagged)
+    b = types.SimpleNamespace(x=x.cuda())
+    if tagged:
+        b.tags_emb, b.tags_indices = te.cuda(), ti.cuda()
+    return b
+
+
+def _run(tagged, dp_mode, steps=6, B=128):
+    """dp_mode None: plain step; 'overlap': DataParallel over a one-rank RCCL group, collectives issued anyway"""
+    from hidvae_amd.optim import HidvaeAdamW
+    from hidvae_amd.parallel import DataParallel
+    from hidvae_amd.step import GraphedTrainStep
+    cfg = O.Cfg(**CFG)
+    m = build_model(cfg, O.formula_params(cfg, seed=100, with_tags=True)).train()
+    torch.manual_seed(1234)
+    multi = dp_mode is not None
+    opt = HidvaeAdamW(_groups(m, tagged), cosine=(1000, 7e-8), flat_grads=multi, first_bucket=m.dp_first_bucket(B) if multi else None).prepare()
+    dp = None
+    if multi:
+        dp = DataParallel(m, opt.grad_buffer)
+        dp.always = True
+    st = GraphedTrainStep(m, opt, [_batch(cfg, B, 500, tagged)], dp=dp, gumbel_t=0.2, warmup=2)
+    rows = []
+    for it in range(steps):
+        rows.append(st([_batch(cfg, B, 500 + it, tagged)]).clone())
+    assert st.graphs is not None and len(st.graphs) == (3 if multi else 1)
+    return torch.stack(rows).cpu(), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("tagged", [False, True], ids=["untagged", "tagged"])
+def test_overlapped_dp_step_equals_the_plain_step_bit_for_bit(tagged):
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL, one rank: the --dist 1 rehearsal as a test
+        created = True
+    try:
+        rows1, sd1 = _run(tagged, "overlap")
+        rows0, sd0 = _run(tagged, None)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.equal(rows1, rows0), "logged loss rows differ between the overlapped DP step and the plain step"
+    for k in sd0:
+        assert torch.equal(sd1[k], sd0[k]), k
+
+
+def _rank_worker(rank, world, port, out_dir, steps, B):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import hidvae_amd  # noqa: F401
+    from hidvae_amd.optim import HidvaeAdamW
+    from hidvae_amd.parallel import DataParallel
+    from hidvae_amd.step import GraphedTrainStep
+    cfg = O.Cfg(**CFG)
+    # replicas start DIFFERENT on purpose: broadcast_parameters must make them rank 0's
+    m = build_model(cfg, O.formula_params(cfg, seed=100 + 13 * rank, with_tags=True)).train()
+    opt = HidvaeAdamW(_groups(m, False), cosine=(1000, 7e-8), flat_grads=True, first_bucket=m.dp_first_bucket(B)).prepare()
+    dp = DataParallel(m, opt.grad_buffer)
+    dp.broadcast_parameters(0)
+    st = GraphedTrainStep(m, opt, [_batch(cfg, B, 700, False)], dp=dp, gumbel_t=0.2, warmup=2)
+    for it in range(steps):
+        st([_batch(cfg, B, 700 + 2 * it + rank, False)])
+    torch.cuda.synchronize()
+    assert st.graphs is not None and len(st.graphs) == 3
+    torch.save({k: v.detach().cpu() for k, v in m.state_dict().items() if not k.startswith("tag_")}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_stay_bit_identical_and_match_the_big_batch(tmp_path):
+    import torch.multiprocessing as mp
+    from hidvae_amd.optim import HidvaeAdamW
+    from hidvae_amd.step import GraphedTrainStep
+    world, steps, B = 2, 5, 96
+    mp.spawn(_rank_worker, args=(world, _free_port(), str(tmp_path), steps, B), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f"replicas diverged: {k}"
+    # ONE process on the concatenated batches: per-item-mean losses make its gradient the mean of the two ranks' gradients
+    cfg = O.Cfg(**CFG)
+    m = build_model(cfg, O.formula_params(cfg, seed=100, with_tags=True)).train()
+    opt = HidvaeAdamW(_groups(m, False), cosine=(1000, 7e-8)).prepare()
+
+    def both(it):
+        a, b = _batch(cfg, B, 700 + 2 * it, False), _batch(cfg, B, 700 + 2 * it + 1, False)
+        return types.SimpleNamespace(x=torch.cat([a.x, b.x]))
+
+    st = GraphedTrainStep(m, opt, [both(0)], gumbel_t=0.2, warmup=2)
+    for it in range(steps):
+        st([both(it)])
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    lr_travel = 2.8e-4 * steps
+    for k in r0:
+        d = (sd[k] - r0[k]).abs()
+        # (Adam turns 1e-6-relative gradient differences -- here: another summation order over the batch -- into O(lr) steps wherever
+        #  |g| ~ eps; the bulk must agree tightly, nothing may be off by more than a fraction of its possible travel)
+        assert float(d.max()) <= 0.5 * lr_travel, (k, float(d.max()))
+        assert float(d.median()) <= 0.01 * lr_travel, (k, float(d.median()))
