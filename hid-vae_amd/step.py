@@ -16,6 +16,7 @@ overlaps the rest of the backward:
 (DDP gives the reference the same thing by bucketing gradients in reverse registration order, train_hidvae.py:630-632,709.)  With
 gradient accumulation, or an optimizer built without a first bucket, the exchange is ONE all-reduce between graph[forward, backward]
 and graph[AdamW]."""
+import os
 import types
 
 import torch
@@ -28,7 +29,7 @@ class GraphedTrainStep:
     overwrites: clone it to keep it.  The first calls run eagerly (allocator / kernel-attribute warm-up, and the randomness
     provider learns the step's dropout requests); the capture happens on call number `warmup + 1`."""
 
-    def __init__(self, model, opt, example_batches, dp=None, gumbel_t=0.2, warmup=3, enabled=True):
+    def __init__(self, model, opt, example_batches, dp=None, gumbel_t=0.2, warmup=3, enabled=True, overlap=None):
         self.model, self.opt, self.dp, self.t = model, opt, dp, gumbel_t
         self.ga = len(example_batches)
         self.tagged = getattr(example_batches[0], "tags_emb", None) is not None
@@ -41,12 +42,23 @@ class GraphedTrainStep:
         self.one = torch.ones((), device=example_batches[0].x.device)
         self.row = None
         self.calls, self.warmup, self.enabled = 0, warmup, enabled
+        # overlap: None = by size.  Measured with one rank (bench.py --dist 1): the split costs ~50 us of fixed latency per step (a third
+        # graph launch, a second collective, two more cross-stream edges): 0.330 vs 0.277 ms on the 4.6 MB core model, where a whole
+        # 8-GPU all-reduce is of that order itself; on the 29 MB tagged model (1.94 vs 2.02 ms) it pays.  Hence: from 16 MB on.
+        self.overlap = overlap
         self.graphs = None
 
     # -- the step, as plain code (this is what gets captured)
     def _overlapped(self):
-        return (self.dp is not None and self.ga == 1 and self.opt.flat_grads and getattr(self.opt, "n_first", 0) > 0
-                and hasattr(self.model, "backward_rest"))
+        if not (self.dp is not None and self.ga == 1 and self.opt.flat_grads and getattr(self.opt, "n_first", 0) > 0
+                and hasattr(self.model, "backward_rest")):
+            return False
+        if self.overlap is not None:
+            return bool(self.overlap)
+        env = os.environ.get("HIDVAE_DP_OVERLAP")
+        if env is not None:
+            return env == "1"
+        return self.opt.grad_buffer.flat.numel() * 4 >= 16 * 1024 * 1024
 
     def _fwd_bwd(self):
         self.opt.zero_grad()

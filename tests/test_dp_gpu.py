@@ -64,7 +64,7 @@ def _run(tagged, dp_mode, steps=6, B=128):
     if multi:
         dp = DataParallel(m, opt.grad_buffer)
         dp.always = True
-    st = GraphedTrainStep(m, opt, [_batch(cfg, B, 500, tagged)], dp=dp, gumbel_t=0.2, warmup=2)
+    st = GraphedTrainStep(m, opt, [_batch(cfg, B, 500, tagged)], dp=dp, gumbel_t=0.2, warmup=2, overlap=True if multi else None)
     rows = []
     for it in range(steps):
         rows.append(st([_batch(cfg, B, 500 + it, tagged)]).clone())
@@ -107,7 +107,7 @@ def _rank_worker(rank, world, port, out_dir, steps, B):
     opt = HidvaeAdamW(_groups(m, False), cosine=(1000, 7e-8), flat_grads=True, first_bucket=m.dp_first_bucket(B)).prepare()
     dp = DataParallel(m, opt.grad_buffer)
     dp.broadcast_parameters(0)
-    st = GraphedTrainStep(m, opt, [_batch(cfg, B, 700, False)], dp=dp, gumbel_t=0.2, warmup=2)
+    st = GraphedTrainStep(m, opt, [_batch(cfg, B, 700, False)], dp=dp, gumbel_t=0.2, warmup=2, overlap=True)
     for it in range(steps):
         st([_batch(cfg, B, 700 + 2 * it + rank, False)])
     torch.cuda.synchronize()
