@@ -487,9 +487,11 @@ def main():
             roof = dict(kernel=describe_launch(top), bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF,
                         traffic=None, us=top["us_per_launch"], share_of_step=top["share"],
                         us_warm=warm["us"] if warm else None, frac_warm=warm["frac"] if warm else None)
-            for key, val in pmc.items():  # (only a PMC row taken of exactly this launch counts)
-                if roof["kernel"].startswith(key):
-                    roof["traffic"] = val
+            # the family's single largest launch, in-step, with the PMC traffic of exactly that launch when profiles/ holds it
+            big = max((r for r in rows if r["entry"] == top["entry"]), key=lambda r: r["us"])
+            roof["largest_launch"] = dict(MxNxK=[big.get("M"), big.get("N"), big.get("K")], us=big["us"],
+                                          achieved=big.get("flops", 0.0) / big["us"] * 1e-6, frac=big.get("flops", 0.0) / big["us"] * 1e-6 / MFMA_F32_PEAK_TF,
+                                          traffic=(warm or {}).get("traffic"), us_warm=(warm or {}).get("us"))
         if roof is None:
             roof = dict(ks[0])
         line = {
@@ -502,7 +504,7 @@ def main():
                                    f" train step = fwd+bwd+{'RCCL all-reduce+' if world > 1 else ''}AdamW(cosine)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(use_graph)},
             "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"], "us_per_launch": roof["us"]}
-                        | {k: roof[k] for k in ("share_of_step", "us_warm", "frac_warm") if k in roof},
+                        | {k: roof[k] for k in ("share_of_step", "us_warm", "frac_warm", "largest_launch") if k in roof},
             "windows_ms_per_step": info["windows_ms_per_step"],
             "kernels": ks, "final_loss": final_loss,
         }

@@ -1055,7 +1055,8 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
         const int64_t wgs = hv_cdiv(M, 64) * hv_cdiv(N, 64);
         while (deep_splits > 2 && wgs * deep_splits > 2048) deep_splits /= 2;
     }
-    const bool big = (tiles32 >= 2048 && K >= 64) || !fits32 || deep_splits > 1;
+    static const int force_tiled = getenv("HIDVAE_GEMM_FORCE_TILED") ? atoi(getenv("HIDVAE_GEMM_FORCE_TILED")) : 0;  // (experiments)
+    const bool big = (tiles32 >= 2048 && K >= 64) || !fits32 || deep_splits > 1 || (force_tiled && split_k > 1 && workspace != nullptr);
     if (!big || split_k == 1) {
         if (!big) {
             // direct path.  split_k == 1: one wave per tile, sequential (ORDER-G) chain; otherwise spread K over up to 16

@@ -53,7 +53,17 @@ class HSemanticIdTokenizer(nn.Module):
 
     def reset(self):
         self.cached_ids = None
+
+    @property
+    def cached_ids(self):
+        return self.__dict__.get("_cached_ids")
+
+    @cached_ids.setter
+    def cached_ids(self, ids):
+        # (an assignment from outside drops the sorted-prefix index and the knowledge that every id is below the codebook size)
+        self.__dict__["_cached_ids"] = ids
         self._prefix_index = {}
+        self._ids_trusted = False
 
     @property
     def sem_ids_dim(self):
@@ -110,6 +120,7 @@ class HSemanticIdTokenizer(nn.Module):
             parts = [self._ids_for(feats[i:i + CORPUS_CHUNK]) for i in range(0, feats.shape[0], CORPUS_CHUNK)]
             self.cached_ids = torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
         self._prefix_index = {}
+        self._ids_trusted = True
         return self.cached_ids
 
     # ------------------------------------------------------------------------------------------------
@@ -129,7 +140,12 @@ class HSemanticIdTokenizer(nn.Module):
         if self.cached_ids.shape[0] == 0 or width == 0:
             return out
         if width not in self._prefix_index:
-            radix = int(max(int(self.cached_ids.max()), self.codebook_size - 1, *(self.tag_class_counts or [0]))) + 2
+            # ids produced by precompute_corpus_ids are < codebook_size (semantic) / < the level's class count (predicted tags): the
+            # radix is known without reading the device; a cache assigned from outside is checked once (one host read)
+            bound = max(self.codebook_size - 1, *(self.tag_class_counts or [0]))
+            if not getattr(self, "_ids_trusted", False):
+                bound = max(bound, int(self.cached_ids.max()))
+            radix = int(bound) + 2
             if radix ** width >= 2 ** 62:
                 raise OverflowError("id prefix does not fit a 64-bit key")
             self._prefix_index[width] = (radix, torch.sort(self._keys(self.cached_ids[:, :width], width, radix)).values)
