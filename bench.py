@@ -404,6 +404,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("HIDVAE_DIST_BACKEND", "nccl") != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
@@ -411,7 +413,10 @@ def main():
         import torch.distributed as dist
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm.  HIDVAE_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU (RCCL refuses two
+        # ranks on one device); then every rank uses device LOCAL_RANK % device_count
+        backend = os.environ.get("HIDVAE_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
 
     dt, m, info = run_workload(args, device, rank, world, dist)
     use_graph, final_loss = info["hip_graph"], info["final_loss"]
