@@ -607,6 +607,7 @@ struct PairArgs {
     int64_t cs_ld, cs_rows, cs_cols;
     float *cs_out;         // db [cols] (nullptr: no bias)
     int cs_accumulate;
+    int lds_a;             // pair32: stage the NN product's k-contiguous A operand through LDS (coalesced loads)
 };
 
 // bias gradient db[c] = sum_b g[b, c]: 32 columns per workgroup, blockDim/32 row groups, partials added in ascending group order
@@ -738,9 +739,122 @@ __global__ __launch_bounds__(64 * SPLIT * NWN) void gemm_direct_kernel(GemmArgs 
     }
 }
 
+// ---- the direct kernel with COALESCED operand loads (k-contiguous operands) ------------------------------------------------------
+// What bounds gemm_direct_kernel at the step's sizes is how its operands arrive, not the MFMA pipe: a lane reads 16
+// bytes of ITS OWN row, so one wave instruction touches 32 different cache lines and uses 32 bytes of each; a stand-alone model of
+// exactly that stream (scratch/mb/loadpat.hip) pulls 4-6.7 TB/s out of L2 chip-wide whatever the ring depth, the same strips read
+// as 8 rows x 128 contiguous bytes per instruction 10-20 TB/s.  The MFMA fragment layout puts neighbouring ROWS on neighbouring
+// lanes, so a coalesced read needs a transposition on the way: here through a PRIVATE LDS strip per wave -- no other wave ever touches
+// it, the LDS unit executes one wave's instructions in order, so there is no barrier and no wait beyond the data's own.
+//   stage = 32 k (two 16-blocks): lane -> row (lane >> 3) + 8 t, bytes [16 (lane & 7), +16) of the row's 128, t = 0..3 : four 16-byte
+//   loads per operand, written as ds_write_b128 at [row][k] (144-byte rows: 16-byte aligned, bank groups rotate by one per row);
+//   the fragment of a 16-block is then the same two 16-byte pieces per lane the register path loads from memory (x = k0 + 4h ..,
+//   y = k0 + 8 + 4h ..) as two ds_read_b128 -- identical registers, identical ORDER-G16 chain, bit-identical results.
+// Operands whose ROWS are contiguous in memory (A of TN, B of NN / TN) already read 128 contiguous bytes per half-wave and keep the
+// register path.
+constexpr int LSTR = 36;  // floats per staged row: 32 k + 4 (144 bytes)
+
+// one wave's accumulation of tile (m0, n0) over 16-blocks [b_lo, b_hi) (+ the ragged tail block when do_tail): sA / sB = the wave's
+// private strips (32 * LSTR floats each; sB unused for a row-contiguous B)
+template <int LAYOUT>
+__device__ __forceinline__ void directL_accumulate(const GemmArgs &g, int64_t m0, int64_t n0, int b_lo, int b_hi, bool do_tail, float *sA,
+                                                   float *sB, f32x16 &acc) {
+    constexpr bool B_KC = (LAYOUT == HIDVAE_GEMM_NT);
+    static_assert(LAYOUT != HIDVAE_GEMM_TN, "the LDS-transposed loader serves k-contiguous A operands (NT, NN)");
+    const int lane = threadIdx.x & 63;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int lda4 = (int)g.lda * 4, ldb4 = (int)g.ldb * 4, Ki = (int)g.K;
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.A), 0, (int)(4 * ((g.M - 1) * g.lda + g.K)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.B), 0, (int)(4 * (B_KC ? (g.N - 1) * g.ldb + g.K : (g.K - 1) * g.ldb + g.N)), 0x00020000);
+    // coalesced slots: t-th load of this lane = row (lane >> 3) + 8 t of the tile, bytes 16 (lane & 7) of the 32-k stage
+    const int lr = lane >> 3, lk = lane & 7;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int64_t ra = (m0 + lr + 8 * t < g.M) ? m0 + lr + 8 * t : g.M - 1;
+        const int64_t rb = (n0 + lr + 8 * t < g.N) ? n0 + lr + 8 * t : g.N - 1;
+        offA[t] = (int)(ra * g.lda) * 4 + 16 * lk;
+        offB[t] = B_KC ? (int)(rb * g.ldb) * 4 + 16 * lk : 0;
+    }
+    // register-path offsets (the ragged tail block, and a row-contiguous B)
+    const int64_t rra = (m0 + i32 < g.M) ? m0 + i32 : g.M - 1;
+    const int64_t rrb = (n0 + i32 < g.N) ? n0 + i32 : g.N - 1;
+    const int va = 4 * ((int)(rra * g.lda) + 4 * h);
+    const int vb = 4 * (B_KC ? (int)(rrb * g.ldb) + 4 * h : (int)(4 * h * g.ldb + rrb));
+    const int nfull = Ki / 16;
+    f32x4 pa[4], pb[4];       // the next stage's coalesced loads
+    float rbv[2][8];          // a row-contiguous B keeps the register path: the stage's two blocks
+    auto fetch = [&](int blk) {  // stage starting at 16-block `blk`: blocks blk and blk+1 where they lie inside [b_lo, b_hi)
+        const int nb = b_hi - blk;  // <= 0: nothing, 1: half a stage
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const bool in = nb >= 2 || (nb == 1 && lk < 4);
+            pa[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, in ? offA[t] : HV_OOB, blk * 64, 0));
+            if (B_KC) pb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, in ? offB[t] : HV_OOB, blk * 64, 0));
+        }
+        if (!B_KC) {
+            load_block<false>(rb_rsrc, ldb4, nb >= 1 ? vb : HV_OOB, blk * 16, rbv[0]);
+            load_block<false>(rb_rsrc, ldb4, nb >= 2 ? vb : HV_OOB, blk * 16 + 16, rbv[1]);
+        }
+    };
+    fetch(b_lo);
+    for (int blk = b_lo; blk < b_hi; blk += 2) {
+        // this wave's staged strip: written and read by this wave only, in program order (no barrier)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            *reinterpret_cast<f32x4 *>(sA + (lr + 8 * t) * LSTR + 4 * lk) = pa[t];
+            if (B_KC) *reinterpret_cast<f32x4 *>(sB + (lr + 8 * t) * LSTR + 4 * lk) = pb[t];
+        }
+        float bcur[2][8];
+        if (!B_KC) {
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) bcur[u][j] = rbv[u][j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float fa[2][8], fb[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(sA + i32 * LSTR + 16 * u + 4 * h);
+            const f32x4 y = *reinterpret_cast<const f32x4 *>(sA + i32 * LSTR + 16 * u + 8 + 4 * h);
+            fa[u][0] = x[0]; fa[u][1] = y[0]; fa[u][2] = x[1]; fa[u][3] = y[1]; fa[u][4] = x[2]; fa[u][5] = y[2]; fa[u][6] = x[3]; fa[u][7] = y[3];
+            if (B_KC) {
+                const f32x4 p = *reinterpret_cast<const f32x4 *>(sB + i32 * LSTR + 16 * u + 4 * h);
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(sB + i32 * LSTR + 16 * u + 8 + 4 * h);
+                fb[u][0] = p[0]; fb[u][1] = q[0]; fb[u][2] = p[1]; fb[u][3] = q[1]; fb[u][4] = p[2]; fb[u][5] = q[2]; fb[u][6] = p[3]; fb[u][7] = q[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) fb[u][j] = bcur[u][j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        fetch(blk + 2);  // the next stage's loads fly behind this stage's 16 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s8], fb[0][s8], acc, 0, 0, 0);
+        if (blk + 1 < b_hi) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][s8], fb[1][s8], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (do_tail && nfull * 16 < Ki) {  // the ragged last block: per-element register path, as gemm_direct_kernel
+        float ta[8], tb[8];
+        load_tail<true>(ra_rsrc, lda4, va, nfull * 16, Ki, h, ta);
+        load_tail<B_KC>(rb_rsrc, ldb4, vb, nfull * 16, Ki, h, tb);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[s8], tb[s8], acc, 0, 0, 0);
+    }
+}
+
 // the 32x32-tile twin of direct16_body / gemm_pair16_kernel: same arithmetic as gemm_direct_kernel with a run-time split
+// stageL (NN only, optional): 32 * LSTR floats per wave -- the k-contiguous A operand then arrives through directL_accumulate
 template <int LAYOUT, int NS>
-__device__ __forceinline__ void direct32_body(const GemmArgs &g, int split, int64_t tile0, int64_t ntiles, int nbx, float *part) {
+__device__ __forceinline__ void direct32_body(const GemmArgs &g, int split, int64_t tile0, int64_t ntiles, int nbx, float *part,
+                                              float *stageL = nullptr) {
     constexpr bool A_KC = (LAYOUT != HIDVAE_GEMM_TN);
     constexpr bool B_KC = (LAYOUT == HIDVAE_GEMM_NT);
     const int lane = threadIdx.x & 63;
@@ -764,6 +878,10 @@ __device__ __forceinline__ void direct32_body(const GemmArgs &g, int split, int6
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        if (LAYOUT == HIDVAE_GEMM_NN && stageL != nullptr) {  // coalesced A through this wave's private LDS strip: same chain, same bits
+            if constexpr (LAYOUT == HIDVAE_GEMM_NN)
+                directL_accumulate<HIDVAE_GEMM_NN>(g, m0, n0, b_lo, b_hi, w == split - 1, stageL + wv * (32 * LSTR), nullptr, acc);
+        } else {
         float ra_[NS][8], rb_[NS][8];
         auto load = [&](float (&av)[8], float (&bv)[8], int blk) {
             const bool in = blk < b_hi;
@@ -787,6 +905,7 @@ __device__ __forceinline__ void direct32_body(const GemmArgs &g, int split, int6
             load_tail<B_KC>(rb_rsrc, ldb4, vb, nfull * 16, Ki, h, rb_[0]);
 #pragma unroll
             for (int s8 = 0; s8 < 8; s8++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[0][s8], rb_[0][s8], acc, 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) part[wv * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i32] = acc[r];
@@ -814,12 +933,74 @@ __device__ __forceinline__ void direct32_body(const GemmArgs &g, int split, int6
 template <int NS1>
 __global__ __launch_bounds__(512) void gemm_pair32_kernel(PairArgs p) {
     __shared__ float part[8 * 1024];
+    __shared__ __attribute__((aligned(16))) float stageL[8 * 32 * LSTR];  // dX = g W: the k-contiguous g rows arrive coalesced (directL)
     const int bid = blockIdx.x;
     const int waves = (int)(blockDim.x >> 6);
     if (bid < p.nb0) direct32_body<HIDVAE_GEMM_TN, 3>(p.g0, p.split0, (int64_t)xcd_slot(bid, p.nb0) * (waves / p.split0), p.nt0, p.nbx0, part);
     else if (bid < p.nb0 + p.nb1)
-        direct32_body<HIDVAE_GEMM_NN, NS1>(p.g1, p.split1, (int64_t)xcd_slot(bid - p.nb0, p.nb1) * (waves / p.split1), p.nt1, p.nbx1, part);
+        direct32_body<HIDVAE_GEMM_NN, NS1>(p.g1, p.split1, (int64_t)xcd_slot(bid - p.nb0, p.nb1) * (waves / p.split1), p.nt1, p.nbx1, part,
+                                          p.lds_a ? stageL : nullptr);
     else colsum32_body(p, (int64_t)(bid - p.nb0 - p.nb1) * 32, part);
+}
+
+template <int LAYOUT, int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void gemm_directL_kernel(GemmArgs g) {
+    __shared__ float part[SPLIT > 1 ? SPLIT * 1024 : 1];
+    __shared__ __attribute__((aligned(16))) float stage[SPLIT * 2 * 32 * LSTR];
+    const int lane = threadIdx.x & 63;
+    const int w = SPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i32 = lane & 31, h = lane >> 5;
+    int bx = blockIdx.x, by = blockIdx.y;
+    xcd_tile(gridDim.x, gridDim.y, g.M >= g.N, bx, by);
+    const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
+    const int nfull = (int)g.K / 16;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    directL_accumulate<LAYOUT>(g, m0, n0, nfull * w / SPLIT, nfull * (w + 1) / SPLIT, w == SPLIT - 1, stage + w * (2 * 32 * LSTR),
+                               stage + w * (2 * 32 * LSTR) + 32 * LSTR, acc);
+    const float *mk = g.mask;
+    if (SPLIT == 1) {
+        const int64_t col = n0 + i32;
+        if (col >= g.N) return;
+        const float bias = g.bias != nullptr ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= g.M) continue;
+            float v = acc[r] + bias;
+            if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            float *dst = g.C + row * g.ldc + col;
+            *dst = g.accumulate ? *dst + v : v;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) part[w * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i32] = acc[r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 1024; e += 64 * SPLIT) {
+            float v = part[e];
+#pragma unroll
+            for (int sidx = 1; sidx < SPLIT; sidx++) v += part[sidx * 1024 + e];  // fixed order: bit-reproducible
+            const int64_t row = m0 + (e >> 5), col = n0 + (e & 31);
+            if (row >= g.M || col >= g.N) continue;
+            v += g.bias != nullptr ? g.bias[col] : 0.0f;
+            if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            float *dst = g.C + row * g.ldc + col;
+            *dst = g.accumulate ? *dst + v : v;
+        }
+    }
+}
+
+template <int SPLIT>
+void launch_directL(int layout, const GemmArgs &g, hipStream_t s) {
+    dim3 grid((unsigned)hv_cdiv(g.N, 32), (unsigned)hv_cdiv(g.M, 32));
+    dim3 block(64 * SPLIT);
+    if (layout == HIDVAE_GEMM_NT) hipLaunchKernelGGL((gemm_directL_kernel<HIDVAE_GEMM_NT, SPLIT>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_directL_kernel<HIDVAE_GEMM_NN, SPLIT>), grid, block, 0, s, g);
 }
 
 template <int SPLIT, int NS, int NWN = 1>
@@ -1076,6 +1257,20 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
                 return HIDVAE_OK;
             }
             const int sp = pick_split32(M, N, K, split_k);
+            // HIDVAE_GEMM_LDS: 0 = register path only, 1 = the LDS-transposed loader wherever it applies, default (2) = where it
+            // measured faster: K shared out over >= 2 waves per tile, or >= 1024 tiles (one exact chain per tile at 512 tiles --
+            // the encoder's first layer at B = 1024 -- is bound by the chain itself: 21.5 us against 18.4 us)
+            static const int use_lds = getenv("HIDVAE_GEMM_LDS") ? atoi(getenv("HIDVAE_GEMM_LDS")) : 2;
+            if (layout != HIDVAE_GEMM_TN && sp <= 8 && (use_lds == 1 || (use_lds == 2 && (sp >= 2 || tiles32 >= 1024)))) {
+                switch (sp) {
+                    case 1: launch_directL<1>(layout, g, s); break;
+                    case 2: launch_directL<2>(layout, g, s); break;
+                    case 4: launch_directL<4>(layout, g, s); break;
+                    default: launch_directL<8>(layout, g, s); break;
+                }
+                HV_LAUNCH_CHECK("gemm_f32 directL");
+                return HIDVAE_OK;
+            }
             const bool deep = K / (16 * sp) >= 12;  // long chains per wave: keep 5 blocks of loads in flight instead of 2
             switch (sp) {
                 case 1: if (deep) launch_direct<1, 6>(layout, g, s); else launch_direct<1, 3>(layout, g, s); break;
@@ -1153,6 +1348,11 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
     p.nb1 = (int)hv_cdiv(p.nt1, waves / p.split1);
     p.cs_x = g; p.cs_ld = ldg; p.cs_rows = B; p.cs_cols = n_out; p.cs_out = db; p.cs_accumulate = accumulate_db;
     const int nbc = db != nullptr ? (int)hv_cdiv(n_out, 32) : 0;
+    // (measured: staging the NN half's A operand through LDS makes the paired launch SLOWER -- tagged step 1.913 -> 1.959 ms, B = 2048
+    //  3.02 -> 3.09 ms: its row-contiguous B operand still takes 8 scalar loads per block and the 2-block stage is shallower than
+    //  the 6-deep register ring; only HIDVAE_GEMM_LDS=1 turns it on)
+    static const int pair_lds = getenv("HIDVAE_GEMM_LDS") ? atoi(getenv("HIDVAE_GEMM_LDS")) : 2;
+    p.lds_a = pair_lds == 1;
     const dim3 grid((unsigned)(p.nb0 + p.nb1 + nbc)), block(64 * waves);
     if (pair16) hipLaunchKernelGGL(gemm_pair16_kernel, grid, block, 0, (hipStream_t)stream, p);
     else if (n_out / (16 * p.split1) >= 12) hipLaunchKernelGGL(gemm_pair32_kernel<6>, grid, block, 0, (hipStream_t)stream, p);
