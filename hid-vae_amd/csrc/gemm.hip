@@ -995,6 +995,107 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_directL_kernel(GemmArgs g) {
     }
 }
 
+// ---- the same idea on 16x16 tiles (v_mfma_f32_16x16x4_f32), NT, one exact chain per output: four times the waves of the 32x32 form.
+// Per 32-k stage a wave reads its 16 A rows and 16 B rows as 8 rows x 128 contiguous bytes per instruction (2 + 2 loads), parks them
+// in its private strips [16][LSTR] and takes each 16-block's fragment as ONE ds_read_b128 per operand (lane (i, q): k0 + 4q .. + 3,
+// what load_block16 reads from memory).  WAVES waves per workgroup, each on its own tile (no barrier anywhere).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gemm_directL16_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float stage[WAVES * 2 * 16 * LSTR];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    float *sA = stage + wv * (2 * 16 * LSTR), *sB = sA + 16 * LSTR;
+    const int nbx = (int)((g.N + 15) / 16), nby = (int)((g.M + 15) / 16);
+    const int64_t ntiles = (int64_t)nbx * nby;
+    const int64_t nslots = (ntiles + WAVES - 1) / WAVES;
+    const int64_t tile = (int64_t)xcd_slot((int)blockIdx.x, (int)nslots) * WAVES + wv;  // neighbouring column tiles share a workgroup
+    if (tile >= ntiles) return;
+    const int64_t m0 = (tile / nbx) * 16, n0 = (tile % nbx) * 16;
+    const int lda4 = (int)g.lda * 4, ldb4 = (int)g.ldb * 4, Ki = (int)g.K;
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.A), 0, (int)(4 * ((g.M - 1) * g.lda + g.K)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.B), 0, (int)(4 * ((g.N - 1) * g.ldb + g.K)), 0x00020000);
+    const int lr = lane >> 3, lk = lane & 7;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int64_t ra = (m0 + lr + 8 * t < g.M) ? m0 + lr + 8 * t : g.M - 1;
+        const int64_t rb = (n0 + lr + 8 * t < g.N) ? n0 + lr + 8 * t : g.N - 1;
+        offA[t] = (int)(ra * g.lda) * 4 + 16 * lk;
+        offB[t] = (int)(rb * g.ldb) * 4 + 16 * lk;
+    }
+    const int64_t rra = (m0 + i16 < g.M) ? m0 + i16 : g.M - 1;
+    const int64_t rrb = (n0 + i16 < g.N) ? n0 + i16 : g.N - 1;
+    const int va = 4 * ((int)(rra * g.lda) + 4 * q), vb = 4 * ((int)(rrb * g.ldb) + 4 * q);
+    const int nfull = Ki / 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pa[2][2], pb[2][2];  // two stages of coalesced loads in flight
+    auto fetch = [&](int st, int blk) {
+        const int nb = nfull - blk;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const bool in = nb >= 2 || (nb == 1 && lk < 4);
+            pa[st][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, in ? offA[t] : HV_OOB, blk * 64, 0));
+            pb[st][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, in ? offB[t] : HV_OOB, blk * 64, 0));
+        }
+    };
+    auto consume = [&](int st, int blk) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            *reinterpret_cast<f32x4 *>(sA + (lr + 8 * t) * LSTR + 4 * lk) = pa[st][t];
+            *reinterpret_cast<f32x4 *>(sB + (lr + 8 * t) * LSTR + 4 * lk) = pb[st][t];
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4 fa[2], fb[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            fa[u] = *reinterpret_cast<const f32x4 *>(sA + i16 * LSTR + 16 * u + 4 * q);
+            fb[u] = *reinterpret_cast<const f32x4 *>(sB + i16 * LSTR + 16 * u + 4 * q);
+        }
+        __builtin_amdgcn_wave_barrier();
+        fetch(st, blk + 4);  // this stage's registers are free again: request the stage after next
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][s4], fb[0][s4], acc, 0, 0, 0);
+        if (blk + 1 < nfull) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1][s4], fb[1][s4], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch(0, 0);
+    fetch(1, 2);
+    for (int blk = 0; blk < nfull; blk += 4) {
+        consume(0, blk);
+        if (blk + 2 < nfull) consume(1, blk + 2);
+    }
+    if (nfull * 16 < Ki) {  // the ragged last block: per-element register path
+        float ta[4], tb[4];
+        load_tail16<true>(ra_rsrc, lda4, va, nfull * 16, Ki, q, ta);
+        load_tail16<true>(rb_rsrc, ldb4, vb, nfull * 16, Ki, q, tb);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s4], tb[s4], acc, 0, 0, 0);
+    }
+    // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+    const int64_t col = n0 + i16;
+    if (col >= g.N) return;
+    const float bias = g.bias != nullptr ? g.bias[col] : 0.0f;
+    const float *mk = g.mask;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int64_t row = m0 + 4 * q + r;
+        if (row >= g.M) continue;
+        float v = acc[r] + bias;
+        if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+        if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+        float *dst = g.C + row * g.ldc + col;
+        *dst = g.accumulate ? *dst + v : v;
+    }
+}
+
 template <int SPLIT>
 void launch_directL(int layout, const GemmArgs &g, hipStream_t s) {
     dim3 grid((unsigned)hv_cdiv(g.N, 32), (unsigned)hv_cdiv(g.M, 32));
@@ -1243,6 +1344,19 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
             // direct path.  split_k == 1: one wave per tile, sequential (ORDER-G) chain; otherwise spread K over up to 16
             // waves of the workgroup until the chip has ~2 waves per SIMD or the chunks get shorter than 32
             // few tiles: 16x16 tiles (4x the waves, shorter dependent MFMA chains) -- the latency-optimised form
+            // NT with ONE exact chain per output (the id-determining forward layers), and the small NT problems the 16x16 form serves
+            // anyway: 16x16 tiles with coalesced operand loads through per-wave LDS strips (gemm_directL16_kernel).  Bit-identical to
+            // the register-path kernels (same ORDER-G16 chain); measured at B = 1024: 1024x512x768 19.5 -> 15.5 us, 1024x768x512
+            // 19.5 -> 13.2, 1024x256x512 10.8 -> 7.9, 1024x512x256 11.3 -> 7.4, 1000x300x333 12.7 -> 8.6 (HIDVAE_GEMM_L16=0: off)
+            static const int use_l16 = getenv("HIDVAE_GEMM_L16") ? atoi(getenv("HIDVAE_GEMM_L16")) : 1;
+            const int64_t nt16 = hv_cdiv(M, 16) * hv_cdiv(N, 16);
+            if (use_l16 && layout == HIDVAE_GEMM_NT && nt16 >= 512 && nt16 <= 8192 && K >= 64 &&
+                (split_k == 1 || use_l16 == 2 || (use_direct16(M, N, K) && K >= 128))) {
+                constexpr int W16 = 4;
+                hipLaunchKernelGGL(gemm_directL16_kernel<W16>, dim3((unsigned)hv_cdiv(nt16, W16)), dim3(64 * W16), 0, s, g);
+                HV_LAUNCH_CHECK("gemm_f32 directL16");
+                return HIDVAE_OK;
+            }
             if (use_direct16(M, N, K)) {
                 const int sp16 = pick_split16(M, N, K, split_k);
                 const bool deep16 = K / (16 * sp16) >= 12;
