@@ -116,7 +116,7 @@ def time_kernel(fn, launches=20, reps=20):
 
 def kernel_rooflines(args, m, device):
     """Live per-kernel timings on the bench shapes.
-    * gemm_direct_kernel (fp32 MFMA roofline, 157.3 TFLOP/s): the largest GEMMs of the step, forward and backward;
+    * gemm_directL16_kernel / gemm_direct_kernel / gemm_pair32_kernel (fp32 MFMA roofline, 157.3 TFLOP/s): the largest GEMMs of the step;
     * rq_forward_kernel (HBM roofline, 8 TB/s): ALGORITHMIC bytes per item exactly as SURVEY.md 8(d) counts them for the tagged
       variant: read z 128 B, write ids 8L, per-level emb_out 128L, loss 4 = 540 B at L=3 (+ the codebooks 4*L*K*32 once per
       launch).  The launch also writes emb_sum and z (128 B each, consumed by the decoder and the backward): `bytes_moved`
@@ -131,7 +131,7 @@ def kernel_rooflines(args, m, device):
     a0 = torch.empty(B, 512, device=device)
     t = time_kernel(lambda: _C.gemm(_C.GEMM_NT, x, w0, out=o0, epilogue=_C.EPI_SILU, aux=a0))
     fl = 2.0 * B * 768 * 512
-    out.append(dict(entry="hidvae_gemm_f32", kernel="gemm_direct_kernel<NT,1,6> encoder layer 0: [B,768]x[768,512]^T + SiLU (exact ORDER-G chain)", bound="mfma",
+    out.append(dict(entry="hidvae_gemm_f32", kernel="gemm_directL16_kernel encoder layer 0: [B,768]x[768,512]^T + SiLU (exact ORDER-G chain, coalesced loads through per-wave LDS strips)", bound="mfma",
                     achieved=fl / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
                     us=t, flops=fl))
     g = torch.randn(B, 512, device=device)

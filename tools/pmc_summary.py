@@ -12,7 +12,7 @@ from collections import defaultdict
 
 # bench.py kernel-name prefix  <-  (substring of the profiled kernel name, grid size in work-items)
 QUOTED = [
-    ("gemm_direct_kernel<NT,1,6> encoder layer 0", "gemm_direct_kernel<0, 1, 6", None),
+    ("gemm_directL16_kernel encoder layer 0", "gemm_directL16_kernel<4>", None),
     ("gemm_direct_kernel<TN,8,3> dW encoder layer 0", "gemm_direct_kernel<2, 8, 3", None),
     ("rq_forward_kernel (fused L-level VQ, code-split variant)", "rq_forward_kernel<3, true, true, true", None),
     ("rq_forward at 1,048,576 items", "rq_forward_pf32_kernel<3, true", None),
