@@ -83,7 +83,7 @@ _SIGNATURES = {
     "hidvae_layernorm_bwd_all_group": [_vp, _i, _vp],
 }
 WS_GEMM, WS_LINEAR_BWD, WS_COLSUM, WS_CODEBOOK_GRAD, WS_LAYERNORM_PARAM_GRAD, WS_LAYERNORM_BWD_ALL = 1, 2, 3, 4, 5, 6
-WS_BATCHNORM_FWD, WS_BATCHNORM_BWD, WS_ID_CENSUS, WS_KMEANS, WS_TAG_LOSS = 7, 8, 9, 10, 11
+WS_BATCHNORM_FWD, WS_BATCHNORM_BWD, WS_ID_CENSUS, WS_KMEANS, WS_TAG_LOSS, WS_LINEAR_BWD_ZEROED = 7, 8, 9, 10, 11, 12
 
 
 class LaunchStamps:
@@ -259,6 +259,35 @@ def _ws(op, device, *dims):
     return torch.empty((n // 4,), device=device, dtype=torch.float32) if n else None
 
 
+# hidvae_linear_bwd's balanced kernel keeps arrival counters at the head of its workspace: zero on entry, zero again on return, and
+# never shared by launches that may run at the same time.  Launches on one stream are serialised, so ONE persistent zero-filled
+# buffer per (device, lane) serves them all; lane 0 is "whatever stream the caller is on", and every side stream that runs Linear
+# backwards concurrently with it (the per-level tag-head streams) registers a lane of its own.
+_WS_LANES = {}
+_WS_LANE_BUFFERS = {}
+_WS_RETIRED = []  # outgrown buffers stay alive: a captured graph may still hold their address
+
+
+def register_ws_lane(stream):
+    """Give `stream` its own hidvae_linear_bwd workspace (call once per side stream that runs backward GEMMs concurrently)."""
+    return _WS_LANES.setdefault(int(stream.cuda_stream), len(_WS_LANES) + 1)
+
+
+def _lane_ws(device, nbytes):
+    lane = _WS_LANES.get(int(torch.cuda.current_stream(device).cuda_stream), 0)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), lane)
+    buf = _WS_LANE_BUFFERS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            # first use inside a capture: a buffer of the capture's own (its zero-fill replays with the graph); never shared
+            return torch.zeros((nbytes // 4,), device=device, dtype=torch.float32)
+        if buf is not None:
+            _WS_RETIRED.append(buf)
+        buf = torch.zeros((nbytes // 4,), device=device, dtype=torch.float32)
+        _WS_LANE_BUFFERS[key] = buf
+    return buf
+
+
 def census_scratch(B, device):
     """A fresh, zero-filled id-census table for batches of B items (hidvae_id_stats / hidvae_bottleneck_fwd).  The CALLER owns it:
     its address is baked into any HIP graph that captured a launch using it, so it must live as long as that graph does."""
@@ -369,7 +398,10 @@ def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accu
     if bias and db is None:
         db = torch.empty((n_out,), device=g.device, dtype=torch.float32)
         accumulate_db = False
-    ws = _ws(WS_LINEAR_BWD, g.device, B, n_out, n_in, int(bool(bias)))
+    if workspace_bytes(WS_LINEAR_BWD_ZEROED, B, n_out, n_in, int(bool(bias))):
+        ws = _lane_ws(g.device, workspace_bytes(WS_LINEAR_BWD, B, n_out, n_in, int(bool(bias))))
+    else:
+        ws = _ws(WS_LINEAR_BWD, g.device, B, n_out, n_in, int(bool(bias)))
     _check(lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
                                    _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, int(bool(accumulate)), _p(dX), n_in,
                                    int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, _p(db if bias else None),

@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include "../../include/hidvae.h"
+#include "rules.h"
 
 static thread_local char g_err[512] = "";
 
@@ -37,8 +38,14 @@ extern "C" int hidvae_query_workspace(int op, const int64_t *d, int n, int64_t *
         if (!need(4)) break;
         fl = d[3] ? cdiv(d[0], 64) * d[1] : 0;
         if (d[0] >= 4096 && 16 * d[1] * d[2] > fl) fl = 16 * d[1] * d[2];
+        // shapes of the balanced kernel: its arrival counters lead the buffer, everything else (its partial tiles, or the scratch of
+        // the other paths when a call of this shape does not take it -- dX == NULL halves the work) comes after them
+        if (hv_lbwd_balanced(d[0], d[1], d[2])) fl = HV_SK_COUNTERS + (fl > HV_SK_WS_FLOATS - HV_SK_COUNTERS ? fl : HV_SK_WS_FLOATS - HV_SK_COUNTERS);
         break;
     }
+    case HIDVAE_WS_LINEAR_BWD_ZEROED:  // B, n_out, n_in, has_bias: leading bytes that must be zero on entry (and are zero on return)
+        if (need(3)) fl = hv_lbwd_balanced(d[0], d[1], d[2]) ? HV_SK_COUNTERS : 0;
+        break;
     case HIDVAE_WS_COLSUM: if (need(2)) fl = cdiv(d[0], 64) * d[1]; break;                             // M, N
     case HIDVAE_WS_CODEBOOK_GRAD: if (need(3)) fl = d[0] > 2048 ? d[1] * d[2] * cdiv(d[0], 2048) * HIDVAE_EMBED_DIM : 0; break;  // B, L, K
     case HIDVAE_WS_LAYERNORM_PARAM_GRAD: if (need(2)) fl = 2 * cdiv(d[0], 128) * d[1]; break;          // M, N

@@ -15,6 +15,7 @@
 // barrier per k-tile).
 #include <stdlib.h>
 #include "common.h"
+#include "rules.h"
 
 namespace {
 
@@ -930,12 +931,15 @@ __device__ __forceinline__ void direct32_body(const GemmArgs &g, int split, int6
     }
 }
 
+// dynamic LDS: 4 KB of split-K partials per wave (+ a 32 x LSTR strip per wave with lds_a) -- sized by the launch, because a static
+// 8-wave allocation (68 KB with the strips) held the usual 4-wave workgroups at two per CU where registers allow four
 template <int NS1>
 __global__ __launch_bounds__(512) void gemm_pair32_kernel(PairArgs p) {
-    __shared__ float part[8 * 1024];
-    __shared__ __attribute__((aligned(16))) float stageL[8 * 32 * LSTR];  // dX = g W: the k-contiguous g rows arrive coalesced (directL)
+    extern __shared__ __attribute__((aligned(16))) float pair_lds[];
     const int bid = blockIdx.x;
     const int waves = (int)(blockDim.x >> 6);
+    float *part = pair_lds;
+    float *stageL = pair_lds + waves * 1024;  // dX = g W: the k-contiguous g rows arrive coalesced (directL), only with lds_a
     if (bid < p.nb0) direct32_body<HIDVAE_GEMM_TN, 3>(p.g0, p.split0, (int64_t)xcd_slot(bid, p.nb0) * (waves / p.split0), p.nt0, p.nbx0, part);
     else if (bid < p.nb0 + p.nb1)
         direct32_body<HIDVAE_GEMM_NN, NS1>(p.g1, p.split1, (int64_t)xcd_slot(bid - p.nb0, p.nb1) * (waves / p.split1), p.nt1, p.nbx1, part,
@@ -943,10 +947,281 @@ __global__ __launch_bounds__(512) void gemm_pair32_kernel(PairArgs p) {
     else colsum32_body(p, (int64_t)(bid - p.nb0 - p.nb1) * 32, part);
 }
 
+// ---- the dW / dX pair of a Linear backward on LDS-SHARED 64x64 tiles, the work dealt out evenly (gemm_mid_sk_kernel) ------------
+// What the per-wave kernels above cannot do is reuse an operand byte: every wave pulls its own 32 x 16 pieces through L1 (8 FLOP per
+// loaded byte), the launches are bound by that flow (the dW and dX halves of a paired launch take exactly as long together as alone,
+// MFMA pipe 33 % busy); and one LDS-tiled workgroup per 64x64 tile leaves SIMDs idle at these sizes (96 + 128 tiles for a 768 x 512
+// layer at B = 1024 on 256 CUs) while a tile's 16 k-steps of 2,048 MFMA cycles each set the launch's length.  Here
+//   * a workgroup is 4 KG waves: wave (kg, wm, wn) owns the 32x32 quarter (wm, wn) of a tile for the k-blocks 16 kg + 16 KG s.  Per
+//     STEP (16 KG consecutive k of one tile) the whole workgroup stages a 64 x 16KG slab of each operand -- one coalesced 16-byte
+//     load per thread and operand, 16 FLOP per loaded byte --, register-prefetched PF steps ahead, three LDS buffers, the next step's
+//     fragments read while this step's MFMAs run, one barrier per step;
+//   * the launch is a list of S = tiles x steps-per-tile steps (dW tiles, then dX tiles, then the bias column sums priced in steps),
+//     cut into G equal contiguous ranges, one per workgroup (G = the workgroup slots of the chip or fewer): every SIMD gets the same
+//     number of MFMAs whatever the tile count.  A range that ends inside a tile leaves a partial 64x64 tile in the workspace; the
+//     workgroup that arrives LAST at a tile (one counter per tile) adds the tile's partials in ascending k order -- always the same
+//     order, whoever is last: deterministic -- and applies the epilogue.  Nobody waits for anybody.
+// Not the ORDER-G16 chain: gradients only (the forward layers keep one exact chain per output).
+// k-major slabs (A of TN, B of NN / TN) live as [k][64 + 4]: lane (i32, h) of a quarter reads k = 8h + j at step j, the two lane
+// halves 8 rows = 544 words = 32 banks apart; k-contiguous slabs (A of NN) as [64][16KG + 4]: two ds_read_b128 per block.
+constexpr int MID_STR = 68;
+
+struct SkArgs {
+    PairArgs p;         // g0 (TN: dW), g1 (NN: dX), nb0 / nb1 = 64x64 tiles, nbx0 / nbx1 = column tiles, cs_* = the bias column sums
+    int n0, n1;         // steps per tile
+    int nbc, cu;        // column-sum units (32 columns each) and their price in steps
+    int S, q, G;        // total steps, steps per workgroup, workgroups
+    float *slabs;       // [G][2][4096] partial tiles
+    int *counters;      // [nb0 + nb1]
+};
+
+template <int KG>
+struct SkGeom {
+    static constexpr int BKS = 16 * KG, T = 256 * KG, KC_STR = BKS + 4, NB = 3, NG = 1024 / T;
+    static constexpr int A_KC_SZ = 64 * KC_STR, KM_SZ = BKS * MID_STR;
+    static constexpr int BUF = (A_KC_SZ > KM_SZ ? A_KC_SZ : KM_SZ) + KM_SZ;
+    static constexpr size_t lds_bytes = (size_t)NB * BUF * 4;
+    static_assert(NB * BUF >= KG * 4096, "the stage buffers must hold the KG partial tiles");
+};
+
+// k-steps [ks0, ks0 + len) of tile (m0, n0) -> the wave's 32x32 accumulator of its k-blocks
+template <int LAYOUT, int KG, int PF>
+__device__ __forceinline__ void sk_accumulate(const GemmArgs &g, int64_t m0, int64_t n0, int ks0, int len, float *lds, f32x16 &acc) {
+    static_assert(LAYOUT != HIDVAE_GEMM_NT && PF >= 2, "gradient products only: TN (dW) and NN (dX)");
+    using G_ = SkGeom<KG>;
+    constexpr bool A_KC = (LAYOUT == HIDVAE_GEMM_NN);
+    constexpr int BKS = G_::BKS, KC_STR = G_::KC_STR, NB = G_::NB, BUF = G_::BUF;
+    constexpr int A_SZ = A_KC ? G_::A_KC_SZ : G_::KM_SZ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int Ki = (int)g.K;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.A), 0, (int)(4 * (A_KC ? (g.M - 1) * g.lda + g.K : (g.K - 1) * g.lda + g.M)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g.B), 0, (int)(4 * ((g.K - 1) * g.ldb + g.N)), 0x00020000);
+    // this thread's 16-byte slot of a slab
+    const int kr = tid >> 4, c4 = (tid & 15) * 4;                      // k-major: row kr of the step, columns c4 .. c4 + 3
+    const int ar = tid / (BKS / 4), ak4 = (tid % (BKS / 4)) * 4;       // k-contiguous: tile row ar, k = ak4 .. ak4 + 3 of the step
+    const int64_t arow = (m0 + ar < g.M) ? m0 + ar : g.M - 1;
+    const int offA = A_KC ? 4 * ((int)(arow * g.lda) + ak4) : 4 * (kr * (int)g.lda + (int)m0 + c4);
+    const int offB = 4 * (kr * (int)g.ldb + (int)n0 + c4);
+    const int stepA = A_KC ? 4 * BKS : 4 * BKS * (int)g.lda, stepB = 4 * BKS * (int)g.ldb;
+    const int ldsA = A_KC ? ar * KC_STR + ak4 : kr * MID_STR + c4, ldsB = kr * MID_STR + c4;
+    f32x4 pa[PF], pb[PF];
+    auto fetch = [&](int slot, int s) {  // (steps past the segment and k rows past K aim out of range: zeros, no traffic)
+        const int ks = ks0 + s;
+        const bool ka = s < len && (A_KC ? ks * BKS + ak4 < Ki : ks * BKS + kr < Ki);
+        const bool kb = s < len && ks * BKS + kr < Ki;
+        pa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, ka ? offA : HV_OOB, ks * stepA, 0));
+        pb[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, kb ? offB : HV_OOB, ks * stepB, 0));
+    };
+    auto stash = [&](int slot, int s, int buf) {
+        float *dst = lds + buf * BUF;
+        f32x4 a = pa[slot];
+        if (A_KC) {  // a 16-byte piece that straddles the end of the row: what follows K belongs to the next row
+            const int k = (ks0 + s) * BKS + ak4;
+            if (k + 4 > Ki) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) a[e] = k + e < Ki ? a[e] : 0.0f;
+            }
+        }
+        *reinterpret_cast<f32x4 *>(dst + ldsA) = a;
+        *reinterpret_cast<f32x4 *>(dst + A_SZ + ldsB) = pb[slot];
+    };
+    float fa[2][8], fb[2][8];
+    auto frags = [&](int fs, int buf) {
+        const float *As = lds + buf * BUF, *Bs = As + A_SZ;
+        if (A_KC) {
+            const float *ap = As + (32 * wm + i32) * KC_STR + 16 * kg + 8 * h;
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(ap), y = *reinterpret_cast<const f32x4 *>(ap + 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { fa[fs][j] = x[j]; fa[fs][4 + j] = y[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) fa[fs][j] = As[(16 * kg + 8 * h + j) * MID_STR + 32 * wm + i32];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) fb[fs][j] = Bs[(16 * kg + 8 * h + j) * MID_STR + 32 * wn + i32];
+    };
+    // prologue: steps 0 and 1 staged, fragments of step 0 in registers, loads of steps 2 .. PF + 1 in flight
+#pragma unroll
+    for (int p = 0; p < PF; p++) fetch(p, p);
+    stash(0, 0, 0);
+    fetch(0, PF);
+    stash(1 % PF, 1, 1);
+    fetch(1 % PF, PF + 1);
+    __syncthreads();
+    frags(0, 0);
+    constexpr int U2 = PF % 2 == 0 ? PF : 2 * PF, UN = U2 % 3 == 0 ? U2 : 3 * U2;  // lcm(2, NB, PF)
+    for (int s0 = 0; s0 < len; s0 += UN) {
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int s = s0 + u;
+            if (s < len) {  // (uniform)
+                if (s + 1 < len) frags((u + 1) & 1, (u + 1) % NB);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u & 1][j], fb[u & 1][j], acc, 0, 0, 0);
+                if (s + 2 < len) {
+                    stash((u + 2) % PF, s + 2, (u + 2) % NB);
+                    fetch((u + 2) % PF, s + 2 + PF);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// epilogue + store of the workgroup's tile: thread t holds the float4 groups e4 = t + T i (row e4 >> 4, columns 4 (e4 & 15) ..)
+template <int KG>
+__device__ __forceinline__ void sk_output(const GemmArgs &g, int64_t m0, int64_t n0, const f32x4 (&v)[SkGeom<KG>::NG]) {
+    const bool vec = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < SkGeom<KG>::NG; i++) {
+        const int e4 = threadIdx.x + SkGeom<KG>::T * i;
+        const int64_t row = m0 + (e4 >> 4), col = n0 + 4 * (e4 & 15);
+        if (row >= g.M || col >= g.N) continue;
+        float *dst = g.C + row * g.ldc + col;
+        f32x4 o = v[i];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (col + e < g.N) {
+                o[e] = apply_epilogue(g.epilogue, o[e], g.aux, row * g.ldaux + col + e);
+                if (g.accumulate) o[e] = dst[e] + o[e];
+            }
+        if (vec && col + 4 <= g.N) *reinterpret_cast<f32x4 *>(dst) = o;
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (col + e < g.N) dst[e] = o[e];
+        }
+    }
+}
+
+// Partial tiles cross workgroups -- possibly XCDs, whose L2s do not see each other's dirty lines -- through memory: system-scope
+// (sc0 sc1) stores and loads that bypass the caches, ordered by the store acknowledgements (s_waitcnt vmcnt(0)) and a relaxed
+// device-scope counter.  A release / acquire FENCE pair would do the same, but on gfx950 that is a write-back of the whole L2 and an
+// invalidate of it per wave: measured 10x slower (220 us for the 768 x 512 layer), every operand re-fetched from HBM.
+__device__ __forceinline__ void sk_store_through(float *p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 sk_load_through(const float *p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// one segment: steps [ks0, ks0 + len) of tile `tl` (of nT steps, first global step tstart) of problem g; v = this workgroup's index
+template <int LAYOUT, int KG, int PF>
+__device__ __forceinline__ void sk_segment(const SkArgs &a, const GemmArgs &g, int tl, int nbx, int counter, int ks0, int len, int nT,
+                                           int tstart, int v, float *lds, int *s_old) {
+    using G_ = SkGeom<KG>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int by = tl / nbx, bx = tl - by * nbx;
+    const int64_t m0 = (int64_t)by * 64, n0 = (int64_t)bx * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    sk_accumulate<LAYOUT, KG, PF>(g, m0, n0, ks0, len, lds, acc);
+    // the KG partial tiles -> LDS (in the stage buffers: every wave is past its last fragment read), summed in ascending kg order
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds[kg * 4096 + (32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + 32 * wn + i32] = acc[r];
+    __syncthreads();
+    f32x4 vv[G_::NG];
+#pragma unroll
+    for (int i = 0; i < G_::NG; i++) {
+        const int e4 = tid + G_::T * i;
+        vv[i] = *reinterpret_cast<const f32x4 *>(lds + 4 * e4);
+#pragma unroll
+        for (int q = 1; q < KG; q++) vv[i] = vv[i] + *reinterpret_cast<const f32x4 *>(lds + q * 4096 + 4 * e4);
+    }
+    if (ks0 == 0 && len == nT) {  // the whole tile
+        sk_output<KG>(g, m0, n0, vv);
+    } else {
+        // a piece of the tile: park it (slot 2v: the tile began before this range; 2v + 1: it begins here and goes on), count arrivals
+        float *mine = a.slabs + ((int64_t)2 * v + (ks0 == 0 ? 1 : 0)) * 4096;
+#pragma unroll
+        for (int i = 0; i < G_::NG; i++) sk_store_through(mine + 4 * (tid + G_::T * i), vv[i]);
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // this thread's piece has been acknowledged by memory
+        __syncthreads();                                     // ... and so has every thread's
+        const int v_first = tstart / a.q, v_last = (tstart + nT - 1) / a.q;
+        if (tid == 0) *s_old = __hip_atomic_fetch_add(a.counters + counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*s_old == v_last - v_first) {  // last to arrive: every piece is in memory
+            for (int u = v_first; u <= v_last; u++) {  // ascending k, whoever finishes
+                const float *src = a.slabs + ((int64_t)2 * u + (u * a.q <= tstart ? 1 : 0)) * 4096;
+                f32x4 w[G_::NG];
+#pragma unroll
+                for (int i = 0; i < G_::NG; i++) w[i] = sk_load_through(src + 4 * (tid + G_::T * i));
+#pragma unroll
+                for (int i = 0; i < G_::NG; i++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[i]) : : "memory");  // (ties the uses of w to the wait)
+#pragma unroll
+                for (int i = 0; i < G_::NG; i++) vv[i] = u == v_first ? w[i] : vv[i] + w[i];
+            }
+            sk_output<KG>(g, m0, n0, vv);
+            if (tid == 0) __hip_atomic_store(a.counters + counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch
+        }
+    }
+    __syncthreads();  // the stage buffers (and s_old) are free again
+}
+
+template <int KG, int PF>
+__global__ __launch_bounds__(256 * KG) void gemm_mid_sk_kernel(SkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float mid_lds[];
+    __shared__ int s_old;
+    const int v = xcd_slot((int)blockIdx.x, a.G);  // XCD j works on the j-th contiguous eighth of the step list
+    if (a.q == 0) {  // one whole tile (or one strip of column sums) per workgroup: nothing to hand over
+        if (v < a.p.nb0) sk_segment<HIDVAE_GEMM_TN, KG, PF>(a, a.p.g0, v, a.p.nbx0, 0, 0, a.n0, a.n0, 0, v, mid_lds, &s_old);
+        else if (v < a.p.nb0 + a.p.nb1) sk_segment<HIDVAE_GEMM_NN, KG, PF>(a, a.p.g1, v - a.p.nb0, a.p.nbx1, 0, 0, a.n1, a.n1, 0, v, mid_lds, &s_old);
+        else colsum32_body(a.p, (int64_t)(v - a.p.nb0 - a.p.nb1) * 32, mid_lds);
+        return;
+    }
+    int step = v * a.q;
+    const int Sg = a.p.nb0 * a.n0 + a.p.nb1 * a.n1;
+    const int hi = step + a.q < a.S ? step + a.q : a.S;
+    const int S0 = a.p.nb0 * a.n0;
+    while (step < hi) {
+        if (step >= Sg) {  // bias column sums: a unit belongs to the range that holds its first step
+            const int rel = step - Sg, u = (rel + a.cu - 1) / a.cu;
+            if (u >= a.nbc || Sg + u * a.cu >= hi) break;
+            colsum32_body(a.p, (int64_t)u * 32, mid_lds);
+            __syncthreads();
+            step = Sg + u * a.cu + 1;
+            continue;
+        }
+        const bool second = step >= S0;
+        const int nT = second ? a.n1 : a.n0;
+        const int rel = second ? step - S0 : step;
+        const int tl = rel / nT, ks0 = rel - tl * nT;
+        int len = nT - ks0;
+        if (len > hi - step) len = hi - step;
+        if (!second) sk_segment<HIDVAE_GEMM_TN, KG, PF>(a, a.p.g0, tl, a.p.nbx0, tl, ks0, len, nT, step - ks0, v, mid_lds, &s_old);
+        else sk_segment<HIDVAE_GEMM_NN, KG, PF>(a, a.p.g1, tl, a.p.nbx1, a.p.nb0 + tl, ks0, len, nT, step - ks0, v, mid_lds, &s_old);
+        step += len;
+    }
+}
+
+template <int KG, int PF>
+int launch_mid_sk(const SkArgs &a, hipStream_t s) {
+    constexpr size_t bytes = SkGeom<KG>::lds_bytes;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_mid_sk_kernel<KG, PF>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (attr != hipSuccess) return -1;
+    hipLaunchKernelGGL((gemm_mid_sk_kernel<KG, PF>), dim3((unsigned)a.G), dim3(256 * KG), bytes, s, a);
+    return 0;
+}
+
 template <int LAYOUT, int SPLIT>
 __global__ __launch_bounds__(64 * SPLIT) void gemm_directL_kernel(GemmArgs g) {
-    __shared__ float part[SPLIT > 1 ? SPLIT * 1024 : 1];
-    __shared__ __attribute__((aligned(16))) float stage[SPLIT * 2 * 32 * LSTR];
+    // per wave: the A strip, the B strip (NT only), and -- after the K loop, in the same words -- the wave's 32x32 partial tile
+    constexpr int WSTRIDE = (LAYOUT == HIDVAE_GEMM_NT ? 2 : 1) * 32 * LSTR;
+    static_assert(WSTRIDE >= 1024, "a wave's strips must hold its partial tile");
+    __shared__ __attribute__((aligned(16))) float stage[SPLIT * WSTRIDE];
     const int lane = threadIdx.x & 63;
     const int w = SPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i32 = lane & 31, h = lane >> 5;
@@ -957,8 +1232,8 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_directL_kernel(GemmArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-    directL_accumulate<LAYOUT>(g, m0, n0, nfull * w / SPLIT, nfull * (w + 1) / SPLIT, w == SPLIT - 1, stage + w * (2 * 32 * LSTR),
-                               stage + w * (2 * 32 * LSTR) + 32 * LSTR, acc);
+    directL_accumulate<LAYOUT>(g, m0, n0, nfull * w / SPLIT, nfull * (w + 1) / SPLIT, w == SPLIT - 1, stage + w * WSTRIDE,
+                               stage + w * WSTRIDE + 32 * LSTR, acc);
     const float *mk = g.mask;
     if (SPLIT == 1) {
         const int64_t col = n0 + i32;
@@ -976,13 +1251,14 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_directL_kernel(GemmArgs g) {
             *dst = g.accumulate ? *dst + v : v;
         }
     } else {
+        __builtin_amdgcn_wave_barrier();  // (this wave's last fragment reads precede its partial tile in program order)
 #pragma unroll
-        for (int r = 0; r < 16; r++) part[w * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i32] = acc[r];
+        for (int r = 0; r < 16; r++) stage[w * WSTRIDE + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i32] = acc[r];
         __syncthreads();
         for (int e = threadIdx.x; e < 1024; e += 64 * SPLIT) {
-            float v = part[e];
+            float v = stage[e];
 #pragma unroll
-            for (int sidx = 1; sidx < SPLIT; sidx++) v += part[sidx * 1024 + e];  // fixed order: bit-reproducible
+            for (int sidx = 1; sidx < SPLIT; sidx++) v += stage[sidx * WSTRIDE + e];  // fixed order: bit-reproducible
             const int64_t row = m0 + (e >> 5), col = n0 + (e & 31);
             if (row >= g.M || col >= g.N) continue;
             v += g.bias != nullptr ? g.bias[col] : 0.0f;
@@ -1416,10 +1692,12 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
 
 extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate, float *workspace, void *stream);
 
-extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
-                                 int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
-                                 int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
-                                 void *stream) {
+// balanced_ok: the workspace follows the contract of HIDVAE_WS_LINEAR_BWD_ZEROED (hidvae_linear_bwd); the grouped entry point's
+// per-problem fallback passes false -- its workspaces are plain scratch
+static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
+                           int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
+                           int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
+                           void *stream, bool balanced_ok) {
     HV_REQUIRE(g && x && dW && B >= 1 && n_out >= 1 && n_in >= 1, "linear_bwd: bad arguments");
     HV_REQUIRE(ldg >= n_out && ldx >= n_in && lddw >= n_in, "linear_bwd: leading dimension too small");
     HV_REQUIRE(dX == nullptr || (W != nullptr && ldw >= n_in && lddx >= n_in), "linear_bwd: dX needs W");
@@ -1432,6 +1710,62 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
     const int s32_0 = pick_split32(n_out, n_in, B, 0), s32_1 = pick_split32(B, n_in, n_out, 0);
     const bool pair32 = small && !use_direct16(n_out, n_in, B) && !use_direct16(B, n_in, n_out) && s32_0 <= 8 && s32_1 <= 8;
     const bool pair = pair16 || pair32;
+    // LDS-shared 64x64 tiles, evenly dealt (gemm_mid_sk_kernel): HIDVAE_GEMM_MID = 0 off, else KG (waves per workgroup / 4)
+    static const int mid_mode = getenv("HIDVAE_GEMM_MID") ? atoi(getenv("HIDVAE_GEMM_MID")) : 4;
+    static const int mid_pf = getenv("HIDVAE_GEMM_MID_PF") ? atoi(getenv("HIDVAE_GEMM_MID_PF")) : 2;
+    static const int mid_minq = getenv("HIDVAE_GEMM_MID_MINQ") ? atoi(getenv("HIDVAE_GEMM_MID_MINQ")) : 6;
+    static const int mid_slots = getenv("HIDVAE_GEMM_MID_SLOTS") ? atoi(getenv("HIDVAE_GEMM_MID_SLOTS")) : 0;
+    if (mid_mode > 0 && balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, dX != nullptr) &&
+        fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && (dX == nullptr || fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw))) {
+        const int KG = mid_mode >= 4 ? 4 : (mid_mode >= 2 ? 2 : 1), BKS = 16 * KG;
+        SkArgs a{};
+        PairArgs &p = a.p;
+        p.g0.M = n_out; p.g0.N = n_in; p.g0.K = B; p.g0.A = g; p.g0.lda = ldg; p.g0.B = x; p.g0.ldb = ldx; p.g0.C = dW; p.g0.ldc = lddw;
+        p.g0.epilogue = HIDVAE_EPI_NONE; p.g0.mask_scale = 1.0f; p.g0.accumulate = accumulate_dw;
+        p.nbx0 = (int)hv_cdiv(n_in, 64);
+        p.nb0 = p.nbx0 * (int)hv_cdiv(n_out, 64);
+        a.n0 = (int)hv_cdiv(B, BKS);
+        if (dX != nullptr) {
+            p.g1.M = B; p.g1.N = n_in; p.g1.K = n_out; p.g1.A = g; p.g1.lda = ldg; p.g1.B = W; p.g1.ldb = ldw; p.g1.C = dX; p.g1.ldc = lddx;
+            p.g1.epilogue = dx_epilogue; p.g1.aux = aux; p.g1.ldaux = aux ? ldaux : 0; p.g1.mask_scale = 1.0f;
+            p.nbx1 = (int)hv_cdiv(n_in, 64);
+            p.nb1 = p.nbx1 * (int)hv_cdiv(B, 64);
+            a.n1 = (int)hv_cdiv(n_out, BKS);
+        } else a.n1 = 1;
+        p.cs_x = g; p.cs_ld = ldg; p.cs_rows = B; p.cs_cols = n_out; p.cs_out = db; p.cs_accumulate = accumulate_db;
+        a.nbc = db != nullptr ? (int)hv_cdiv(n_out, 32) : 0;
+        a.cu = (int)hv_cdiv(B, 512);  // a 32-column strip of B rows, priced against a step's MFMAs (~1 us either way)
+        a.S = p.nb0 * a.n0 + p.nb1 * a.n1 + a.nbc * a.cu;
+        const int slots = mid_slots > 0 ? mid_slots : (KG == 4 ? 256 : 512);
+        int G = a.S / mid_minq;
+        if (G > slots) G = slots;
+        if (G < 1) G = 1;
+        a.q = (int)hv_cdiv(a.S, G);
+        a.G = (int)hv_cdiv(a.S, a.q);
+        // one tile per workgroup when the tiles fit the chip in one round and are short (B = 1024: 24.8 us against 29.1 for the 768 x 512
+        // layer -- a range that ends inside a tile costs ~3.5 us of pipeline refill and hand-over); even ranges otherwise (B = 2048:
+        // 45.6 against 80.3 us)
+        static const int mid_sched = getenv("HIDVAE_GEMM_MID_SCHED") ? atoi(getenv("HIDVAE_GEMM_MID_SCHED")) : 0;  // 1: tile per workgroup, 2: even ranges
+        const int longest = a.n0 > (p.nb1 ? a.n1 : 0) ? a.n0 : a.n1;
+        const bool tiles = mid_sched == 1 || (mid_sched == 0 && p.nb0 + p.nb1 + a.nbc <= slots && longest * KG <= 96);
+        if (tiles) {
+            a.q = 0;
+            a.G = p.nb0 + p.nb1 + a.nbc;
+        }
+        if (p.nb0 + p.nb1 <= HV_SK_COUNTERS && (tiles || a.G <= HV_SK_MAX_G)) {
+            a.counters = reinterpret_cast<int *>(workspace);
+            a.slabs = workspace + HV_SK_COUNTERS;
+            int rc;
+            if (KG == 4) rc = mid_pf >= 4 ? launch_mid_sk<4, 4>(a, (hipStream_t)stream) : launch_mid_sk<4, 2>(a, (hipStream_t)stream);
+            else if (KG == 2) rc = mid_pf >= 4 ? launch_mid_sk<2, 4>(a, (hipStream_t)stream) : launch_mid_sk<2, 2>(a, (hipStream_t)stream);
+            else rc = mid_pf >= 4 ? launch_mid_sk<1, 4>(a, (hipStream_t)stream) : launch_mid_sk<1, 2>(a, (hipStream_t)stream);
+            HV_REQUIRE(rc == 0, "linear_bwd: could not size the LDS of gemm_mid_sk_kernel");
+            HV_LAUNCH_CHECK("linear_bwd mid");
+            return HIDVAE_OK;
+        }
+    }
+    // (a workspace of a balanced-kernel shape keeps its leading counters to itself, whichever path this call takes)
+    if (balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, true)) workspace += HV_SK_COUNTERS;
     HV_REQUIRE(db == nullptr || pair || workspace != nullptr || B <= 16384, "linear_bwd: the unpaired bias gradient needs the colsum workspace");
     if (!pair) {
         // (the workspace serves the bias column sums first -- only for B > 16384 -- and then, in stream order, the slabs of dW)
@@ -1466,13 +1800,22 @@ extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, in
     //  3.02 -> 3.09 ms: its row-contiguous B operand still takes 8 scalar loads per block and the 2-block stage is shallower than
     //  the 6-deep register ring; only HIDVAE_GEMM_LDS=1 turns it on)
     static const int pair_lds = getenv("HIDVAE_GEMM_LDS") ? atoi(getenv("HIDVAE_GEMM_LDS")) : 2;
-    p.lds_a = pair_lds == 1;
+    p.lds_a = pair_lds == 1 && (size_t)(p.split0 > p.split1 ? p.split0 : p.split1) * (4096 + 32 * LSTR * 4) <= 65536;
     const dim3 grid((unsigned)(p.nb0 + p.nb1 + nbc)), block(64 * waves);
+    const size_t lds32 = (size_t)waves * (4096 + (p.lds_a ? 32 * LSTR * 4 : 0));
     if (pair16) hipLaunchKernelGGL(gemm_pair16_kernel, grid, block, 0, (hipStream_t)stream, p);
-    else if (n_out / (16 * p.split1) >= 12) hipLaunchKernelGGL(gemm_pair32_kernel<6>, grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_pair32_kernel<3>, grid, block, 0, (hipStream_t)stream, p);
+    else if (n_out / (16 * p.split1) >= 12) hipLaunchKernelGGL(gemm_pair32_kernel<6>, grid, block, lds32, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_pair32_kernel<3>, grid, block, lds32, (hipStream_t)stream, p);
     HV_LAUNCH_CHECK("linear_bwd pair");
     return HIDVAE_OK;
+}
+
+extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
+                                 int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
+                                 int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
+                                 void *stream) {
+    return linear_bwd_impl(g, ldg, x, ldx, W, ldw, B, n_out, n_in, dW, lddw, accumulate_dw, dX, lddx, dx_epilogue, aux, ldaux, db,
+                           accumulate_db, workspace, stream, true);
 }
 
 extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate,
@@ -1560,8 +1903,8 @@ extern "C" int hidvae_linear_bwd_group(const hidvae_linear_bwd_problem *pr, int 
     if (!ok) {
         for (int i = 0; i < n; i++) {
             const hidvae_linear_bwd_problem &q = pr[i];
-            const int rc = hidvae_linear_bwd(q.g, q.ldg, q.x, q.ldx, q.W, q.ldw, q.B, q.n_out, q.n_in, q.dW, q.lddw, q.accumulate_dw, q.dX, q.lddx,
-                                             q.dx_epilogue, q.aux, q.ldaux, q.db, q.accumulate_db, q.workspace, stream);
+            const int rc = linear_bwd_impl(q.g, q.ldg, q.x, q.ldx, q.W, q.ldw, q.B, q.n_out, q.n_in, q.dW, q.lddw, q.accumulate_dw, q.dX, q.lddx,
+                                           q.dx_epilogue, q.aux, q.ldaux, q.db, q.accumulate_db, q.workspace, stream, false);
             if (rc != HIDVAE_OK) return rc;
         }
         return HIDVAE_OK;

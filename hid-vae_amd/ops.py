@@ -25,6 +25,7 @@ def side_stream():
     d = torch.cuda.current_device()
     if d not in _SIDE:
         _SIDE[d] = torch.cuda.Stream()
+        _C.register_ws_lane(_SIDE[d])
     return _SIDE[d]
 
 

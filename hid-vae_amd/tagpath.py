@@ -415,6 +415,7 @@ def _tag_streams(device, n):
     st = _TAG_STREAMS.setdefault(key, [None])
     while len(st) < n:
         st.append(torch.cuda.Stream(device=device))
+        _C.register_ws_lane(st[-1])  # its Linear backwards run next to the other levels': a workspace of their own
     return st
 
 

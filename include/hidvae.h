@@ -69,6 +69,9 @@ const char *hidvae_last_error(void);
 #define HIDVAE_WS_ID_CENSUS 9            /* B  -> `scratch` of hidvae_id_stats / `census_scratch` of hidvae_bottleneck_fwd (zero-fill once) */
 #define HIDVAE_WS_KMEANS 10              /* N, K                      -> shift_scratch of hidvae_kmeans_iter             */
 #define HIDVAE_WS_TAG_LOSS 11            /* B, C                      -> row_loss + row_hit + zbuf of hidvae_tag_loss_fwd */
+#define HIDVAE_WS_LINEAR_BWD_ZEROED 12   /* B, n_out, n_in, has_bias  -> leading bytes of the hidvae_linear_bwd workspace that must be ZERO
+                                            on entry (arrival counters of the balanced kernel; left zero on return).  Non-zero means: hand
+                                            hidvae_linear_bwd a workspace that no launch running CONCURRENTLY shares (one per stream). */
 int hidvae_query_workspace(int op, const int64_t *dims, int n_dims, int64_t *bytes);
 
 /* ---- a2/a3/a9/a10: Linear layers (modules/encoder.py:23-36, h_rqvae.py:132-188,322-331) ------------
@@ -105,6 +108,11 @@ int hidvae_gemm_bf16(int layout, int64_t M, int64_t N, int64_t K, const float *A
  * Both products are independent, so small problems share one grid (the dW tiles first, then the dX tiles) instead of paying
  * two launches; the arithmetic, split and summation order are those of hidvae_gemm_f32(split_k = 0) on each product, so
  * the results are bit-identical to the two separate calls.  Shapes outside the small-problem regime fall back to them.
+ * Mid-size layers at batches 256 .. 4095 (hidvae_query_workspace(HIDVAE_WS_LINEAR_BWD_ZEROED, ...) > 0) run on the balanced
+ * LDS-shared kernel instead when a workspace is given: 64x64 tiles whose k-steps are dealt evenly over the chip's workgroup slots,
+ * partial tiles added in ascending k order by the last workgroup to arrive (deterministic, but a different summation order than
+ * hidvae_gemm_f32).  It keeps arrival counters in the first ZEROED bytes of the workspace: zero on entry, zero again on return,
+ * never shared with a launch that may run at the same time.  Without a workspace the paired kernels above are used.
  * accumulate_dw: dW += g^T x (gradient accumulation straight into a flat gradient buffer's slot).
  * db (optional): the bias gradient db[n_out] = column sums of g, from the same launch (fixed summation order; the fallback
  * uses hidvae_colsum and needs its workspace of ceil(B/64)*n_out floats when B > 16384).  workspace (optional) is also what lets the

@@ -44,8 +44,11 @@ def test_query_workspace_is_host_only_and_matches_the_documented_formulas():
     assert q(_C.WS_GEMM, 1024, 512, 768, 1) == 0                       # direct path: no slabs
     assert q(_C.WS_GEMM, 65536, 512, 768, 4) == 4 * 65536 * 512 * 4   # LDS-tiled path with split_k slabs
     assert q(_C.WS_GEMM, 512, 768, 8192, 0) == 16 * 512 * 768 * 4     # deep-K weight gradient
-    assert q(_C.WS_LINEAR_BWD, 1024, 512, 768, 1) == 16 * 512 * 4
-    assert q(_C.WS_LINEAR_BWD, 8192, 512, 768, 0) == 16 * 512 * 768 * 4
+    assert q(_C.WS_LINEAR_BWD, 128, 512, 768, 1) == 2 * 512 * 4          # small batch: the column-sum partials of the fallback
+    sk = (4096 + 512 * 2 * 4096) * 4                                    # balanced kernel: arrival counters + two partial tiles per workgroup
+    assert q(_C.WS_LINEAR_BWD, 1024, 512, 768, 1) == sk and q(_C.WS_LINEAR_BWD_ZEROED, 1024, 512, 768, 1) == 4096 * 4
+    assert q(_C.WS_LINEAR_BWD_ZEROED, 1024, 128, 32, 1) == 0 and q(_C.WS_LINEAR_BWD_ZEROED, 32768, 512, 768, 0) == 0
+    assert q(_C.WS_LINEAR_BWD, 32768, 512, 768, 0) == 16 * 512 * 768 * 4
     assert q(_C.WS_COLSUM, 1000, 48) == 16 * 48 * 4
     assert q(_C.WS_CODEBOOK_GRAD, 2048, 3, 256) == 0 and q(_C.WS_CODEBOOK_GRAD, 8192, 3, 256) == 3 * 256 * 4 * 32 * 4
     assert q(_C.WS_LAYERNORM_BWD_ALL, 1024, 230) == 2 * 256 * 230 * 4

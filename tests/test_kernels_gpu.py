@@ -229,24 +229,61 @@ def test_kmeans_matches_reference_golden(C, name):
 @pytest.mark.parametrize("B,n_out,n_in", [(1024, 256, 128), (1024, 32, 128), (1024, 128, 32), (96, 40, 24), (1000, 512, 256),
                                           (1024, 768, 512), (17, 5, 3)])
 def test_linear_bwd_pair_is_bit_identical_to_two_gemms(C, B, n_out, n_in):
+    """(the mid-size layers -- 1024 x 768 x 512 here -- take the balanced LDS-shared kernel, whose summation order is its own:
+    tight tolerance against the two GEMMs instead of bit identity; tests/test_kernels_gpu.py::test_linear_bwd_balanced_* cover it)"""
     g = dev(fill.gauss((B, n_out), 70))
     x = dev(fill.gauss((B, n_in), 71))
     w = dev(fill.gauss((n_out, n_in), 72))
     pre = dev(fill.gauss((B, n_in), 73))
+    balanced = C.workspace_bytes(C.WS_LINEAR_BWD_ZEROED, B, n_out, n_in, 0) > 0
+    same = (lambda a, b: H.rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-6) if balanced else torch.equal
     for epi, aux in ((C.EPI_NONE, None), (C.EPI_DSILU, pre)):
         dW, dX = C.linear_bwd(g, x, w, True, epi, aux)
-        assert torch.equal(dW, C.gemm(C.GEMM_TN, g, x, split_k=0))
-        assert torch.equal(dX, C.gemm(C.GEMM_NN, g, w, epilogue=epi, aux=aux, split_k=0))
+        assert same(dW, C.gemm(C.GEMM_TN, g, x, split_k=0))
+        assert same(dX, C.gemm(C.GEMM_NN, g, w, epilogue=epi, aux=aux, split_k=0))
     dW, dX = C.linear_bwd(g, x, w, False)
-    assert dX is None and torch.equal(dW, C.gemm(C.GEMM_TN, g, x, split_k=0))
+    assert dX is None and same(dW, C.gemm(C.GEMM_TN, g, x, split_k=0))
     dW2, dX2, db = C.linear_bwd(g, x, w, True, bias=True)  # bias gradient from the same launch
-    assert torch.equal(dW2, dW) and torch.equal(dX2, C.gemm(C.GEMM_NN, g, w, split_k=0))
+    assert same(dW2, dW) and same(dX2, C.gemm(C.GEMM_NN, g, w, split_k=0))
     assert H.close(db.cpu().numpy(), g.cpu().double().sum(0).float().numpy(), 1e-5, 1e-5)
     slot = torch.ones(n_out, device="cuda")
     C.linear_bwd(g, x, w, True, bias=True, db=slot, accumulate_db=True)
     assert H.close(slot.cpu().numpy(), 1.0 + g.cpu().double().sum(0).float().numpy(), 1e-5, 1e-5)
     # and against fp32 torch (loose: different summation order)
     assert H.rel_err(dW.cpu().numpy(), (g.cpu().double().T @ x.cpu().double()).float().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,n_out,n_in", [(1024, 768, 512), (1024, 691, 768), (1000, 460, 512), (2048, 512, 256), (2047, 333, 385),
+                                          (3000, 768, 512), (4095, 200, 300), (8192, 256, 128)])
+def test_linear_bwd_balanced_kernel_against_float64_and_itself(C, B, n_out, n_in):
+    """gemm_mid_sk_kernel (one 64x64 tile per workgroup at B ~ 1024, even k-step ranges with last-arriver hand-over above): dW with
+    accumulation, dX with and without the activation-derivative epilogue, db -- against float64, ragged shapes included -- and
+    bit-identical from launch to launch (the hand-over adds partial tiles in ascending k order whoever arrives last)"""
+    assert C.workspace_bytes(C.WS_LINEAR_BWD_ZEROED, B, n_out, n_in, 1) > 0, "not a shape of the balanced kernel"
+    g = dev(fill.gauss((B, n_out), 74))
+    x = dev(fill.gauss((B, n_in), 75))
+    w = dev(fill.gauss((n_out, n_in), 76))
+    pre = dev(fill.gauss((B, n_in), 77))
+    gd, xd, wd, pd = g.cpu().double(), x.cpu().double(), w.cpu().double(), pre.cpu().double()
+    for epi, aux in ((C.EPI_NONE, None), (C.EPI_DSILU, pre)):
+        dW0, db0 = torch.ones(n_out, n_in, device="cuda"), torch.ones(n_out, device="cuda")
+        dW, dX, db = C.linear_bwd(g, x, w, True, epi, aux, dW=dW0, accumulate=True, bias=True, db=db0, accumulate_db=True)
+        want_dX = gd @ wd
+        if aux is not None:
+            sg = torch.sigmoid(pd)
+            want_dX = want_dX * (sg * (1 + pd * (1 - sg)))
+        assert H.rel_err(dW.cpu().numpy(), (1.0 + gd.T @ xd).float().numpy()) < 2e-6
+        assert H.rel_err(dX.cpu().numpy(), want_dX.float().numpy()) < 2e-6
+        assert H.close(db.cpu().numpy(), (1.0 + gd.sum(0)).float().numpy(), 1e-5, 1e-5)
+    first = C.linear_bwd(g, x, w, True, bias=True)
+    for _ in range(5):
+        again = C.linear_bwd(g, x, w, True, bias=True)
+        assert all(torch.equal(a, b) for a, b in zip(first, again))
+    only, none = C.linear_bwd(g, x, w, False)
+    assert none is None and H.rel_err(only.cpu().numpy(), (gd.T @ xd).float().numpy()) < 2e-6
+    # the arrival counters at the head of the lane's workspace are zero again
+    lane = C._lane_ws(g.device, 4)
+    assert int(lane[:4096].view(torch.int32).abs().sum()) == 0
 
 
 @pytest.mark.parametrize("B,mode,norm", [(1024, 3, True), (50, 3, True), (16, 2, False), (333, 3, False)])
