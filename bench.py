@@ -116,7 +116,7 @@ def time_kernel(fn, launches=20, reps=20):
 
 def kernel_rooflines(args, m, device):
     """Live per-kernel timings on the bench shapes.
-    * gemm_directL16_kernel / gemm_direct_kernel / gemm_pair32_kernel (fp32 MFMA roofline, 157.3 TFLOP/s): the largest GEMMs of the step;
+    * gemm_directL16_kernel / gemm_direct_kernel / gemm_mid_sk_kernel (fp32 MFMA roofline, 157.3 TFLOP/s): the largest GEMMs of the step;
     * rq_forward_kernel (HBM roofline, 8 TB/s): ALGORITHMIC bytes per item exactly as SURVEY.md 8(d) counts them for the tagged
       variant: read z 128 B, write ids 8L, per-level emb_out 128L, loss 4 = 540 B at L=3 (+ the codebooks 4*L*K*32 once per
       launch).  The launch also writes emb_sum and z (128 B each, consumed by the decoder and the backward): `bytes_moved`
@@ -145,7 +145,7 @@ def kernel_rooflines(args, m, device):
     pre = torch.randn(B, 512, device=device)
     t = time_kernel(lambda: _C.linear_bwd(gd, xd, wd, True, _C.EPI_DSILU, pre))
     fl2 = 4.0 * B * 768 * 512
-    out.append(dict(entry="hidvae_linear_bwd", kernel="gemm_pair32_kernel decoder layer 3 backward: dW [768,512] = g^T x and dX = (g W) * silu'(pre) in one launch",
+    out.append(dict(entry="hidvae_linear_bwd", kernel="gemm_mid_sk_kernel decoder layer 3 backward: dW [768,512] = g^T x and dX = (g W) * silu'(pre) in one launch (LDS-shared 64x64 tiles, one per workgroup)",
                     bound="mfma", achieved=fl2 / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl2 / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
                     us=t, flops=fl2))
     # the same layer in the throughput regime (LDS-tiled kernel; corpus tokenisation and large-batch training run here)
@@ -238,8 +238,8 @@ def summarize_timeline(rows):
 
 
 def describe_launch(r):
-    what = {"hidvae_gemm_f32": "forward Linear layers: gemm_direct16/gemm_direct kernels, fp32 MFMA, one exact ORDER-G chain per output",
-            "hidvae_linear_bwd": "one-launch Linear backward dW = g^T x + dX = g W (+ db): gemm_pair16 / gemm_pair32 kernels, fp32 MFMA",
+    what = {"hidvae_gemm_f32": "forward Linear layers: gemm_directL16 / gemm_direct16 kernels, fp32 MFMA, one exact ORDER-G chain per output",
+            "hidvae_linear_bwd": "one-launch Linear backward dW = g^T x + dX = g W (+ db): gemm_mid_sk (widest layer) / gemm_pair16 / gemm_pair32 kernels, fp32 MFMA",
             "hidvae_bottleneck_fwd": "fused middle launch: encoder[-2:] + L-level RQ + decoder[:2], fp32 MFMA"}.get(r["entry"], "")
     shapes = "; ".join(f"{m}x{n}x{k}" for m, n, k in r.get("shapes", [])[:8])
     return f"{r['entry']} x{r['launches']} launches per step ({what}{'; MxNxK: ' + shapes if shapes else ''})"

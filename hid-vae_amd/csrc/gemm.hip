@@ -1055,15 +1055,21 @@ __device__ __forceinline__ void sk_accumulate(const GemmArgs &g, int64_t m0, int
     __syncthreads();
     frags(0, 0);
     constexpr int U2 = PF % 2 == 0 ? PF : 2 * PF, UN = U2 % 3 == 0 ? U2 : 3 * U2;  // lcm(2, NB, PF)
+    constexpr int FRAG_AT = 2;
     for (int s0 = 0; s0 < len; s0 += UN) {
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             const int s = s0 + u;
             if (s < len) {  // (uniform)
+                // this step's MFMAs lead (their fragments arrived during the previous step); the next step's fragment reads are
+                // issued behind the first of them, so the matrix pipe starts right after the barrier and the reads fly under it
+#pragma unroll
+                for (int j = 0; j < FRAG_AT; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u & 1][j], fb[u & 1][j], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (s + 1 < len) frags((u + 1) & 1, (u + 1) % NB);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u & 1][j], fb[u & 1][j], acc, 0, 0, 0);
+                for (int j = FRAG_AT; j < 8; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u & 1][j], fb[u & 1][j], acc, 0, 0, 0);
                 if (s + 2 < len) {
                     stash((u + 2) % PF, s + 2, (u + 2) % NB);
                     fetch((u + 2) % PF, s + 2 + PF);

@@ -17,7 +17,7 @@ QUOTED = [
     ("rq_forward_kernel (fused L-level VQ, code-split variant)", "rq_forward_kernel<3, true, true, true", None),
     ("rq_forward at 1,048,576 items", "rq_forward_pf32_kernel<3, true", None),
     ("gemm_f32_kernel<2,2,NT> encoder layer 0 at 65,536 rows", "gemm_f32_kernel<2, 2, 0>", None),
-    ("gemm_pair32_kernel decoder layer 3 backward", "gemm_pair32_kernel<6>", None),
+    ("gemm_mid_sk_kernel decoder layer 3 backward", "gemm_mid_sk_kernel<4, 2>", None),
     ("rq_forward_kernel streamed code-split (4x1024, B=4096)", "rq_forward_kernel<3, true, false, true, 4, true>", None),
     ("gemm_bf16_kernel<NT> encoder layer 0 at 8192 rows", "gemm_bf16_kernel<0>", None),
 ]

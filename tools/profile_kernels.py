@@ -33,7 +33,7 @@ for _ in range(10):
     _C.gemm(_C.GEMM_TN, g, x, out=gw, split_k=0)
     _C.linear_bwd(g1, o0, w1, True, _C.EPI_DSILU, pre)  # the paired dW + dX launch of encoder layer 1
     _C.rq_forward(y_small, cb, cc, True, 3, True, 0.4)
-# round 2: the launch family that leads the step (hidvae_linear_bwd, gemm_pair32 on the decoder's last layer), the streamed
+# round 2: the launch family that leads the step (hidvae_linear_bwd, gemm_mid_sk on the decoder's last layer), the streamed
 # code-split RQ kernel of config 5 (4 x 1024 codes, B = 4096) and the opt-in bf16 GEMM
 wd3 = torch.randn(768, 512, device=dev) * 0.03
 gd, xd, pd = torch.randn(B, 768, device=dev), torch.randn(B, 512, device=dev), torch.randn(B, 512, device=dev)
@@ -42,11 +42,13 @@ cb5, cc5 = _C.codebook_prepare(tabs5, [i == 0 for i in range(4)])
 y5 = torch.randn(4096, 32, device=dev)
 x8 = torch.randn(8192, 768, device=dev)
 o8, a8 = torch.empty(8192, 512, device=dev), torch.empty(8192, 512, device=dev)
+g8 = torch.randn(8192, 256, device=dev)
 for _ in range(10):
     _C.linear_bwd(gd, xd, wd3, True, _C.EPI_DSILU, pd)
     _C.rq_forward(y5, cb5, cc5, True, 3, True, 0.4)
     _C.gemm(_C.GEMM_NT, x8, w0, out=o8, epilogue=_C.EPI_SILU, aux=a8)       # fp32 LDS-tiled at B = 8192
     _C.gemm_bf16(_C.GEMM_NT, x8, w0, out=o8, epilogue=_C.EPI_SILU, aux=a8)  # the same layer in the opt-in bf16 mode
+    _C.linear_bwd(g8, o8, w1, True, _C.EPI_DSILU, a8)                       # gemm_mid_sk_kernel with even k-step ranges (B = 8192)
 xb = torch.randn(1 << 16, 768, device=dev)
 ob, ab = torch.empty(1 << 16, 512, device=dev), torch.empty(1 << 16, 512, device=dev)
 for _ in range(5):
