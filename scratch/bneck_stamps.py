@@ -10,17 +10,18 @@ h1 = torch.randn(B, K2, device=dev); W2 = torch.randn(N2, K2, device=dev) * 0.06
 Wd0 = torch.randn(Nd0, 32, device=dev) * 0.2; Wd1 = torch.randn(Nd1, Nd0, device=dev) * 0.09
 tabs = [(torch.rand(K, 32, device=dev) * 2 - 1) * (1.0 if i == 0 else 0.35 * 0.5 ** i) for i in range(L)]
 cb, cc = _C.codebook_prepare(tabs, [i == 0 for i in range(L)])
-names = ["start", "staged", "enc2 done", "enc3 done", "r loaded", "levels done", "HY written", "dec0 done", "claim issued", "dec1 done", "end"]
+SCR = _C.census_scratch(B, dev)
+names = ["start", "staged", "enc2 done", "enc3 done", "levels done", "dec0 done", "dec1 done", "end"]
 lib = _C.lib()
 for rep in range(4):
-    _C.bottleneck_fwd(h1, W2, W3, cb, cc, True, 3, 0.4, Wd0, Wd1, id_stats=True)
+    _C.bottleneck_fwd(h1, W2, W3, cb, cc, True, 3, 0.4, Wd0, Wd1, id_stats=True, scratch=SCR)
     torch.cuda.synchronize()
     out = (ctypes.c_ulonglong * 16)()
     assert lib.hidvae_debug_stamps(out) == 0
-    t = [out[i] for i in range(11)]
-    print("rep", rep, " ".join(f"{names[i]}:+{(t[i]-t[i-1])}" for i in range(1, 11)), "total", t[10] - t[0], flush=True)
+    t = [out[i] for i in range(8)]
+    print("rep", rep, " ".join(f"{names[i]}:+{(t[i]-t[i-1])}" for i in range(1, 8)), "total (10 ns ticks)", t[7] - t[0], flush=True)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(20): _C.bottleneck_fwd(h1, W2, W3, cb, cc, True, 3, 0.4, Wd0, Wd1, id_stats=True)
+for _ in range(20): _C.bottleneck_fwd(h1, W2, W3, cb, cc, True, 3, 0.4, Wd0, Wd1, id_stats=True, scratch=SCR)
 e1.record(); torch.cuda.synchronize()
 print("launch-to-launch us:", e0.elapsed_time(e1) * 50)

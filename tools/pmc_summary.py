@@ -17,7 +17,8 @@ QUOTED = [
     ("rq_forward_kernel (fused L-level VQ, code-split variant)", "rq_forward_kernel<3, true, true, true", None),
     ("rq_forward at 1,048,576 items", "rq_forward_pf32_kernel<3, true", None),
     ("gemm_f32_kernel<2,2,NT> encoder layer 0 at 65,536 rows", "gemm_f32_kernel<2, 2, 0>", None),
-    ("gemm_mid_sk_kernel decoder layer 3 backward", "gemm_mid_sk_kernel<4, 2>", None),
+    ("gemm_mid_sk_kernel decoder layer 3 backward", "gemm_mid_sk_kernel<4, 2>", 253952),   # 96 + 128 tiles + 24 column-sum strips, 1024 threads each
+    ("gemm_mid_sk_kernel even ranges (B=8192, 256x512 layer)", "gemm_mid_sk_kernel<4, 2>", 262144),
     ("rq_forward_kernel streamed code-split (4x1024, B=4096)", "rq_forward_kernel<3, true, false, true, 4, true>", None),
     ("gemm_bf16_kernel<NT> encoder layer 0 at 8192 rows", "gemm_bf16_kernel<0>", None),
 ]
@@ -40,7 +41,7 @@ def main():
     w = csv.writer(sys.stdout)
     w.writerow(["bench_kernel_prefix", "kernel", "grid_work_items", "launches", "FETCH_SIZE_KB", "WRITE_SIZE_KB"])
     for prefix, sub, _ in QUOTED:
-        keys = [k for k in fetch if sub in k[0]]
+        keys = [k for k in fetch if sub in k[0] and (_ is None or int(k[1]) == _)]
         if not keys:
             continue
         k = max(keys, key=lambda kk: int(kk[1]))  # the quoted launch is the largest grid of that instantiation
