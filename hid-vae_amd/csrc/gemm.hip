@@ -1378,6 +1378,144 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_directL16_kernel(GemmArgs g) 
     }
 }
 
+// ---- the exact-chain forward layers on LDS-SHARED tiles (gemm_tile16_kernel): NT, one ORDER-G16 chain per output -----------------
+// gemm_directL16_kernel gives every wave its own 16x16 tile and its own copy of the operand rows: 4 FLOP per byte through L1, and
+// the step's forward layers run at the rate that flow allows (60 TFLOP/s).  Here a workgroup of WM x WN waves owns a (16 WM) x (16 WN)
+// tile and stages a (16 WM + 16 WN) x 64-k slab per step with coalesced 16-byte loads (one row = 256 contiguous bytes per 16 lanes),
+// register-prefetched two steps ahead into one of three LDS buffers; wave (wm, wn) reads its two 16 x 16 fragments per block as one
+// ds_read_b128 each (rows 68 floats apart: conflict-free) and runs the SAME v_mfma_f32_16x16x4_f32 sequence over ascending k as
+// gemm_directL16_kernel -- bit-identical results, 2 WM WN / (WM + WN) times fewer operand bytes per FLOP.
+constexpr int T16_BKS = 64, T16_STR = T16_BKS + 4;
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_tile16_kernel(GemmArgs g) {
+    constexpr int T = 64 * WM * WN, RA = 16 * WM, RB = 16 * WN, NB = 3, PF = 2;
+    constexpr int A_SZ = RA * T16_STR, BUF = (RA + RB) * T16_STR;
+    constexpr int SLOTS = (RA + RB) * (T16_BKS / 4), NV = (SLOTS + T - 1) / T;  // 16-byte slots of a slab, per thread
+    extern __shared__ __attribute__((aligned(16))) float t16_lds[];
+    float *lds = t16_lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int nbx = (int)((g.N + RB - 1) / RB), nby = (int)((g.M + RA - 1) / RA);
+    const int tile = xcd_slot((int)blockIdx.x, nbx * nby);
+    const int by = tile / nbx, bx = tile - by * nbx;
+    const int64_t m0 = (int64_t)by * RA, n0 = (int64_t)bx * RB;
+    const int Ki = (int)g.K;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A), 0, (int)(4 * ((g.M - 1) * g.lda + g.K)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.B), 0, (int)(4 * ((g.N - 1) * g.ldb + g.K)), 0x00020000);
+    // this thread's slots: slot s < RA * 16 -> A row s / 16, else B row; k piece 4 (s % 16)
+    // (WN == 4: the A slab's slots are exactly the threads' first slot, every later slot is B's -- the buffer resource of a load is
+    //  then known at compile time, as the scalar operand it is)
+    static_assert(WN == 4 && SLOTS == NV * T && RA * (T16_BKS / 4) == T, "slot v == 0 <-> A, v >= 1 <-> B");
+    int off[NV], dst[NV], k4[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const int sl = tid + v * T;
+        const bool a_slot = v == 0;
+        const int r = (a_slot ? sl : sl - T) / (T16_BKS / 4);
+        k4[v] = 4 * (sl % (T16_BKS / 4));
+        const int64_t row = a_slot ? ((m0 + r < g.M) ? m0 + r : g.M - 1) : ((n0 + r < g.N) ? n0 + r : g.N - 1);
+        off[v] = 4 * ((int)(row * (a_slot ? g.lda : g.ldb)) + k4[v]);
+        dst[v] = (a_slot ? 0 : A_SZ) + r * T16_STR + k4[v];
+    }
+    const int nsteps = (Ki + T16_BKS - 1) / T16_BKS;
+    f32x4 pf[PF][NV];
+    auto fetch = [&](int slot, int s) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const bool in = s * T16_BKS + k4[v] < Ki;
+            pf[slot][v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v == 0 ? ra : rb, in ? off[v] : HV_OOB, s * (4 * T16_BKS), 0));
+        }
+    };
+    auto stash = [&](int slot, int s, int buf) {
+        float *base = lds + buf * BUF;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            f32x4 x = pf[slot][v];
+            const int k = s * T16_BKS + k4[v];
+            if (k + 4 > Ki) {  // the piece straddles the end of the row: what follows K belongs to the next row
+#pragma unroll
+                for (int e = 0; e < 4; e++) x[e] = k + e < Ki ? x[e] : 0.0f;
+            }
+            *reinterpret_cast<f32x4 *>(base + dst[v]) = x;
+        }
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[2][4], fb[2][4];
+    auto frags = [&](int fs, int buf) {
+        const float *As = lds + buf * BUF + (16 * wm + i16) * T16_STR + 4 * q;
+        const float *Bs = lds + buf * BUF + A_SZ + (16 * wn + i16) * T16_STR + 4 * q;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            fa[fs][u] = *reinterpret_cast<const f32x4 *>(As + 16 * u);
+            fb[fs][u] = *reinterpret_cast<const f32x4 *>(Bs + 16 * u);
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; p++) fetch(p, p);
+    stash(0, 0, 0);
+    fetch(0, PF);
+    stash(1 % PF, 1, 1);
+    fetch(1 % PF, PF + 1);
+    __syncthreads();
+    frags(0, 0);
+    constexpr int UN = 6;  // lcm(2 fragment sets, NB, PF)
+    for (int s0 = 0; s0 < nsteps; s0 += UN) {
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int s = s0 + u;
+            if (s < nsteps) {  // (uniform)
+                const int nblk = (Ki - s * T16_BKS + 15) / 16;  // 16-blocks of this step that hold any k < K (>= 4: all of them)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u & 1][0][s4], fb[u & 1][0][s4], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < nsteps) frags((u + 1) & 1, (u + 1) % NB);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 1; b < 4; b++)
+                    if (b < nblk) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u & 1][b][s4], fb[u & 1][b][s4], acc, 0, 0, 0);
+                    }
+                if (s + 2 < nsteps) {
+                    stash((u + 2) % PF, s + 2, (u + 2) % NB);
+                    fetch((u + 2) % PF, s + 2 + PF);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+    const int64_t col = n0 + 16 * wn + i16;
+    if (col >= g.N) return;
+    const float bias = g.bias != nullptr ? g.bias[col] : 0.0f;
+    const float *mk = g.mask;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int64_t row = m0 + 16 * wm + 4 * q + r;
+        if (row >= g.M) continue;
+        float v = acc[r] + bias;
+        if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
+        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+        if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+        float *dstp = g.C + row * g.ldc + col;
+        *dstp = g.accumulate ? *dstp + v : v;
+    }
+}
+
+template <int WM, int WN>
+int launch_tile16(const GemmArgs &g, hipStream_t s) {
+    constexpr size_t bytes = (size_t)3 * (16 * WM + 16 * WN) * T16_STR * 4;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile16_kernel<WM, WN>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (attr != hipSuccess) return -1;
+    const int64_t tiles = hv_cdiv(g.M, 16 * WM) * hv_cdiv(g.N, 16 * WN);
+    hipLaunchKernelGGL((gemm_tile16_kernel<WM, WN>), dim3((unsigned)tiles), dim3(64 * WM * WN), bytes, s, g);
+    return 0;
+}
+
 template <int SPLIT>
 void launch_directL(int layout, const GemmArgs &g, hipStream_t s) {
     dim3 grid((unsigned)hv_cdiv(g.N, 32), (unsigned)hv_cdiv(g.M, 32));
@@ -1632,6 +1770,18 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
             // 19.5 -> 13.2, 1024x256x512 10.8 -> 7.9, 1024x512x256 11.3 -> 7.4, 1000x300x333 12.7 -> 8.6 (HIDVAE_GEMM_L16=0: off)
             static const int use_l16 = getenv("HIDVAE_GEMM_L16") ? atoi(getenv("HIDVAE_GEMM_L16")) : 1;
             const int64_t nt16 = hv_cdiv(M, 16) * hv_cdiv(N, 16);
+            // the widest of them on LDS-shared 32x64 tiles (gemm_tile16_kernel): same chain, same bits, a third of the operand traffic
+            static const int use_t16 = getenv("HIDVAE_GEMM_T16") ? atoi(getenv("HIDVAE_GEMM_T16")) : 1;
+            // -- where the tiles fill the chip in ONE round (192 .. 256 of them): 1024x512x768 16.1 -> 13.5 us (32x64), 2048x512x768
+            // 24.9 -> 20.7 (64x64); with 1.5 rounds (1024x768x512 on 32x64 tiles) the finer-grained kernel below wins, 14.8 vs 16.3
+            const int64_t t_small = hv_cdiv(M, 32) * hv_cdiv(N, 64), t_big = hv_cdiv(M, 64) * hv_cdiv(N, 64);
+            const bool fit_small = t_small >= 192 && t_small <= 256, fit_big = t_big >= 224 && t_big <= 256;  // (192 64x64 tiles: no gain)
+            if (use_t16 && layout == HIDVAE_GEMM_NT && split_k == 1 && K >= 256 && (fit_small || fit_big || use_t16 >= 2)) {
+                const int rc = (use_t16 == 3 || (use_t16 == 1 && !fit_small)) ? launch_tile16<4, 4>(g, s) : launch_tile16<2, 4>(g, s);
+                HV_REQUIRE(rc == 0, "gemm_f32: could not size the LDS of gemm_tile16_kernel");
+                HV_LAUNCH_CHECK("gemm_f32 tile16");
+                return HIDVAE_OK;
+            }
             if (use_l16 && layout == HIDVAE_GEMM_NT && nt16 >= 512 && nt16 <= 8192 && K >= 64 &&
                 (split_k == 1 || use_l16 == 2 || (use_direct16(M, N, K) && K >= 128))) {
                 constexpr int W16 = 4;

@@ -22,7 +22,8 @@ def dev(a):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (1024, 512, 768), (128, 32, 128), (100, 38, 115), (33, 230, 691),
-                                   (7, 5, 3), (256, 768, 512), (4096, 1024, 96), (8192, 512, 40)])
+                                   (7, 5, 3), (256, 768, 512), (4096, 1024, 96), (8192, 512, 40),
+                                   (1000, 500, 333), (2048, 512, 777)])  # (the last two: gemm_tile16_kernel, ragged K, both tile shapes)
 def test_gemm_nt_is_the_sequential_fmaf_chain(C, M, N, K):
     x = fill.uniform((M, K), 1, -1, 1)
     w = fill.uniform((N, K), 2, -1, 1)
