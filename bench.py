@@ -116,7 +116,7 @@ def time_kernel(fn, launches=20, reps=20):
 
 def kernel_rooflines(args, m, device):
     """Live per-kernel timings on the bench shapes.
-    * gemm_directL16_kernel / gemm_direct_kernel / gemm_mid_sk_kernel (fp32 MFMA roofline, 157.3 TFLOP/s): the largest GEMMs of the step;
+    * gemm_tile16_kernel / gemm_direct_kernel / gemm_mid_sk_kernel (fp32 MFMA roofline, 157.3 TFLOP/s): the largest GEMMs of the step;
     * rq_forward_kernel (HBM roofline, 8 TB/s): ALGORITHMIC bytes per item exactly as SURVEY.md 8(d) counts them for the tagged
       variant: read z 128 B, write ids 8L, per-level emb_out 128L, loss 4 = 540 B at L=3 (+ the codebooks 4*L*K*32 once per
       launch).  The launch also writes emb_sum and z (128 B each, consumed by the decoder and the backward): `bytes_moved`
@@ -131,7 +131,7 @@ def kernel_rooflines(args, m, device):
     a0 = torch.empty(B, 512, device=device)
     t = time_kernel(lambda: _C.gemm(_C.GEMM_NT, x, w0, out=o0, epilogue=_C.EPI_SILU, aux=a0))
     fl = 2.0 * B * 768 * 512
-    out.append(dict(entry="hidvae_gemm_f32", kernel="gemm_directL16_kernel encoder layer 0: [B,768]x[768,512]^T + SiLU (exact ORDER-G chain, coalesced loads through per-wave LDS strips)", bound="mfma",
+    out.append(dict(entry="hidvae_gemm_f32", kernel="gemm_tile16_kernel encoder layer 0: [B,768]x[768,512]^T + SiLU (exact ORDER-G chain, LDS-shared 32x64 tiles)", bound="mfma",
                     achieved=fl / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
                     us=t, flops=fl))
     g = torch.randn(B, 512, device=device)
@@ -238,7 +238,7 @@ def summarize_timeline(rows):
 
 
 def describe_launch(r):
-    what = {"hidvae_gemm_f32": "forward Linear layers: gemm_directL16 / gemm_direct16 kernels, fp32 MFMA, one exact ORDER-G chain per output",
+    what = {"hidvae_gemm_f32": "forward Linear layers: gemm_tile16 / gemm_directL16 / gemm_direct16 kernels, fp32 MFMA, one exact ORDER-G chain per output",
             "hidvae_linear_bwd": "one-launch Linear backward dW = g^T x + dX = g W (+ db): gemm_mid_sk (widest layer) / gemm_pair16 / gemm_pair32 kernels, fp32 MFMA",
             "hidvae_bottleneck_fwd": "fused middle launch: encoder[-2:] + L-level RQ + decoder[:2], fp32 MFMA"}.get(r["entry"], "")
     shapes = "; ".join(f"{m}x{n}x{k}" for m, n, k in r.get("shapes", [])[:8])

@@ -12,12 +12,12 @@ from collections import defaultdict
 
 # bench.py kernel-name prefix  <-  (substring of the profiled kernel name, grid size in work-items)
 QUOTED = [
-    ("gemm_directL16_kernel encoder layer 0", "gemm_directL16_kernel<4>", None),
+    ("gemm_tile16_kernel encoder layer 0", "gemm_tile16_kernel<2, 4>", None),
     ("gemm_direct_kernel<TN,8,3> dW encoder layer 0", "gemm_direct_kernel<2, 8, 3", None),
     ("rq_forward_kernel (fused L-level VQ, code-split variant)", "rq_forward_kernel<3, true, true, true", None),
     ("rq_forward at 1,048,576 items", "rq_forward_pf32_kernel<3, true", None),
     ("gemm_f32_kernel<2,2,NT> encoder layer 0 at 65,536 rows", "gemm_f32_kernel<2, 2, 0>", None),
-    ("gemm_mid_sk_kernel decoder layer 3 backward", "gemm_mid_sk_kernel<4, 2>", 253952),   # 96 + 128 tiles + 24 column-sum strips, 1024 threads each
+    ("gemm_mid_sk_kernel decoder layer 3 backward", "gemm_mid_sk_kernel<4, 2>", 229376),   # 96 + 128 tiles (no bias here), 1024 threads each
     ("gemm_mid_sk_kernel even ranges (B=8192, 256x512 layer)", "gemm_mid_sk_kernel<4, 2>", 262144),
     ("rq_forward_kernel streamed code-split (4x1024, B=4096)", "rq_forward_kernel<3, true, false, true, 4, true>", None),
     ("gemm_bf16_kernel<NT> encoder layer 0 at 8192 rows", "gemm_bf16_kernel<0>", None),
