@@ -348,3 +348,36 @@ def test_padded_to_jagged_and_its_backward(C, dtype, B, N, D):
         gx[b, :int(lengths[b])] = w[row:row + int(lengths[b])]
         row += int(lengths[b])
     assert torch.equal(x.grad, gx)
+
+
+@pytest.mark.parametrize("M,N,relu,masked", [(1024, 768, True, True), (1000, 691, False, True), (37, 230, True, False), (2048, 256, False, False),
+                                             (5, 1024, True, True)])
+def test_layernorm_forward_and_backward_against_float64(C, M, N, relu, masked):
+    """hidvae_layernorm_fwd + hidvae_layernorm_bwd_all (gx and the affine gradients from one pass over the rows + a fixed-order finish)
+    against torch float64 autograd of drop(relu(LN(x))) + res; gradient slots with accumulation; launch-to-launch bit identity"""
+    x = dev(fill.gauss((M, N), 80))
+    gamma, beta = dev(fill.uniform((N,), 81, 0.5, 1.5)), dev(fill.uniform((N,), 82, -0.3, 0.3))
+    gy = dev(fill.gauss((M, N), 83))
+    mask = dev((fill.uniform((M, N), 84, 0, 1) < 0.7).astype(np.float32)) if masked else None
+    scale = 1.0 / 0.7 if masked else 1.0
+    y, mean, rstd = C.layernorm_fwd(x, gamma, beta, 1e-5, relu, mask, scale, None)
+    xd = x.cpu().double().requires_grad_(True)
+    gd, bd = gamma.cpu().double().requires_grad_(True), beta.cpu().double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (N,), gd, bd, 1e-5)
+    if relu:
+        ref = torch.relu(ref)
+    if masked:
+        ref = ref * (mask.cpu().double() * scale)
+    assert H.close(y.cpu().numpy(), ref.detach().float().numpy(), 2e-5, 2e-5)
+    ref.backward(gy.cpu().double())
+    gg0, gb0 = torch.ones(N, device="cuda"), torch.ones(N, device="cuda")
+    gx, gg, gb = C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, scale, gg=gg0, gb=gb0, accumulate=True)
+    # (an element whose pre-activation is within rounding of 0 may sit on the other side of the ReLU in float64: bulk-tight)
+    assert H.rel_err(gx.cpu().numpy(), xd.grad.float().numpy()) < 3e-5
+    assert H.rel_err(gg.cpu().numpy(), (1.0 + gd.grad).float().numpy()) < 3e-5
+    assert H.rel_err(gb.cpu().numpy(), (1.0 + bd.grad).float().numpy()) < 3e-5
+    a = C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, scale)
+    b = C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, scale)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    none, gg2, gb2 = C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, scale, need_gx=False)
+    assert none is None and torch.equal(gg2, a[1]) and torch.equal(gb2, a[2])
