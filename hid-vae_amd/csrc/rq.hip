@@ -899,7 +899,10 @@ __device__ __forceinline__ void pf32_tile(const char *Ch, const char *Cl, const 
     if (best1 < before) tbest = t;
 }
 
-template <int MODE, bool TRAIN, int NW, int NT>  // NT: 32-code tiles per level when known at compile time (full unroll), else 0
+// PIPE (needs NT > 0): two accumulator sets in ping-pong -- the MFMAs of tile t + 1 are issued one at a time between the scan
+// operations of tile t (a wave issues in order: behind a chain of dependent MFMAs it could not issue anything), so the matrix pipe
+// and the vector ALU work at the same time INSIDE a wave, not only across the waves of a SIMD.  16 more VGPRs: 8 waves per workgroup.
+template <int MODE, bool TRAIN, int NW, int NT, bool PIPE = false>  // NT: 32-code tiles per level when known at compile time (full unroll), else 0
 __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char pf_lds[];
     __shared__ unsigned ccmax_bits[HIDVAE_MAX_LEVELS];
@@ -950,7 +953,52 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
             }
             float best1 = INFINITY, best2 = INFINITY;
             int tbest = 0;
-            if (NT > 0) {
+            if (NT > 0 && PIPE) {
+                f32x16 acc2[2];
+                auto issue = [&](int tt, int sl) {
+                    const int rowb = 32 * tt * 64;
+                    const bf16x8_t ah0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Ch + rowb + off_p0));
+                    const bf16x8_t ah1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Ch + rowb + off_p1));
+                    const bf16x8_t al0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Cl + rowb + off_p0));
+                    const bf16x8_t al1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Cl + rowb + off_p1));
+                    f32x16 acc;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const float4 c4 = *reinterpret_cast<const float4 *>(ccs + 32 * tt + 8 * g + 4 * h);
+                        acc[4 * g] = c4.x; acc[4 * g + 1] = c4.y; acc[4 * g + 2] = c4.z; acc[4 * g + 3] = c4.w;
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[0], acc, 0, 0, 0);  // (the MFMA order of pf32_tile: the same scores)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[1], acc, 0, 0, 0);
+                    acc2[sl] = acc;
+                };
+                auto scan = [&](int tt, int sl) {
+                    const float before = best1;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const float sc = __uint_as_float((__float_as_uint(acc2[sl][j]) & 0xfffffff0u) | (unsigned)j);
+                        best2 = __builtin_amdgcn_fmed3f(best1, best2, sc);
+                        best1 = vmin_f32(best1, sc);
+                    }
+                    if (best1 < before) tbest = 32 * tt;
+                };
+                issue(0, 0);
+#pragma unroll
+                for (int tt = 0; tt < NT; tt++) {
+                    if (tt + 1 < NT) issue(tt + 1, (tt + 1) & 1);
+                    scan(tt, tt & 1);
+                    if (tt + 1 < NT) {
+#pragma unroll
+                        for (int i = 0; i < 6; i++) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA of the next tile ...
+                            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // ... eight scan operations of this one under it
+                        }
+                    }
+                }
+            } else if (NT > 0) {
 #pragma unroll
                 for (int tt = 0; tt < NT; tt++) pf32_tile(Ch, Cl, ccs, 32 * tt, off_p0, off_p1, h, bh, bl, best1, best2, tbest);
             } else {
@@ -1631,13 +1679,18 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
         p.nchunks = 1;
         constexpr int PF32_NW = 12;  // waves per workgroup: three per SIMD, up to 170 VGPRs each (measured at 1M items: 16 waves / 128 VGPRs
                                      // with spills 480-500 us, 12 waves 436-448 us, 8 waves 457 us)
-        const int64_t nt = hv_cdiv(B, 32 * PF32_NW);
+        // ping-pong accumulators (8 waves): 131,072 items 79.5 -> 67.9 us, 524,288 232 -> 217, 1,048,576 388 -> 386 (HIDVAE_RQ_PF32_PIPE=0: off)
+        static const int pipe_env = getenv("HIDVAE_RQ_PF32_PIPE") ? atoi(getenv("HIDVAE_RQ_PF32_PIPE")) : 1;
+        const bool pipe = pipe_env != 0 && KCp == 256;
+        const int pnw = pipe ? 8 : PF32_NW;
+        const int64_t nt = hv_cdiv(B, 32 * pnw);
         const int pgrid = (int)(nt < 256 ? nt : 256);
 #define HV_PF32(M, T)                                                                                                          \
     {                                                                                                                          \
-        auto kern = KCp == 256 ? rq_forward_pf32_kernel<M, T, PF32_NW, 8> : rq_forward_pf32_kernel<M, T, PF32_NW, 0>;                    \
+        auto kern = pipe ? rq_forward_pf32_kernel<M, T, 8, 8, true>                                                             \
+                         : (KCp == 256 ? rq_forward_pf32_kernel<M, T, PF32_NW, 8> : rq_forward_pf32_kernel<M, T, PF32_NW, 0>);  \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf32_bytes); \
-        hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * PF32_NW), pf32_bytes, s, p);                                           \
+        hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * pnw), pf32_bytes, s, p);                                               \
     }
         if (!training) HV_PF32(HIDVAE_MODE_STE, false)
         else if (mode == HIDVAE_MODE_STE) HV_PF32(HIDVAE_MODE_STE, true)
