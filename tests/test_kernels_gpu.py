@@ -381,3 +381,22 @@ def test_layernorm_forward_and_backward_against_float64(C, M, N, relu, masked):
     assert all(torch.equal(u, v) for u, v in zip(a, b))
     none, gg2, gb2 = C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, scale, need_gx=False)
     assert none is None and torch.equal(gg2, a[1]) and torch.equal(gb2, a[2])
+
+
+def test_linear_bwd_hand_over_is_stable_under_traffic(C):
+    """equal-range schedule of the balanced kernel: partial tiles cross workgroups (and XCDs) through cache-bypassing stores / loads and
+    an arrival counter -- 600 launches with a large copy running on a second stream, every result bit-identical to the first
+    (the long version, 20,000 launches on five shapes: scratch/sk_stress.py)"""
+    B, n_out, n_in = 2048, 768, 512
+    g, x, w = dev(fill.gauss((B, n_out), 90)), dev(fill.gauss((B, n_in), 91)), dev(fill.gauss((n_out, n_in), 92))
+    ref = [t.clone() for t in C.linear_bwd(g, x, w, True, bias=True)]
+    side = torch.cuda.Stream()
+    big_a, big_b = torch.randn(32 << 20, device="cuda"), torch.empty(32 << 20, device="cuda")
+    for it in range(600):
+        if it % 40 == 0:
+            with torch.cuda.stream(side):
+                big_b.copy_(big_a)
+        out = C.linear_bwd(g, x, w, True, bias=True)
+        if it % 20 == 0 or it >= 590:
+            assert all(torch.equal(a, b) for a, b in zip(out, ref)), f"launch {it} differs"
+    torch.cuda.synchronize()
