@@ -13,6 +13,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step -- python3 $R/
 note "pass step done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_tagged -- python3 $R/bench.py --cpu-seconds 0 --steps 50 --warmup 5 --also-large 0 --kernels 0 --windows 1 --tagged 1 > $OUT/step_tagged.log 2>&1
 note "pass step_tagged done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_config3 -- python3 $R/bench.py --cpu-seconds 0 --steps 50 --warmup 5 --also-large 0 --also-tagged 0 --kernels 0 --windows 1 --batch 2048 --tagged 1 > $OUT/step_config3.log 2>&1
+note "pass step_config3 (B=2048, tagged) done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_config5 -- python3 $R/bench.py --cpu-seconds 0 --steps 100 --warmup 10 --also-large 0 --also-tagged 0 --kernels 0 --windows 1 --batch 4096 --levels 4 --codes 1024 > $OUT/step_config5.log 2>&1
+note "pass step_config5 (B=4096, 4x1024) done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_config4 -- python3 $R/bench.py --cpu-seconds 0 --steps 100 --warmup 10 --also-large 0 --also-tagged 0 --kernels 0 --windows 1 --batch 8192 > $OUT/step_config4.log 2>&1
+note "pass step_config4 (B=8192 shard) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/quoted -- python3 $R/tools/profile_kernels.py > $OUT/quoted.log 2>&1
 note "pass quoted done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/tools/profile_kernels.py > $OUT/fetch.log 2>&1
@@ -27,10 +33,10 @@ note "pass tcc done"
 python3 $R/tools/pmc_summary.py $OUT/fetch $OUT/write > $OUT/${TAG}_quoted_kernels_pmc_hbm_traffic.csv
 python3 $R/tools/pmc_table.py $OUT/sq > $OUT/${TAG}_quoted_kernels_pmc_sq.csv
 python3 $R/tools/pmc_table.py $OUT/tcc > $OUT/${TAG}_quoted_kernels_pmc_l2.csv
-for d in step step_tagged quoted; do
+for d in step step_tagged step_config3 step_config4 step_config5 quoted; do
   f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1)
   cp "$f" $OUT/${TAG}_${d}_kernel_stats.csv
 done
 # keep only the folded files in the merge-back (<= 64 MiB)
-rm -rf $OUT/step $OUT/step_tagged $OUT/quoted $OUT/fetch $OUT/write $OUT/sq $OUT/tcc
+rm -rf $OUT/step $OUT/step_tagged $OUT/step_config3 $OUT/step_config4 $OUT/step_config5 $OUT/quoted $OUT/fetch $OUT/write $OUT/sq $OUT/tcc
 ls -la $OUT
