@@ -414,7 +414,7 @@ def _tag_streams(device, n):
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     st = _TAG_STREAMS.setdefault(key, [None])
     while len(st) < n:
-        st.append(torch.cuda.Stream(device=device))
+        st.append(torch.cuda.Stream(device=device))  # (a high-priority stream for the widest level: 4.4 ms instead of 1.8 under graph replay)
         _C.register_ws_lane(st[-1])  # its Linear backwards run next to the other levels': a workspace of their own
     return st
 
@@ -544,7 +544,15 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
     # 2.31 ms against 2.64 ms on one stream.  HIDVAE_TAG_STREAMS=0 keeps everything on the caller's stream.
     # (one stream per level: 2.31 ms; additionally splitting projector+alignment from predictor+loss, 2L branches: 2.68 ms)
     main = torch.cuda.current_stream()
-    branch = _tag_streams(emb_cat.device, L) if (L > 1 and os.environ.get("HIDVAE_TAG_STREAMS", "1") != "0") else None
+    # HIDVAE_TAG_STREAMS: 2 (default) = EVERY level on a stream of its own, the caller's stream is left to the decoder and the loss
+    # (1.78-1.79 ms against 1.85-1.86 ms with level 0 on the caller's stream, B = 2048: 2.84 vs 2.91 ms); 1 = level 0 stays with the caller
+    mode = os.environ.get("HIDVAE_TAG_STREAMS", "2")
+    branch = _tag_streams(emb_cat.device, L + (1 if mode == "2" else 0)) if (L > 1 and mode != "0") else None
+    if branch is not None and mode == "2":
+        branch = [None] + branch[1:]
+        lvl_stream = lambda i: branch[i + 1]
+    else:
+        lvl_stream = lambda i: (branch[i] if branch is not None and i > 0 else None)
     if branch is not None:
         for t in (emb_cat, tags_emb, tags_indices):  # main-stream allocations that the branches (and their backward) read
             for st in branch[1:]:
@@ -552,7 +560,7 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
         for st in branch[1:]:
             st.wait_stream(main)
     for i in range(L):
-        st = branch[i] if branch is not None and i > 0 else None
+        st = lvl_stream(i)
         with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
             c_nce, c_att, c_gate = views[3 * i], views[3 * i + 1], views[3 * i + 2]
             proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
