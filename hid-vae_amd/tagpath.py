@@ -419,6 +419,26 @@ def _tag_streams(device, n):
     return st
 
 
+def early_mixup(rand, targets, device, n_levels):
+    """The mixup pairing of the step (one torch.rand + hidvae_mixup_plan, ~28 us) needs nothing but the tag indices: issued at the
+    START of the forward on the first tag stream, it runs beside the encoder instead of between the quantiser and the heads.
+    Only with every level on a stream of its own (HIDVAE_TAG_STREAMS=2); tag_heads_forward then makes the other levels wait for it."""
+    if os.environ.get("HIDVAE_TAG_STREAMS", "2") != "2" or os.environ.get("HIDVAE_TAG_GROUPED", "0") == "1" or n_levels < 2 or n_levels > 4:
+        return
+    st = _tag_streams(device, n_levels + 1)
+    main = torch.cuda.current_stream()
+    st[1].wait_stream(main)
+    targets.record_stream(st[1])
+    with torch.cuda.stream(st[1]):
+        rand.prepare_mixup(targets, device)
+        for triple in rand._mix:
+            for t in triple:
+                if torch.is_tensor(t):
+                    for other in st[2:]:
+                        t.record_stream(other)
+    rand._mix_early = True
+
+
 def _glin(xs, mods, act=_C.EPI_NONE, masks=None, scales=None):
     """the same Linear of every head in one launch: xs / mods / masks lists over the heads"""
     n = len(xs)
@@ -535,7 +555,10 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
     E = model.tag_embed_dim
     aligns, preds, accs = [], [], []
     lm = model.tag_prediction_loss
-    if training and torch.is_grad_enabled() and lm.use_mixup and B > 1 and hasattr(rand, "prepare_mixup"):
+    mix_early = bool(getattr(rand, "_mix_early", False))
+    if mix_early:
+        rand._mix_early = False  # (the pairing of this step is already on its way: early_mixup)
+    elif training and torch.is_grad_enabled() and lm.use_mixup and B > 1 and hasattr(rand, "prepare_mixup"):
         rand.prepare_mixup(tags_indices[:, :L], emb_cat.device)  # the pairings of all levels from one batched set of launches
     # The L levels' heads are independent of each other (~100 launches each, most of them small), so levels 1..L-1 run on their
     # own streams beside level 0.  Autograd replays each branch's backward on the stream its forward ran on and joins them
@@ -559,6 +582,9 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
                 t.record_stream(st)
         for st in branch[1:]:
             st.wait_stream(main)
+        if mix_early:
+            for st in branch[2:]:
+                st.wait_stream(branch[1])
     for i in range(L):
         st = lvl_stream(i)
         with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
