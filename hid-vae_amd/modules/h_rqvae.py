@@ -341,11 +341,13 @@ class HRqVae(nn.Module, _HubMixin):
         if self.training and tagged:
             r = self._rand()
             if hasattr(r, "begin_step"):
-                r.begin_step(x.device)  # all dropout keep-masks of the step from one launch (rand.DeviceRand)
-            lm = self.tag_prediction_loss
-            if torch.is_grad_enabled() and lm.use_mixup and x.shape[0] > 1 and hasattr(r, "prepare_mixup"):
-                from ..tagpath import early_mixup
-                early_mixup(r, tags_indices[:, :self.n_layers], x.device, self.n_layers)  # beside the encoder, not after the quantiser
+                # all dropout keep-masks of the step from one launch, and the mixup pairing (rand.DeviceRand) -- on the first tag stream,
+                # beside the encoder, when the heads run on streams of their own (tagpath.early_rand)
+                from ..tagpath import early_rand
+                lm = self.tag_prediction_loss
+                mix = torch.is_grad_enabled() and lm.use_mixup and x.shape[0] > 1 and hasattr(r, "prepare_mixup")
+                if not (hasattr(r, "_arena") and early_rand(r, tags_indices[:, :self.n_layers], x.device, self.n_layers, mix)):
+                    r.begin_step(x.device)
         self._prepared = self._prepare_codebooks_async()  # effective codebooks + |c|^2 on the helper stream, beside the encoder
         # data-parallel overlap (step.GraphedTrainStep): with `dp_cut` set the backward is split in two at the inputs of the decoder's
         # tail and of the loss launch, so the gradients of the decoder's last layers -- final first -- go on the wire while the rest of

@@ -419,24 +419,32 @@ def _tag_streams(device, n):
     return st
 
 
-def early_mixup(rand, targets, device, n_levels):
-    """The mixup pairing of the step (one torch.rand + hidvae_mixup_plan, ~28 us) needs nothing but the tag indices: issued at the
-    START of the forward on the first tag stream, it runs beside the encoder instead of between the quantiser and the heads.
-    Only with every level on a stream of its own (HIDVAE_TAG_STREAMS=2); tag_heads_forward then makes the other levels wait for it."""
+def early_rand(rand, targets, device, n_levels, want_mixup):
+    """The step's random draws need nothing from the model: the keep-masks of every dropout site (one torch.bernoulli, ~30 us) and the
+    mixup pairing (one torch.rand + hidvae_mixup_plan, ~28 us; needs only the tag indices) are issued at the START of the forward on
+    the first tag stream, where they run beside the encoder instead of in front of it / between the quantiser and the heads.  The
+    generator is advanced in the same order as before (masks, then pairing), so the draws are the same numbers.
+    Only with every level on a stream of its own (HIDVAE_TAG_STREAMS=2); tag_heads_forward makes the other levels wait for them.
+    -> True if the draws were issued here."""
     if os.environ.get("HIDVAE_TAG_STREAMS", "2") != "2" or os.environ.get("HIDVAE_TAG_GROUPED", "0") == "1" or n_levels < 2 or n_levels > 4:
-        return
+        return False
     st = _tag_streams(device, n_levels + 1)
     main = torch.cuda.current_stream()
     st[1].wait_stream(main)
     targets.record_stream(st[1])
     with torch.cuda.stream(st[1]):
-        rand.prepare_mixup(targets, device)
-        for triple in rand._mix:
-            for t in triple:
-                if torch.is_tensor(t):
-                    for other in st[2:]:
-                        t.record_stream(other)
-    rand._mix_early = True
+        rand.begin_step(device)
+        made = [rand._arena] if getattr(rand, "_arena", None) is not None else []
+        if want_mixup:
+            rand.prepare_mixup(targets, device)
+            made += [t for triple in rand._mix for t in triple if torch.is_tensor(t)]
+        for t in made:  # allocated on the first tag stream, read on the others (and by their backward)
+            for other in st[2:]:
+                t.record_stream(other)
+            t.record_stream(main)
+    rand._early = True
+    rand._mix_early = bool(want_mixup)
+    return True
 
 
 def _glin(xs, mods, act=_C.EPI_NONE, masks=None, scales=None):
@@ -555,9 +563,12 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
     E = model.tag_embed_dim
     aligns, preds, accs = [], [], []
     lm = model.tag_prediction_loss
-    mix_early = bool(getattr(rand, "_mix_early", False))
+    early = bool(getattr(rand, "_early", False))       # (the draws of this step are already on their way on the first tag stream:
+    mix_early = bool(getattr(rand, "_mix_early", False))  #  early_rand)
+    if early:
+        rand._early = rand._mix_early = False
     if mix_early:
-        rand._mix_early = False  # (the pairing of this step is already on its way: early_mixup)
+        pass
     elif training and torch.is_grad_enabled() and lm.use_mixup and B > 1 and hasattr(rand, "prepare_mixup"):
         rand.prepare_mixup(tags_indices[:, :L], emb_cat.device)  # the pairings of all levels from one batched set of launches
     # The L levels' heads are independent of each other (~100 launches each, most of them small), so levels 1..L-1 run on their
@@ -582,7 +593,7 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
                 t.record_stream(st)
         for st in branch[1:]:
             st.wait_stream(main)
-        if mix_early:
+        if early:
             for st in branch[2:]:
                 st.wait_stream(branch[1])
     for i in range(L):
