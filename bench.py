@@ -176,6 +176,14 @@ def kernel_rooflines(args, m, device):
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=algb / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t, algorithmic_bytes=algb,
                     bytes_moved=(128 + 8 * L + 128 * L + 128 + 128 + 4) * big + 4 * L * K * 32,
                     fp32_equivalent_mfma_frac=2.0 * big * L * K * 32 / t * 1e-6 / MFMA_F32_PEAK_TF, items_per_s=big / t * 1e6))
+    # the ids-only form of the same search (HSemanticIdTokenizer.precompute_corpus_ids: only the ids leave the launch), priced on ITS
+    # algorithmic bytes: read z 128 B + write ids 8 L per item
+    t = time_kernel(lambda: _C.rq_ids(yb, cb, cc, True), launches=2, reps=5)
+    algi = (128 + 8 * L) * big + 4 * L * K * 32
+    out.append(dict(kernel="rq_forward ids-only at 1,048,576 items (rq_forward_pf32_kernel<.., IDS>: eval search, no output rows, no winner fetch after the last level)",
+                    bound="hbm", achieved=algi / t * 1e-3, peak=HBM_PEAK_GBS, unit="GB/s", frac=algi / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t,
+                    algorithmic_bytes=algi, bytes_moved=algi, fp32_equivalent_mfma_frac=2.0 * big * L * K * 32 / t * 1e-6 / MFMA_F32_PEAK_TF,
+                    items_per_s=big / t * 1e6))
     return out
 
 
@@ -399,11 +407,81 @@ def run_workload(args, device, rank, world, dist):
 
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, child=None, env=None):
+    """`python bench.py --gpus N` with no launcher around it: start N rank processes, one per device, and relay rank 0's JSON line.
+
+    Runs BEFORE anything in this process touches the GPU (the parent never does: it only waits).  Every child is this script again
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- exactly the environment `python -m torch.distributed.run
+    --nproc-per-node N` gives it, so both ways of starting the N > 1 bench run the same code.  (The reference gets its ranks from
+    `accelerate launch`, train_hidvae.py:186-189.)  Rank 0's stdout is relayed to ours, the other ranks' stdout goes to stderr; the
+    exit code is the first non-zero child code; when one rank dies the others are terminated (by PID) instead of left waiting in a
+    collective.  `child` replaces the command (tests)."""
+    import subprocess
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(_free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), HIDVAE_BENCH_CHILD="1")
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+
+    def relay():  # rank 0 prints the one JSON line (and nothing else) on stdout
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode() if isinstance(line, bytes) else line)
+            sys.stdout.flush()
+
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # a dead rank leaves the others in a collective that never completes
+                        q.terminate()
+            if pending:
+                time.sleep(0.05)
+        pump.join(timeout=10)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one (before any GPU call in this process; device_count() does not initialise the GPU)
+        if os.environ.get("HIDVAE_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
+            print(f"[bench] --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible (RCCL wants one device per rank)", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        if "WORLD_SIZE" in os.environ and args.gpus > 1:
+            print(f"[bench] --gpus {args.gpus} disagrees with WORLD_SIZE={world} of the launcher", file=sys.stderr)
+            sys.exit(2)
     if os.environ.get("HIDVAE_DIST_BACKEND", "nccl") != "nccl":
         local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -417,6 +495,9 @@ def main():
         # ranks on one device); then every rank uses device LOCAL_RANK % device_count
         backend = os.environ.get("HIDVAE_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+        if dist.get_world_size() != world:
+            raise RuntimeError(f"process group reports {dist.get_world_size()} ranks, the environment said {world}")
+        world = dist.get_world_size()  # n_gpus of the line below = what the communicator (RCCL) reports, not what a flag asked for
 
     dt, m, info = run_workload(args, device, rank, world, dist)
     use_graph, final_loss = info["hip_graph"], info["final_loss"]

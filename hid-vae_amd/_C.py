@@ -98,12 +98,14 @@ class LaunchStamps:
     def __init__(self, device, capacity=4096):
         self.buf = torch.zeros((2 * capacity,), dtype=torch.int64, device=device)
         self.names, self.dims = [], []  # dims: (M, N, K, flops) of GEMM-class launches, else None
+        self.streams = []               # the stream handle every launch went to (tools/step_gantt.py draws one lane per stream)
 
-    def _slot(self, name, dims=None):
+    def _slot(self, name, dims=None, stream=None):
         if 2 * len(self.names) + 2 > self.buf.numel():
             raise RuntimeError("LaunchStamps: capacity exceeded")
         self.names.append(name)
         self.dims.append(dims)
+        self.streams.append(int(getattr(stream, "value", stream) or 0))
         return self.buf.data_ptr() + 16 * (len(self.names) - 1)
 
     def rows(self):
@@ -112,6 +114,13 @@ class LaunchStamps:
         empty = [v for n, v in zip(self.names, d) if n == "(empty)"]
         base = sorted(empty)[len(empty) // 2] if empty else 0.0
         return [(n, v - base) for n, v in zip(self.names, d) if n != "(empty)"], base
+
+    def spans(self):
+        """[(entry, stream handle, start us, end us)] on the device's wall clock, relative to the first stamp (absolute positions:
+        which launches of which stream ran beside each other, where a stream sat idle)"""
+        t = self.buf[: 2 * len(self.names)].cpu().reshape(-1, 2).double() * self.TICK_US
+        t0 = float(t[:, 0].min()) if len(self.names) else 0.0
+        return [(n, s, float(a) - t0, float(b) - t0) for n, s, (a, b) in zip(self.names, self.streams, t.tolist()) if n != "(empty)"]
 
     def rows_with_dims(self):
         rows, base = self.rows()
@@ -174,7 +183,7 @@ class _LibProxy:
             st = _STAMPS
             if st is None:
                 return fn(*a)
-            p = st._slot(name, _gemm_dims(name, a))
+            p = st._slot(name, _gemm_dims(name, a), a[-1])
             L.hidvae_timestamp(ctypes.c_void_p(p), a[-1])
             rc = fn(*a)
             L.hidvae_timestamp(ctypes.c_void_p(p + 8), a[-1])
@@ -482,6 +491,21 @@ def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=Fa
                                    float(beta), _p(z), _p(ids), _p(emb_cat), L * EMBED_DIM, _p(emb_sum), _p(res), _p(qloss),
                                    _stream()), "hidvae_rq_forward")
     return z if z is not None else y, ids, emb_cat, emb_sum, res, qloss
+
+
+def rq_ids(y, cb_eff, cc, normalize_input=False):
+    """Semantic ids only (eval-mode search, o = e): hidvae_rq_forward with every output but `ids` NULL -- the corpus tokenisation of
+    HSemanticIdTokenizer.precompute_corpus_ids (reference h_semids.py:109-195).  At corpus sizes the launch takes the ids-only form of
+    the prefilter kernel (no output rows, no winner fetch after the last level); the ids are those of rq_forward bit for bit."""
+    _f32(y, "y")
+    if y.dim() != 2 or y.shape[1] != EMBED_DIM or not y.is_contiguous():
+        raise RuntimeError(f"rq_ids: expected contiguous [B,32] input, got {tuple(y.shape)}")
+    B = y.shape[0]
+    L, K, _ = cb_eff.shape
+    ids = torch.empty((B, L), device=y.device, dtype=torch.int64)
+    _check(lib().hidvae_rq_forward(_p(y), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, MODE_STE, 0, 0.0, None, _p(ids),
+                                   None, L * EMBED_DIM, None, None, None, _stream()), "hidvae_rq_forward")
+    return ids
 
 
 def bottleneck_eligible(B, K2, N2, Nd0, Nd1, L, K):

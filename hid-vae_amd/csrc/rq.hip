@@ -902,8 +902,14 @@ __device__ __forceinline__ void pf32_tile(const char *Ch, const char *Cl, const 
 // PIPE (needs NT > 0): two accumulator sets in ping-pong -- the MFMAs of tile t + 1 are issued one at a time between the scan
 // operations of tile t (a wave issues in order: behind a chain of dependent MFMAs it could not issue anything), so the matrix pipe
 // and the vector ALU work at the same time INSIDE a wave, not only across the waves of a SIMD.  16 more VGPRs: 8 waves per workgroup.
-template <int MODE, bool TRAIN, int NW, int NT, bool PIPE = false>  // NT: 32-code tiles per level when known at compile time (full unroll), else 0
+// IDS (the corpus tokenisation of HSemanticIdTokenizer.precompute_corpus_ids, reference h_semids.py:109-195: only the ids leave the
+// launch): eval-mode search with NO output but ids -- no z / emb_cat / emb_sum / res_cat / loss stores and none of their arithmetic,
+// no winner-row fetch after the last level (nothing consumes that residual), the next tile's input rows requested a whole tile
+// ahead (nothing but loads shares the in-order vmcnt queue now), and -- 16 fewer live registers per lane without the output rows --
+// more waves per SIMD to cover the one dependent fetch per level that is left.  Same scores, same confirmation: the same ids.
+template <int MODE, bool TRAIN, int NW, int NT, bool PIPE = false, bool IDS = false>  // NT: 32-code tiles per level when known at compile time (full unroll), else 0
 __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
+    static_assert(!IDS || !TRAIN, "the ids-only form is an eval-mode search");
     extern __shared__ __attribute__((aligned(16))) char pf_lds[];
     __shared__ unsigned ccmax_bits[HIDVAE_MAX_LEVELS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -917,22 +923,39 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
     const int sw = (n >> 2) & 3;
     const int off_p0 = n * 64 + (((2 * h) ^ sw) << 4), off_p1 = n * 64 + (((2 * h + 1) ^ sw) << 4);  // this lane's A-fragment chunks
     const int64_t ntiles = (a.B + TILE_ITEMS - 1) / TILE_ITEMS;
+    constexpr bool PREF = IDS && NW < 16;  // (at 16 waves = 128 registers per lane the 16 prefetch registers spill; four waves per SIMD
+                                           //  cover the tile's first load instead)
+    float rnext[16];  // IDS: the input rows of this workgroup's NEXT tile, in flight while the current one is searched
+    if (PREF && (int64_t)blockIdx.x < ntiles) {
+        const int64_t it0 = (int64_t)blockIdx.x * TILE_ITEMS + wave * 32 + n;
+        load16(a.y + (it0 < a.B ? it0 : a.B - 1) * D + 16 * h, rnext);
+    }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t item = tile * TILE_ITEMS + wave * 32 + n;
         const bool valid = item < a.B;
         const int64_t src = valid ? item : a.B - 1;
         float r[16];
-        load16(a.y + src * D + 16 * h, r);
+        if (PREF) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) r[j] = rnext[j];
+            const int64_t tn = tile + gridDim.x;
+            if (tn < ntiles) {
+                const int64_t itn = tn * TILE_ITEMS + wave * 32 + n;
+                load16(a.y + (itn < a.B ? itn : a.B - 1) * D + 16 * h, rnext);
+            }
+        } else {
+            load16(a.y + src * D + 16 * h, r);
+        }
         if (a.normalize_input) {
             const float den = fmaxf(sqrtf(dotH(r, r)), 1e-12f);
 #pragma unroll
             for (int j = 0; j < 16; j++) r[j] = r[j] / den;
         }
-        if (a.z != nullptr && valid) store16(a.z + item * D + 16 * h, r);
+        if (!IDS && a.z != nullptr && valid) store16(a.z + item * D + 16 * h, r);
         float loss = 0.0f;
         float esum[16];
         for (int i = 0; i < a.L; i++) {
-            if (a.res_cat != nullptr && valid) store16(a.res_cat + item * (a.L * D) + i * D + 16 * h, r);
+            if (!IDS && a.res_cat != nullptr && valid) store16(a.res_cat + item * (a.L * D) + i * D + 16 * h, r);
             const float xx = dotH(r, r);
             const char *Ch = pf_lds + i * lvl_bytes;
             const char *Cl = Ch + (size_t)a.KC * 64;
@@ -1018,6 +1041,16 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
             const bool undecided = !(best2 - best1 > delta);
             if (__ballot(undecided) != 0ull)
                 bidx = pf32_confirm<NT>(a, i, Ch, Cl, ccs, off_p0, off_p1, h, lane, r, xx, undecided ? best1 + delta : -INFINITY, idx1);
+            if (IDS) {
+                if (valid && h == 0) a.ids[item * a.L + i] = (int64_t)bidx;
+                if (i + 1 < a.L) {  // eval: o = e, the next level searches r - e (quantize.py:146-148, h_rqvae.py:552)
+                    float e[16];
+                    load16(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 16 * h, e);
+#pragma unroll
+                    for (int j = 0; j < 16; j++) r[j] = r[j] - e[j];
+                }
+                continue;
+            }
             float e[16];
             load16(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 16 * h, e);
             const float cce = a.cc[(int64_t)i * a.K + bidx];
@@ -1036,6 +1069,7 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
                 r[j] = r[j] - o[j];
             }
         }
+        if (IDS) continue;
         if (a.emb_sum != nullptr && valid) store16(a.emb_sum + item * D + 16 * h, esum);
         if (valid && a.qloss != nullptr && h == 0) a.qloss[item] = loss;
     }
@@ -1673,7 +1707,8 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     const bool prefilter_on = pf_env != 0;
     const int KCp = (int)(hv_cdiv(K, 32) * 32);
     const size_t pf32_bytes = pf32_level_bytes(KCp) * (size_t)L;
-    if (prefilter_on && pf_env != 16 && B >= (pf_env == 32 ? 256 * 256 : 128 * 1024) && pf32_bytes <= 152 * 1024) {
+    const bool ids_only = !training && !z && !emb_cat && !emb_sum && !res_cat && !qloss;  // eval, every output but ids NULL
+    if (prefilter_on && pf_env != 16 && B >= ((pf_env == 32 || ids_only) ? 256 * 256 : 128 * 1024) && pf32_bytes <= 152 * 1024) {
         FwdArgs p = a;
         p.KC = KCp;
         p.nchunks = 1;
@@ -1692,6 +1727,20 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf32_bytes); \
         hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * pnw), pf32_bytes, s, p);                                               \
     }
+        // ids only: the tokenizer's corpus pass
+        static const int ids_nw_env = getenv("HIDVAE_RQ_IDS_NW") ? atoi(getenv("HIDVAE_RQ_IDS_NW")) : 16;
+        if (ids_only && KCp == 256 && ids_nw_env != 0) {
+            const int inw = ids_nw_env == 8 ? 8 : (ids_nw_env == 12 ? 12 : 16);
+            const int64_t nti = hv_cdiv(B, 32 * inw);
+            const int igrid = (int)(nti < 256 ? nti : 256);
+            auto kern = inw == 8 ? rq_forward_pf32_kernel<HIDVAE_MODE_STE, false, 8, 8, true, true>
+                                 : (inw == 12 ? rq_forward_pf32_kernel<HIDVAE_MODE_STE, false, 12, 8, true, true>
+                                              : rq_forward_pf32_kernel<HIDVAE_MODE_STE, false, 16, 8, true, true>);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf32_bytes);
+            hipLaunchKernelGGL(kern, dim3(igrid), dim3(64 * inw), pf32_bytes, s, p);
+            HV_LAUNCH_CHECK("rq_forward ids-only");
+            return HIDVAE_OK;
+        }
         if (!training) HV_PF32(HIDVAE_MODE_STE, false)
         else if (mode == HIDVAE_MODE_STE) HV_PF32(HIDVAE_MODE_STE, true)
         else HV_PF32(HIDVAE_MODE_ROTATION, true)

@@ -330,6 +330,19 @@ class HRqVae(nn.Module, _HubMixin):
                             tag_align_loss_by_layer=by_layer[0], tag_pred_loss_by_layer=by_layer[1],
                             tag_pred_accuracy_by_layer=by_layer[2])
 
+    @torch.no_grad()
+    def semantic_ids_only(self, encoded_x: Tensor) -> Tensor:
+        """sem_ids [B, L] of get_semantic_ids(encoded_x) in eval mode and nothing else: the corpus pass of the tokenizer
+        (reference h_semids.py:109-195 keeps only `.sem_ids` of the level loop's output).  One launch that writes 8 L bytes per item."""
+        if self.training:
+            raise RuntimeError("semantic_ids_only is the eval-mode search (model.eval() first); training outputs differ (SURVEY Q6)")
+        y = encoded_x.float().contiguous()
+        self._maybe_kmeans(y, False)
+        if self.layers[0].sim_vq:
+            return self.get_semantic_ids(y).sem_ids
+        cb, cc = _C.codebook_prepare([t.detach() for t in self._tables()], self._normalize_flags())
+        return _C.rq_ids(y, cb, cc, False)
+
     # ------------------------------------------------------------------------------------------ the step
     def forward(self, batch, gumbel_t: float = 1.0) -> HRqVaeComputedLosses:
         x = batch.x.float().contiguous()

@@ -77,9 +77,9 @@ class HSemanticIdTokenizer(nn.Module):
     def _ids_for(self, feats: Tensor) -> Tensor:
         """feats [..., input_dim] -> ids [n_items, sem_ids_dim-ish] (semantic ids, plus tag ids in the combined modes)."""
         flat = feats.reshape(-1, feats.shape[-1]).to(self.hrq_vae.device)
-        sem = self.hrq_vae.get_semantic_ids(self.hrq_vae.encode(flat)).sem_ids
         if not (self.use_concatenated_ids or self.use_interleaved_ids):
-            return sem
+            return self.hrq_vae.semantic_ids_only(self.hrq_vae.encode(flat))  # only the ids leave the launch
+        sem = self.hrq_vae.get_semantic_ids(self.hrq_vae.encode(flat)).sem_ids
         tags = self.hrq_vae.predict_tags(flat)["predictions"]
         if tags.shape[0] != sem.shape[0]:
             raise ValueError(f"Semantic ID batch size ({sem.shape[0]}) does not match predicted tag batch size ({tags.shape[0]})")

@@ -51,6 +51,7 @@ def grad_sink(p):
         return None, False
     acc = bool(p._hv_written)
     p._hv_written = True
+    p._hv_nwrites = getattr(p, "_hv_nwrites", 0) + 1  # (FlatGradBuffer.check_first_bucket_untouched reads it)
     return v, acc
 
 

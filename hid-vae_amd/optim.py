@@ -174,7 +174,12 @@ class HidvaeAdamW(torch.optim.Optimizer):
                 gg["lr"] = self._lr_at(g["lr"], step + offset)
             gg["params"] = ids
             groups.append(gg)
-        return {"state": state, "param_groups": groups}
+        # (one extra top-level key, which torch.optim.Optimizer.load_state_dict ignores: where the LR schedule stands relative to Adam's
+        #  step count -- non-zero after a resume without optimizer state; dropping it rewound the schedule on the NEXT resume)
+        out = {"state": state, "param_groups": groups}
+        if offset:
+            out["hidvae_schedule_offset"] = offset
+        return out
 
     def load_state_dict(self, sd):
         """Accepts torch.optim.AdamW.state_dict() (written here or by the reference's torch optimizer) and the round-1 private
@@ -182,10 +187,27 @@ class HidvaeAdamW(torch.optim.Optimizer):
         the file), bias correction restarts from step 0 while the learning-rate schedule keeps its position (start_step)."""
         self.prepare()
         if "hidvae_m" in sd:
-            self._m.copy_(sd["hidvae_m"].to(self._m.device))
-            self._v.copy_(sd["hidvae_v"].to(self._v.device))
+            # private flat layout.  The moments in the file are laid out in the order recorded under "order" (indices into the
+            # parameters enumerated over the groups), or -- files written before the order was recorded (round 1) -- in group order.
+            # This optimizer's own flat order may differ (a data-parallel first bucket leads the buffer), so the moments are
+            # scattered parameter by parameter, never copied positionally.
+            mine = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+            order = sd.get("order")
+            src = list(range(len(mine))) if order is None else [int(i) for i in order]
+            numels = sd.get("numels") or [mine[i].numel() for i in src]
+            if sorted(src) != list(range(len(mine))) or [mine[i].numel() for i in src] != [int(n) for n in numels] \
+                    or sum(int(n) for n in numels) != sd["hidvae_m"].numel():
+                raise ValueError("hidvae flat optimizer state does not match this optimizer's parameters (count / sizes / order)")
+            slots = self._slots()
+            fm, fv = sd["hidvae_m"].reshape(-1), sd["hidvae_v"].reshape(-1)
+            off = 0
+            for i in src:
+                o, n = slots[id(mine[i])]
+                self._m[o:o + n].copy_(fm[off:off + n].to(self._m.device))
+                self._v[o:o + n].copy_(fv[off:off + n].to(self._v.device))
+                off += n
             self.step_dev[0] = int(sd["step"])
-            self.step_dev[1] = 0
+            self.step_dev[1] = int(sd.get("schedule_offset", 0))
             return True
         if "state" not in sd or "param_groups" not in sd:
             raise ValueError("optimizer state is neither a torch.optim.AdamW state_dict nor a hidvae flat state")
@@ -217,7 +239,7 @@ class HidvaeAdamW(torch.optim.Optimizer):
         prev = int(self.step_dev[0])
         if restored:
             self.step_dev[0] = max(steps)
-            self.step_dev[1] = 0
+            self.step_dev[1] = int(sd.get("hidvae_schedule_offset", 0))
         else:  # nothing to restore: a fresh Adam (bias correction from step 0) on a schedule that continues where the run was
             self.step_dev[0] = 0
             self.step_dev[1] = prev
@@ -249,7 +271,10 @@ class HidvaeAdamW(torch.optim.Optimizer):
     def flat_state(self):
         """round-1 private checkpoint payload, kept for files written then (load_state_dict reads both)"""
         self.prepare()
+        mine = {id(p): i for i, p in enumerate(p for g in self.param_groups for p in g["params"] if p.requires_grad)}
         return {"hidvae_m": self._m.detach().cpu(), "hidvae_v": self._v.detach().cpu(), "step": int(self.step_dev[0].item()),
+                "schedule_offset": int(self.step_dev[1].item()),
+                "order": [mine[id(p)] for p in self._params], "numels": [p.numel() for p in self._params],
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
                 "cosine": (self.T_max, self.eta_min), "step_lr": (self.step_size, self.gamma)}
 

@@ -47,14 +47,28 @@ class FlatGradBuffer:
             p._hv_written = False
         self._sealed = False
         self._sealed_upto = 0
+        self._first_marks = None
 
     @torch.no_grad()
     def seal(self, upto=None):
         """complete the buffer; upto = n: only the first n parameters (the first bucket of an overlapped exchange) -- the rest is
         sealed by a later call"""
+        if getattr(self, "_first_marks", None):
+            self.check_first_bucket_untouched()  # (also hands the first bucket's .grad back)
         if self._sealed:
             return
         n = len(self.params) if upto is None else upto
+        if upto is not None and upto < len(self.params):
+            # first bucket of an overlapped exchange: it goes on the wire NOW, so every slot in it must already hold its final gradient.
+            # A slot nobody produced means the backward took another path than the one the bucket was chosen for (HRqVae.dp_first_bucket
+            # for another batch size / fuse_bottleneck setting): zero-filling it here and letting part 2 accumulate into it would race
+            # with the collective and silently lose that gradient.
+            missing = [i for i in range(self._sealed_upto, n) if not self.params[i]._hv_written and self.params[i].grad is None]
+            if missing:
+                raise RuntimeError(f"FlatGradBuffer.seal(upto={upto}): first-bucket slots {missing} were not produced by the first half of the "
+                                   "split backward -- the bucket was chosen for a different forward path (batch size / fuse_bottleneck changed "
+                                   "since HRqVae.dp_first_bucket); rebuild the optimizer's first_bucket or step without overlap")
+            self._pending_marks = n
         for i in range(self._sealed_upto, n):
             p, v = self.params[i], self.views[i]
             if p._hv_written:
@@ -68,6 +82,25 @@ class FlatGradBuffer:
             p._hv_written = True  # a further backward before the next zero() accumulates
         self._sealed_upto = max(self._sealed_upto, n)
         self._sealed = self._sealed_upto == len(self.params)
+        if getattr(self, "_pending_marks", None):
+            # kernel writes through the C ABI are counted by ops.grad_sink; for autograd's own accumulation the first bucket's .grad is
+            # taken away for the duration of the second half (a gradient that appears there is a late producer)
+            self._first_marks = [(i, getattr(self.params[i], "_hv_nwrites", 0)) for i in range(self._pending_marks)]
+            for i, _ in self._first_marks:
+                self.params[i].grad = None
+            self._pending_marks = None
+
+    def check_first_bucket_untouched(self):
+        """after the second half of a split backward: nothing may have written a first-bucket slot since seal(upto) -- its all-reduce
+        is (or was) in flight on those bytes"""
+        for i, nwr in getattr(self, "_first_marks", None) or []:
+            p = self.params[i]
+            late = getattr(p, "_hv_nwrites", 0) != nwr or p.grad is not None
+            p.grad = self.views[i]
+            if late:
+                raise RuntimeError(f"FlatGradBuffer: first-bucket slot {i} was written during the second half of the split backward, while its "
+                                   "all-reduce was in flight (the first bucket does not match the path the forward took)")
+        self._first_marks = None
 
     def numel_of_first(self, n):
         return sum(p.numel() for p in self.params[:n])
@@ -87,6 +120,13 @@ class DataParallel:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.always = False  # rehearsal switch: issue the collective even in a one-rank group (bench.py --dist 1)
+
+    def capturable(self):
+        """may the gradient exchange be captured into a HIP graph?  RCCL collectives are stream operations (yes); gloo's run on the
+        host (no).  A one-rank group that issues no collective at all (`always` unset) has nothing to capture."""
+        if not dist.is_initialized() or (self.world == 1 and not self.always):
+            return False
+        return dist.get_backend(self.group) == "nccl"
 
     def broadcast_parameters(self, src=0):
         """DDP-style start: every replica takes rank `src`'s parameters and buffers."""

@@ -6,16 +6,22 @@ microseconds long.  Issued one by one from Python the step is host-bound (0.80 m
 once and replayed it is 0.28 / 2.3 ms.  Nothing in the step synchronises with the host (losses, the mixup weight, the AdamW step
 counter and the learning-rate schedule live on the device), which is what makes the capture legal.
 
-Data parallel: collectives stay outside the graphs.  The backward is split in two at the inputs of the decoder's tail and of the
-loss launch (HRqVae.dp_cut), and the flat gradient buffer leads with the parameters the first half completes, so the exchange
-overlaps the rest of the backward:
+Data parallel.  Over RCCL (backend "nccl") the gradient all-reduce is captured INSIDE the step's graph -- RCCL collectives are
+graph nodes like any kernel -- so a data-parallel step is still ONE graph launch per optimizer step:
 
-    graph[zero_grad, forward, backward part 1]  ->  all-reduce(bucket 1) on RCCL's stream  ||  graph[backward part 2]
-                                                ->  all-reduce(bucket 2)  ->  graph[AdamW]
+    graph[zero_grad, forward, backward, all-reduce(flat gradients), AdamW]
 
-(DDP gives the reference the same thing by bucketing gradients in reverse registration order, train_hidvae.py:630-632,709.)  With
-gradient accumulation, or an optimizer built without a first bucket, the exchange is ONE all-reduce between graph[forward, backward]
-and graph[AdamW]."""
+(round 2 kept the collective between two graphs: a second graph launch and two host-side enqueues per step, 45 us of fixed cost on
+a 232 us step).  With a first bucket (HRqVae.dp_cut: the backward is split in two at the inputs of the decoder's tail and of the
+loss launch, and the flat gradient buffer leads with the parameters the first half completes) the exchange overlaps the rest of
+the backward, inside the same graph:
+
+    graph[zero_grad, forward, backward part 1, all-reduce(bucket 1) on RCCL's stream || backward part 2, all-reduce(bucket 2), AdamW]
+
+(DDP gives the reference the same thing by bucketing gradients in reverse registration order, train_hidvae.py:630-632,709.)
+Backends whose collectives run on the host (gloo: CPU tests, several ranks on one GPU) cannot be captured; there the collectives
+stay between graphs as before: graph[fwd, bwd part 1] -> all-reduce || graph[bwd part 2] -> all-reduce -> graph[AdamW], or
+graph[fwd, bwd] -> all-reduce -> graph[AdamW].  HIDVAE_DP_GRAPH_COLLECTIVES=0/1 overrides the choice."""
 import os
 import types
 
@@ -45,8 +51,10 @@ class GraphedTrainStep:
         # overlap: None = by size.  Measured with one rank (bench.py --dist 1): the split costs ~50 us of fixed latency per step (a third
         # graph launch, a second collective, two more cross-stream edges): 0.330 vs 0.277 ms on the 4.6 MB core model, where a whole
         # 8-GPU all-reduce is of that order itself; on the 29 MB tagged model (1.94 vs 2.02 ms) it pays.  Hence: from 16 MB on.
+        # PROVISIONAL: the threshold comes from one-rank runs where the collective moves no data; no N > 1 hardware measurement exists yet
         self.overlap = overlap
         self.graphs = None
+        self.in_graph = False  # True once the collectives were captured inside the (single) step graph
 
     # -- the step, as plain code (this is what gets captured)
     def _overlapped(self):
@@ -86,6 +94,7 @@ class GraphedTrainStep:
 
     def _part2(self):  # the rest of the backward
         self.model.backward_rest()
+        self.opt.grad_buffer.check_first_bucket_untouched()
         self.opt.grad_buffer.seal()
 
     def _exchange_overlapped(self, run1, run2):
@@ -100,6 +109,15 @@ class GraphedTrainStep:
                 w.wait()                               # (stream-side wait: the host does not block)
         return 1.0 / self.dp.world
 
+    def _collectives_capturable(self):
+        """RCCL collectives are stream operations and can be captured; host-side backends (gloo) cannot"""
+        if self.dp is None:
+            return False
+        env = os.environ.get("HIDVAE_DP_GRAPH_COLLECTIVES")
+        if env is not None:
+            return env == "1"
+        return self.dp.capturable()
+
     def _eager(self):
         if self._overlapped():
             self.opt.grad_scale = self._exchange_overlapped(self._part1, self._part2)
@@ -111,7 +129,13 @@ class GraphedTrainStep:
         self.opt.step()
 
     def _capture(self):
-        if self._overlapped():
+        if self.dp is not None and self._collectives_capturable():
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._eager()  # the collectives become nodes of the graph (they fork to RCCL's stream and join back)
+            self.graphs = (g1,)
+            self.in_graph = True
+        elif self._overlapped():
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self._part1()

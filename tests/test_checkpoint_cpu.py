@@ -94,6 +94,52 @@ def test_resume_without_optimizer_state_restarts_bias_correction_but_not_the_sch
         opt.load_state_dict({"state": {}, "param_groups": [{"params": [0]}]})
 
 
+def test_flat_state_round_trips_into_an_optimizer_with_a_first_bucket():
+    """the flat moment layout leads with the data-parallel first bucket, so a flat state must be scattered parameter by
+    parameter (positional copies put Adam moments on the wrong parameters; sizes match, nothing raised)"""
+    m = mirror_model()
+    opt = HidvaeAdamW(groups_of(m), cosine=(1000, 1e-6)).prepare()
+    opt._m.copy_(torch.arange(opt._m.numel(), dtype=torch.float32))
+    opt._v.copy_(torch.arange(opt._v.numel(), dtype=torch.float32) * 2)
+    opt.step_dev[0] = 9
+    per_param = {id(p): opt._m[o:o + n].clone() for p, (o, n) in ((p, opt._slots()[id(p)]) for p in opt._params)}
+    # same model object, another optimizer whose flat order leads with the decoder's last two layers
+    first = list(m.decoder.parameters())[-2:]
+    opt2 = HidvaeAdamW(groups_of(m), cosine=(1000, 1e-6), first_bucket=first).prepare()
+    assert opt2.n_first == 2 and opt2._params[0] is first[0] and opt2._params[0] is not opt._params[0]
+    fs = opt.flat_state()
+    assert opt2.load_state_dict(fs) is True
+    for p in opt2._params:
+        o, n = opt2._slots()[id(p)]
+        assert torch.equal(opt2._m[o:o + n], per_param[id(p)]), "moment landed on another parameter"
+    # and back: a state written WITH a first bucket loads into a plain optimizer
+    opt3 = HidvaeAdamW(groups_of(m), cosine=(1000, 1e-6)).prepare()
+    assert opt3.load_state_dict(opt2.flat_state()) is True and torch.equal(opt3._m, opt._m) and torch.equal(opt3._v, opt._v)
+    # a round-1 file (no order recorded) is in group order
+    legacy = {k: v for k, v in fs.items() if k not in ("order", "numels", "schedule_offset")}
+    opt4 = HidvaeAdamW(groups_of(m), cosine=(1000, 1e-6), first_bucket=first).prepare()
+    assert opt4.load_state_dict(legacy) is True
+    for p in opt4._params:
+        o, n = opt4._slots()[id(p)]
+        assert torch.equal(opt4._m[o:o + n], per_param[id(p)])
+    bad = dict(fs, numels=[1] + fs["numels"][1:])
+    with pytest.raises(ValueError):
+        opt4.load_state_dict(bad)
+
+
+def test_resuming_twice_keeps_the_schedule_position():
+    """state_dict() dropped the schedule offset of a run resumed without optimizer state"""
+    opt = HidvaeAdamW(groups_of(mirror_model()), cosine=(1000, 1e-6)).prepare()
+    opt.restart_without_state(500)
+    opt.step_dev[0] = 3  # three optimizer steps after the restart
+    opt._m.fill_(0.5)
+    sd = opt.state_dict()
+    opt2 = HidvaeAdamW(groups_of(mirror_model()), cosine=(1000, 1e-6)).prepare()
+    assert opt2.load_state_dict(sd) is True
+    assert opt2.step_dev.tolist() == [3, 500] and abs(opt2.current_lr() - opt.current_lr()) < 1e-12
+    torch.optim.AdamW(groups_of(mirror_model())).load_state_dict(sd)  # the extra key does not disturb torch's own loader
+
+
 REFERENCE_SIDE = r'''
 import sys, types, json
 sys.path.insert(0, "/root/reference")

@@ -187,3 +187,46 @@ def test_state_dict_contract_matches_the_reference():
     assert len(got) == len(want["entries"]) == 146
     assert got == want["entries"]
     assert sum(p.numel() for p in m.parameters()) == want["n_parameters"] == 7244236
+
+
+def test_flat_grad_buffer_first_bucket_is_self_checking():
+    """a first bucket that the first half of a split backward did not complete must raise, not be zero-filled; and a write
+    into the first bucket during the second half (while its all-reduce is in flight) must raise as well"""
+    import pytest
+    import torch
+    from hidvae_amd.ops import grad_sink
+    from hidvae_amd.parallel import FlatGradBuffer
+    ps = [torch.nn.Parameter(torch.zeros(4)) for _ in range(3)]
+    buf = FlatGradBuffer(ps)
+    # (a) slot 1 of the first bucket not produced
+    buf.zero()
+    dst, acc = grad_sink(ps[0])
+    dst.fill_(1.0)
+    with pytest.raises(RuntimeError, match="were not produced"):
+        buf.seal(upto=2)
+    # (b) a kernel-style late write into the first bucket
+    buf.zero()
+    for p in ps[:2]:
+        grad_sink(p)[0].fill_(2.0)
+    buf.seal(upto=2)
+    grad_sink(ps[1])
+    with pytest.raises(RuntimeError, match="second half"):
+        buf.check_first_bucket_untouched()
+    # (c) an autograd-style late gradient for a first-bucket parameter
+    buf.zero()
+    for p in ps[:2]:
+        grad_sink(p)[0].fill_(2.0)
+    buf.seal(upto=2)
+    ps[0].grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="second half"):
+        buf.seal()
+    # (d) the good path: the bucket is left alone, the rest arrives, everything ends up as views of the flat buffer
+    buf.zero()
+    for p in ps[:2]:
+        grad_sink(p)[0].fill_(3.0)
+    buf.seal(upto=2)
+    ps[2].grad = torch.full((4,), 5.0)
+    buf.check_first_bucket_untouched()
+    buf.seal()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(ps, buf.views))
+    assert buf.flat.tolist() == [3.0] * 8 + [5.0] * 4

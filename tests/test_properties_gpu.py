@@ -194,6 +194,35 @@ def test_prefilter_kernel_is_bit_identical_to_the_exact_kernel(C, mode, training
         assert torch.equal(big[j], want), (kind, name, int((big[j] != want).sum()))
 
 
+@pytest.mark.parametrize("kind", ["spread", "near_duplicates", "exact_duplicates", "tiny_residuals"])
+@pytest.mark.parametrize("N,K", [(70000, 256), (270001, 256), (1000, 256), (66000, 96)])
+def test_ids_only_launch_gives_the_ids_of_the_full_eval_launch(C, kind, N, K):
+    """hidvae_rq_forward with every output but `ids` NULL (the tokenizer's corpus pass) takes, from 65536 items and K = 256 on, the
+    ids-only form of the prefilter kernel: no output rows, no winner fetch after the last level, 16 waves per workgroup.  Its ids
+    must be those of the full eval-mode launch (pieces below 65536 items: the exact fp32 kernel) bit for bit, ambiguous items
+    (duplicate / near-duplicate codes) and collapsing residual norms included; other sizes take the ordinary kernels with NULL
+    outputs."""
+    L = 3
+    g = torch.Generator(device="cuda").manual_seed(19)
+    tabs = tables(L, K, 83)
+    if kind == "near_duplicates":
+        for t in tabs:
+            t[K // 2:] = t[:K // 2] * (1.0 + 1e-6 * torch.randn(K // 2, 1, device="cuda", generator=g))
+    elif kind == "exact_duplicates":
+        for t in tabs:
+            t[K // 2:] = t[:K // 2]
+    elif kind == "tiny_residuals":
+        tabs[1] = tabs[1] * 50.0
+        tabs[2] = tabs[2] * 1e-4
+    y = torch.randn(N, 32, device="cuda", generator=g)
+    cb, cc = C.codebook_prepare(tabs, [True, False, False])
+    for normalize in (True, False):
+        got = C.rq_ids(y, cb, cc, normalize)
+        cuts = list(range(0, N, 60000)) + [N]
+        want = torch.cat([C.rq_forward(y[lo:hi].contiguous(), cb, cc, normalize, 2, False, 0.4)[1] for lo, hi in zip(cuts[:-1], cuts[1:])], 0)
+        assert torch.equal(got, want), (kind, normalize, int((got != want).sum()))
+
+
 def test_mixup_plan_kernel_properties(C):
     """hidvae_mixup_plan (one launch for the pairings and lambdas of all levels): partner is a permutation of the valid rows among
     themselves with the matching inverse, -1 on invalid rows, for ragged / maximal / single-row shapes; over many draws lam has the
