@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
+import hidvae_amd  # noqa: E402,F401  (before the first HIP call of the process: it sets the graph-queue default the runtime reads at init)
 
 AMAZON = dict(commitment_weight=0.4, tag_alignment_weight=0.15, tag_prediction_weight=0.55, tag_class_counts=[38, 168, 348],
               use_focal_loss=True, focal_loss_params={"gamma_0": 2.7, "alpha_0": 0.24, "gamma_1": 2.7, "alpha_1": 0.24,

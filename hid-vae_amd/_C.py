@@ -26,7 +26,7 @@ _SIGNATURES = {
     "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _i, _vp, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
-    "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "hidvae_bottleneck_fwd": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp,
                               _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _vp],
@@ -83,7 +83,7 @@ _SIGNATURES = {
     "hidvae_layernorm_bwd_all_group": [_vp, _i, _vp],
 }
 WS_GEMM, WS_LINEAR_BWD, WS_COLSUM, WS_CODEBOOK_GRAD, WS_LAYERNORM_PARAM_GRAD, WS_LAYERNORM_BWD_ALL = 1, 2, 3, 4, 5, 6
-WS_BATCHNORM_FWD, WS_BATCHNORM_BWD, WS_ID_CENSUS, WS_KMEANS, WS_TAG_LOSS, WS_LINEAR_BWD_ZEROED = 7, 8, 9, 10, 11, 12
+WS_BATCHNORM_FWD, WS_BATCHNORM_BWD, WS_ID_CENSUS, WS_KMEANS, WS_TAG_LOSS, WS_LINEAR_BWD_ZEROED, WS_RQ_FORWARD = 7, 8, 9, 10, 11, 12, 13
 
 
 class LaunchStamps:
@@ -487,9 +487,10 @@ def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=Fa
     emb_sum = torch.empty((B, EMBED_DIM), device=dev, dtype=torch.float32)
     res = torch.empty((B, L * EMBED_DIM), device=dev, dtype=torch.float32) if want_res else None
     qloss = torch.empty((B,), device=dev, dtype=torch.float32)
+    ws = _ws(WS_RQ_FORWARD, dev, B, L, K)
     _check(lib().hidvae_rq_forward(_p(y), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, int(mode), int(bool(training)),
                                    float(beta), _p(z), _p(ids), _p(emb_cat), L * EMBED_DIM, _p(emb_sum), _p(res), _p(qloss),
-                                   _stream()), "hidvae_rq_forward")
+                                   _p(ws), _stream()), "hidvae_rq_forward")
     return z if z is not None else y, ids, emb_cat, emb_sum, res, qloss
 
 
@@ -503,8 +504,9 @@ def rq_ids(y, cb_eff, cc, normalize_input=False):
     B = y.shape[0]
     L, K, _ = cb_eff.shape
     ids = torch.empty((B, L), device=y.device, dtype=torch.int64)
+    ws = _ws(WS_RQ_FORWARD, y.device, B, L, K)
     _check(lib().hidvae_rq_forward(_p(y), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, MODE_STE, 0, 0.0, None, _p(ids),
-                                   None, L * EMBED_DIM, None, None, None, _stream()), "hidvae_rq_forward")
+                                   None, L * EMBED_DIM, None, None, None, _p(ws), _stream()), "hidvae_rq_forward")
     return ids
 
 

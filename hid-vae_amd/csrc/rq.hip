@@ -160,6 +160,13 @@ struct FwdArgs {
     unsigned long long *census;   // id-tuple census table (census_size slots + 3 control words), see bottleneck_fwd_kernel
     int64_t census_size;
     float *p_unique;
+    // prefilter kernels: items whose approximate search is too close to call are appended here (and get a tentative result); the exact
+    // kernel then runs over exactly those items and overwrites every output of theirs (hidvae_rq_forward, "deferred confirmation")
+    int *fix_list;                // [>= B] item numbers
+    unsigned *fix_count;          // number of entries (zeroed before the prefilter launch)
+    // exact kernels: when `list` is set, the launch processes items list[0 .. *list_count) instead of 0 .. B
+    const int *list;
+    const unsigned *list_count;
 };
 
 // stage codes [c0, c0+KC) of level `lvl` into LDS, d-major: Cs[d][KC+2], then |c|^2 (padding: 0 / +inf)
@@ -404,12 +411,15 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
     static_assert(!CSPLIT || NW == 4, "the code-split variant merges four quarter searches");
     constexpr int TILE_ITEMS = CSPLIT ? ITEMS_PER_WAVE : ITEMS_PER_WAVE * NW;
     int phase = 0;  // running level count across tiles: candidate buffers alternate, one barrier per level suffices
-    const int64_t ntiles = (a.B + TILE_ITEMS - 1) / TILE_ITEMS;
+    const int64_t nB = a.list != nullptr ? (int64_t)*a.list_count : a.B;  // (a listed launch: the items the prefilter could not decide)
+    const int64_t ntiles = (nB + TILE_ITEMS - 1) / TILE_ITEMS;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t item = tile * TILE_ITEMS + (CSPLIT ? 0 : wave * ITEMS_PER_WAVE) + it;
-        const bool in_range = item < a.B;
+        const int64_t pos = tile * TILE_ITEMS + (CSPLIT ? 0 : wave * ITEMS_PER_WAVE) + it;
+        const bool in_range = pos < nB;
         const bool valid = in_range && (!CSPLIT || wave == 0);  // stores: every item once
-        const int64_t src = in_range ? item : a.B - 1;
+        const int64_t spos = in_range ? pos : nB - 1;
+        const int64_t item = a.list != nullptr ? (int64_t)a.list[spos] : pos;
+        const int64_t src = a.list != nullptr ? item : spos;
         float r[8];
         load8(a.y + src * D + 8 * q, r);
         if (a.normalize_input) {  // F.normalize(eps=1e-12), modules/encoder.py:32
@@ -430,20 +440,21 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_kernel(FwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Large batches: split-bf16 PREFILTER + exact confirmation.  The exact search above spends 8 fp32 MFMAs (256 cycles) per
+// Large batches: split-bf16 PREFILTER + deferred exact confirmation.  The exact search above spends 8 fp32 MFMAs (256 cycles) per
 // 16 codes x 16 items; here every code row and every residual is split into two bf16 numbers (x = hi + lo + O(2^-18 |x|)) and the
-// three products hi.hi + hi.lo + lo.hi run on v_mfma_f32_16x16x32_bf16 (3 x 16 cycles for the same tile).  The approximate score
-// s_k = |c_k|^2 - 2 dot~ differs from the exact fp32 distance (minus |x|^2) by less than
+// three products hi.hi + hi.lo + lo.hi run on bf16 MFMA.  The approximate score s_k = |c_k|^2 - 2 dot~ differs from the exact fp32
+// distance (minus |x|^2) by less than
 //     e = 2 (3 * 2^-18 + 128 * 2^-24) |x||c_k| + 2^-21 (|x|^2 + |c_k|^2)  <  2^-15 (|x|^2 + max_k |c_k|^2),
 // so if the runner-up's score exceeds the best by more than DELTA = 2^-14 (|x|^2 + max|c|^2), the approximate argmin IS the
 // exact argmin (the exact winner k* has s_k* <= d_k* + e <= d_j + e <= s_j + 2e for every j).  Each lane keeps the smallest and the
-// second smallest score it has seen (one v_med3 on top of the running minimum); an item whose two best scores are closer than DELTA is
-// re-searched exactly (the fp32 MFMA chain of rq_level_loop, codes read from global memory instead of LDS) -- wave-uniformly,
-// i.e. for the 16 items of that wave; ~0.1 % of item-levels on codebook-like data.  Everything after the argmin (winner row,
-// rotation, loss, residual) is the exact fp32 code, so ids and every float are bit-identical to rq_forward_kernel.
+// second smallest score it has seen (one v_med3 on top of the running minimum).  An item with a level whose two best scores are
+// closer than DELTA is UNDECIDED: the prefilter launch carries on with the approximate winner, appends the item to a list, and the
+// exact kernel (rq_forward_kernel over that list, ~1 % of the items on codebook-like data) recomputes and overwrites every output of
+// the listed items afterwards.  Everything after the argmin (winner row, rotation, loss, residual) is the exact fp32 code, so ids
+// and every float are bit-identical to rq_forward_kernel.  (Rounds 1-2 confirmed inside the prefilter launch: a wave with one
+// undecided item re-scanned the level -- 9 % of the 32-item waves, 20 % of the launch's time and 40 registers per lane.)
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-constexpr int PF_ROW = 40;  // bf16 per LDS code row: 32 + 8 padding (80 B: conflict-free 128-bit fragment reads)
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {  // round-to-nearest-even: v_cvt_pk_bf16_f32 on gfx950
     const __bf16 h = (__bf16)x;
@@ -454,197 +465,25 @@ __device__ __forceinline__ void split_bf16(float x, unsigned &hi, unsigned &lo) 
     lo = bf16_rne(x - __uint_as_float(hi << 16));
 }
 
-__host__ __device__ __forceinline__ size_t pf_level_bytes(int KC) { return (size_t)KC * (2 * PF_ROW * 2 + 4); }
-
-// stage level `lvl`: hi / lo bf16 images [KC][PF_ROW], |c|^2 [KC] (padding codes: zeros / +inf), and max |c|^2 into *ccmax_bits
-__device__ __forceinline__ void pf_stage(char *base, const FwdArgs &a, int lvl, unsigned *ccmax_bits) {
-    unsigned short *Ch = reinterpret_cast<unsigned short *>(base);
-    unsigned short *Cl = Ch + (size_t)a.KC * PF_ROW;
-    float *ccs = reinterpret_cast<float *>(Cl + (size_t)a.KC * PF_ROW);
-    const float *src = a.cb_eff + (int64_t)lvl * a.K * D;
-    for (int idx = threadIdx.x; idx < a.KC * 8; idx += blockDim.x) {
-        const int kl = idx >> 3, d4 = idx & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kl < a.K) v = *reinterpret_cast<const float4 *>(src + (int64_t)kl * D + 4 * d4);
-        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-        split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
-        *reinterpret_cast<uint2 *>(Ch + kl * PF_ROW + 4 * d4) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-        *reinterpret_cast<uint2 *>(Cl + kl * PF_ROW + 4 * d4) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
-    }
-    float mx = 0.0f;
-    for (int kl = threadIdx.x; kl < a.KC; kl += blockDim.x) {
-        const float c = kl < a.K ? a.cc[(int64_t)lvl * a.K + kl] : INFINITY;
-        ccs[kl] = c;
-        if (kl < a.K) mx = fmaxf(mx, c);
-    }
-    atomicMax(ccmax_bits, __float_as_uint(mx));  // |c|^2 >= 0: the bit patterns order like the values
-}
-
-template <int MODE, bool TRAIN, int NW>
-__global__ __launch_bounds__(64 * NW) void rq_forward_prefilter_kernel(FwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char pf_lds[];
-    __shared__ unsigned ccmax_bits[HIDVAE_MAX_LEVELS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int it = lane & 15, q = lane >> 4;
-    const size_t lvl_bytes = pf_level_bytes(a.KC);
-    if (threadIdx.x < HIDVAE_MAX_LEVELS) ccmax_bits[threadIdx.x] = 0u;
-    __syncthreads();
-    for (int i = 0; i < a.L; i++) pf_stage(pf_lds + i * lvl_bytes, a, i, &ccmax_bits[i]);
-    __syncthreads();
-    constexpr int TILE_ITEMS = ITEMS_PER_WAVE * NW;
-    const int64_t ntiles = (a.B + TILE_ITEMS - 1) / TILE_ITEMS;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t item = tile * TILE_ITEMS + wave * ITEMS_PER_WAVE + it;
-        const bool valid = item < a.B;
-        const int64_t src = valid ? item : a.B - 1;
-        float r[8];
-        load8(a.y + src * D + 8 * q, r);
-        if (a.normalize_input) {
-            const float den = fmaxf(sqrtf(dotQ(r, r)), 1e-12f);
-#pragma unroll
-            for (int j = 0; j < 8; j++) r[j] = r[j] / den;
-        }
-        if (a.z != nullptr && valid) store8(a.z + item * D + 8 * q, r);
-        float loss = 0.0f;
-        float esum[8];
-        for (int i = 0; i < a.L; i++) {
-            if (a.res_cat != nullptr && valid) store8(a.res_cat + item * (a.L * D) + i * D + 8 * q, r);
-            const float xx = dotQ(r, r);
-            const char *base = pf_lds + i * lvl_bytes;
-            const unsigned short *Ch = reinterpret_cast<const unsigned short *>(base);
-            const unsigned short *Cl = Ch + (size_t)a.KC * PF_ROW;
-            const float *ccs = reinterpret_cast<const float *>(Cl + (size_t)a.KC * PF_ROW);
-            // the residual as two bf16 B fragments (k = 8q + j: exactly the dims this lane holds)
-            unsigned hw[8], lw[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) split_bf16(r[j], hw[j], lw[j]);
-            const uint4 bhu = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
-            const uint4 blu = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
-            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bhu), bl = __builtin_bit_cast(bf16x8_t, blu);
-            float best1 = INFINITY, best2 = INFINITY;
-            int idx1 = 0;
-            const unsigned short *ah_row = Ch + it * PF_ROW + 8 * q, *al_row = Cl + it * PF_ROW + 8 * q;
-            for (int t = 0; t < a.KC; t += 32) {  // two independent 16-code tiles per iteration
-                const bf16x8_t ah0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(ah_row + t * PF_ROW));
-                const bf16x8_t al0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(al_row + t * PF_ROW));
-                const bf16x8_t ah1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(ah_row + (t + 16) * PF_ROW));
-                const bf16x8_t al1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(al_row + (t + 16) * PF_ROW));
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bh, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bh, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bl, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bl, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bh, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bh, acc1, 0, 0, 0);
-                const float4 c0 = *reinterpret_cast<const float4 *>(ccs + t + 4 * q);
-                const float4 c1 = *reinterpret_cast<const float4 *>(ccs + t + 16 + 4 * q);
-                const float cc0[4] = {c0.x, c0.y, c0.z, c0.w};
-                const float cc1[4] = {c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const float s0 = fmaf(-2.0f, acc0[g], cc0[g]);
-                    best2 = __builtin_amdgcn_fmed3f(best1, best2, s0);
-                    if (s0 < best1) { best1 = s0; idx1 = t + 4 * q + g; }
-                }
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const float s1 = fmaf(-2.0f, acc1[g], cc1[g]);
-                    best2 = __builtin_amdgcn_fmed3f(best1, best2, s1);
-                    if (s1 < best1) { best1 = s1; idx1 = t + 16 + 4 * q + g; }
-                }
-            }
-            // (packing the code number into the scores' low mantissa bits -- one v_max + one v_med3 per score -- was tried: 4 %
-            //  slower; the loop is bound by latencies, not by VALU issue)
-            // merge the item's 4 quarter-lanes: smallest (lowest index on ties) and second smallest of the union
-#pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
-                const float o1 = __shfl_xor(best1, o), o2 = __shfl_xor(best2, o);
-                const int oi = __shfl_xor(idx1, o);
-                best2 = fminf(fmaxf(best1, o1), fminf(best2, o2));
-                if (o1 < best1 || (o1 == best1 && oi < idx1)) { best1 = o1; idx1 = oi; }
-            }
-            const float delta = 6.103515625e-05f * (xx + __uint_as_float(ccmax_bits[i]));  // 2^-14 (|x|^2 + max |c|^2)
-            int bidx = idx1;
-            if (__ballot(!(best2 - best1 > delta)) != 0ull) {  // some item of this wave is too close to call: exact search
-                float best = INFINITY;
-                bidx = 0;
-                const float *cbl = a.cb_eff + (int64_t)i * a.K * D;
-                const float *ccl = a.cc + (int64_t)i * a.K;
-                for (int t = 0; t < a.KC; t += 16) {
-                    float av[8];
-                    if (t + it < a.K) load8(cbl + (int64_t)(t + it) * D + 8 * q, av);
-                    else {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) av[j] = 0.0f;
-                    }
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], r[j], acc, 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const int k = t + 4 * q + g;
-                        const float cck = k < a.K ? ccl[k] : INFINITY;
-                        const float d0 = fmaf(-2.0f, acc[g], xx + cck);
-                        if (d0 < best) { best = d0; bidx = k; }
-                    }
-                }
-#pragma unroll
-                for (int o = 16; o <= 32; o <<= 1) {
-                    const float ob = __shfl_xor(best, o);
-                    const int oi = __shfl_xor(bidx, o);
-                    if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-                }
-            }
-            float e[8];
-            load8(a.cb_eff + ((int64_t)i * a.K + bidx) * D + 8 * q, e);
-            const float cce = a.cc[(int64_t)i * a.K + bidx];
-            float o[8], u[8], qv[8], w[8];
-            level_output<MODE, TRAIN>(r, e, xx, cce, o, u, qv, w);
-            float df[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) df[j] = r[j] - e[j];
-            const float l1 = dotQ(df, df);
-            loss = loss + (l1 + a.beta * l1);
-            if (valid) {
-                if (q == 0) a.ids[item * a.L + i] = (int64_t)bidx;
-                if (a.emb_cat != nullptr) store8(a.emb_cat + item * a.ld_cat + i * D + 8 * q, o);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                esum[j] = (i == 0) ? o[j] : esum[j] + o[j];
-                r[j] = r[j] - o[j];
-            }
-        }
-        if (valid) {
-            if (a.emb_sum != nullptr) store8(a.emb_sum + item * D + 8 * q, esum);
-            if (a.qloss != nullptr && q == 0) a.qloss[item] = loss;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Corpus-sized batches (B >= 131072): the same split-bf16 prefilter on v_mfma_f32_32x32x16_bf16, 32 items per wave.
-// The 16-item kernel above is bound by vector-instruction issue, not by the matrix pipe (rocprofv3 at 1M items: SQ_ACTIVE_INST_ANY
-// = 70 % of the SIMD issue slots, MFMA busy 16 %): per score it spends an fma, a compare, two selects and a med3, its MFMAs hold the
-// issue port for 8 cycles per 256 scores, and the per-level scalar work (square roots, divisions, cross-lane sums) is replicated on
-// the 4 lanes that share an item.  Here
+// The prefilter kernel (B >= 65536): v_mfma_f32_32x32x16_bf16, 32 items per wave.
 //   * lane = (n = lane & 31, h = lane >> 5) holds dims [16h, 16h+16) of item n: two lanes per item, one cross-lane step per reduction
 //     (p0+p1 | p2+p3 are in-lane, then one v_permlane32_swap: the same (p0+p1)+(p2+p3) as everywhere else, bit for bit);
 //   * the LDS images hold bf16 hi/lo of -2c and the accumulators start from |c|^2, so a score IS the accumulator (no fma);
 //   * the lane's running best carries its accumulator number j in the 4 low mantissa bits (one v_and_or per score, |error| < 2^-19 |s|,
 //     inside the slack of DELTA), the 32-code tile is tracked by one compare per 16 scores: per score and_or + med3 + min;
-//   * one 32x32x16 MFMA yields 1024 partial scores per 8 issue cycles (16x16x32: 256);
-//   * an undecided item does not send its wave through all K codes again: pf32_confirm re-scans the scores for the codes within DELTA
-//     of the best (usually two) and gives only those the exact fp32 distance (the full re-search cost 100 of 550 us on random data,
-//     where ~0.3 % of item-levels -- 9 % of 32-item waves -- are undecided; the confirmation costs 16 us).
+//   * one 32x32x16 MFMA yields 1024 partial scores per 8 issue cycles.
 // 64-byte code rows are stored with their four 16-byte chunks XOR-swizzled by (code >> 2) & 3: ds_read_b128 fragment reads are
 // conflict-free without padding (SQ_LDS_BANK_CONFLICT 0; 33 KB per level at K = 256).  Everything after the argmin is the exact fp32
-// code in the new lane geometry.  12 waves per workgroup (three per SIMD, <= 170 VGPRs: at 16 waves / 128 VGPRs the 16-dims-per-lane
-// tail spills).  Measured at 1,048,576 items, 3x256, ROTATION: 394-440 us against 433-500 us for the 16-item kernel on the same box.
-// What the launch is NOT bound by (each measured): the winner-row gather (removing it changes nothing), in-order
-// vmcnt waits behind the stores (prefetching the next tile ahead of the stores changes nothing, scratch/store_stream.hip), LDS
-// bandwidth; its 668 B/item of stores cost ~110-180 us on top of the arithmetic instead of hiding under it, and neither quad-transposed
-// 64-byte stores nor whole-line stores staged through LDS moved that inside this kernel (the staging's extra registers cost more).
+// code in this lane geometry.
+// WHAT BOUNDS IT (rocprofv3 counters of the ids-only form at 1,048,576 items, 3 x 256, profiles/r03_*): the vector ALU.  A wave64
+// vector instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.1), the launch issues 790 of them
+// per wave and level -- 3 per score (index pack, med3, min: the minimum for an exact top-2 with its index) = 371, the rest the
+// residual split, the merge and the tail -- i.e. 71 % of the launch's cycles; the matrix pipe is 36 % busy, LDS 25 %, and doubling
+// the waves per SIMD (8 -> 16 per workgroup) buys 7 %.  HBM traffic is 152-796 B/item against a vector-ALU floor of ~85 us per
+// million items at the clock the chip holds under this load (1.6 GHz): an HBM roofline fraction above ~0.2 is out of reach for an
+// EXACT argmin in this formulation.
+// What the launch is NOT bound by (each measured): the winner-row gather, in-order vmcnt waits behind the stores, LDS bandwidth.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float PF_PAD_CC = 1.0e30f;  // |c|^2 of padding codes: finite (the packed index must not turn +inf into a NaN)
@@ -732,137 +571,6 @@ __device__ __forceinline__ void pf32_stage(char *base, const FwdArgs &a, int lvl
     atomicMax(ccmax_bits, __float_as_uint(mx));
 }
 
-// exact argmin for the wave's 32 items (rare path): two passes of the 16-item fp32 chain of rq_level_loop, codes from global memory
-__device__ __forceinline__ int pf32_exact_search(const FwdArgs &a, int lvl, const float (&r)[16], float xx, int lane) {
-    const int it = lane & 15, q = lane >> 4, n = lane & 31;
-    const float *cbl = a.cb_eff + (int64_t)lvl * a.K * D;
-    const float *ccl = a.cc + (int64_t)lvl * a.K;
-    int res[2];
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int srcl = it + 16 * pass + 32 * (q >> 1);  // the lane that holds dims [8q, 8q+8) of item it + 16 pass
-        float rq[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float lo = __shfl(r[j], srcl), hi = __shfl(r[8 + j], srcl);
-            rq[j] = (q & 1) ? hi : lo;
-        }
-        const float xxq = __shfl(xx, srcl);
-        float best = INFINITY;
-        int bidx = 0;
-        for (int t = 0; t < a.KC; t += 16) {
-            float av[8];
-            if (t + it < a.K) load8(cbl + (int64_t)(t + it) * D + 8 * q, av);
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; j++) av[j] = 0.0f;
-            }
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 8; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], rq[j], acc, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int k = t + 4 * q + g;
-                const float cck = k < a.K ? ccl[k] : INFINITY;
-                const float d0 = fmaf(-2.0f, acc[g], xxq + cck);
-                if (d0 < best) { best = d0; bidx = k; }
-            }
-        }
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            const float ob = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bidx, o);
-            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-        }
-        res[pass] = bidx;
-    }
-    const int v0 = __shfl(res[0], n & 15), v1 = __shfl(res[1], n & 15);
-    return (n >> 4) ? v1 : v0;
-}
-
-// Too close to call (rare): by the argument above the exact argmin is one of the codes whose approximate score lies within DELTA of
-// the best one -- usually two codes.  Re-scan the level's scores, every lane keeping up to four such codes of its half of the
-// codebook, then give exactly those the exact fp32 distance (the ORDER-P fmaf chain of the 16x16x4 MFMA, here on the vector ALU,
-// codes from global memory) and keep the smallest, lowest code on ties.  A lane with more than four candidates (duplicated codes)
-// sends the wave to the full exact search.  thr = best + DELTA for the undecided items, -inf for the others (they keep idx1).
-template <int NT>
-__device__ __forceinline__ int pf32_confirm(const FwdArgs &a, int lvl, const char *Ch, const char *Cl, const float *ccs, int off_p0,
-                                            int off_p1, int h, int lane, const float (&r)[16], float xx, float thr, int idx1) {
-    unsigned hw[16], lw[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) split_bf16(r[j], hw[j], lw[j]);
-    bf16x8_t bh[2], bl[2];
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-        bh[p] = __builtin_bit_cast(bf16x8_t, make_uint4(hw[8 * p] | (hw[8 * p + 1] << 16), hw[8 * p + 2] | (hw[8 * p + 3] << 16),
-                                                        hw[8 * p + 4] | (hw[8 * p + 5] << 16), hw[8 * p + 6] | (hw[8 * p + 7] << 16)));
-        bl[p] = __builtin_bit_cast(bf16x8_t, make_uint4(lw[8 * p] | (lw[8 * p + 1] << 16), lw[8 * p + 2] | (lw[8 * p + 3] << 16),
-                                                        lw[8 * p + 4] | (lw[8 * p + 5] << 16), lw[8 * p + 6] | (lw[8 * p + 7] << 16)));
-    }
-    unsigned long long cands = 0ull;
-    int cnt = 0;
-    for (int t = 0; t < a.KC; t += 32) {
-        const int rowb = t * 64;
-        const bf16x8_t ah0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Ch + rowb + off_p0));
-        const bf16x8_t ah1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Ch + rowb + off_p1));
-        const bf16x8_t al0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Cl + rowb + off_p0));
-        const bf16x8_t al1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Cl + rowb + off_p1));
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(ccs + t + 8 * g + 4 * h);
-            acc[4 * g] = c4.x; acc[4 * g + 1] = c4.y; acc[4 * g + 2] = c4.z; acc[4 * g + 3] = c4.w;
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[0], acc, 0, 0, 0);  // (the very MFMAs of pf32_tile: the same scores)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[1], acc, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const float s = __uint_as_float((__float_as_uint(acc[j]) & 0xfffffff0u) | (unsigned)j);
-            if (s <= thr) {
-                cands = (cands << 16) | (unsigned long long)(unsigned)(t + (j & 3) + 8 * (j >> 2) + 4 * h);
-                cnt++;
-            }
-        }
-    }
-    if (__ballot(cnt > 4) != 0ull) return pf32_exact_search(a, lvl, r, xx, lane);
-    float xlo[16], xhi[16];  // the whole residual on both lanes of the item
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const float other = __uint_as_float(swap32_other(__float_as_uint(r[j]), h));
-        xlo[j] = h ? other : r[j];
-        xhi[j] = h ? r[j] : other;
-    }
-    float dbest = INFINITY;
-    int kbest = 0x7fffffff;
-    for (int c = 0; __ballot(c < cnt) != 0ull; c++) {
-        if (c < cnt) {
-            const int k = (int)((cands >> (16 * c)) & 0xffffull);
-            const float *row = a.cb_eff + ((int64_t)lvl * a.K + k) * D;
-            float clo[16], chi[16];
-            load16(row, clo);
-            load16(row + 16, chi);
-            float dot = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {  // d = j, 8 + j, 16 + j, 24 + j: the order in which the MFMA chain meets them
-                dot = fmaf(clo[j], xlo[j], dot);
-                dot = fmaf(clo[8 + j], xlo[8 + j], dot);
-                dot = fmaf(chi[j], xhi[j], dot);
-                dot = fmaf(chi[8 + j], xhi[8 + j], dot);
-            }
-            const float d = fmaf(-2.0f, dot, xx + a.cc[(int64_t)lvl * a.K + k]);
-            if (d < dbest || (d == dbest && k < kbest)) { dbest = d; kbest = k; }
-        }
-    }
-    const float od = __uint_as_float(swap32_other(__float_as_uint(dbest), h));
-    const int ok = (int)swap32_other((unsigned)kbest, h);
-    if (od < dbest || (od == dbest && ok < kbest)) kbest = ok;
-    return thr == -INFINITY ? idx1 : kbest;
-}
-
 __device__ __forceinline__ float vmin_f32(float x, float y) {  // one v_min_f32 (fminf would canonicalise its operands first)
     float m;
     asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y));
@@ -901,12 +609,10 @@ __device__ __forceinline__ void pf32_tile(const char *Ch, const char *Cl, const 
 
 // PIPE (needs NT > 0): two accumulator sets in ping-pong -- the MFMAs of tile t + 1 are issued one at a time between the scan
 // operations of tile t (a wave issues in order: behind a chain of dependent MFMAs it could not issue anything), so the matrix pipe
-// and the vector ALU work at the same time INSIDE a wave, not only across the waves of a SIMD.  16 more VGPRs: 8 waves per workgroup.
+// and the vector ALU work at the same time INSIDE a wave, not only across the waves of a SIMD.
 // IDS (the corpus tokenisation of HSemanticIdTokenizer.precompute_corpus_ids, reference h_semids.py:109-195: only the ids leave the
 // launch): eval-mode search with NO output but ids -- no z / emb_cat / emb_sum / res_cat / loss stores and none of their arithmetic,
-// no winner-row fetch after the last level (nothing consumes that residual), the next tile's input rows requested a whole tile
-// ahead (nothing but loads shares the in-order vmcnt queue now), and -- 16 fewer live registers per lane without the output rows --
-// more waves per SIMD to cover the one dependent fetch per level that is left.  Same scores, same confirmation: the same ids.
+// no winner-row fetch after the last level (nothing consumes that residual).  Same scores, same decisions: the same ids.
 template <int MODE, bool TRAIN, int NW, int NT, bool PIPE = false, bool IDS = false>  // NT: 32-code tiles per level when known at compile time (full unroll), else 0
 __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
     static_assert(!IDS || !TRAIN, "the ids-only form is an eval-mode search");
@@ -923,29 +629,12 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
     const int sw = (n >> 2) & 3;
     const int off_p0 = n * 64 + (((2 * h) ^ sw) << 4), off_p1 = n * 64 + (((2 * h + 1) ^ sw) << 4);  // this lane's A-fragment chunks
     const int64_t ntiles = (a.B + TILE_ITEMS - 1) / TILE_ITEMS;
-    constexpr bool PREF = IDS && NW < 16;  // (at 16 waves = 128 registers per lane the 16 prefetch registers spill; four waves per SIMD
-                                           //  cover the tile's first load instead)
-    float rnext[16];  // IDS: the input rows of this workgroup's NEXT tile, in flight while the current one is searched
-    if (PREF && (int64_t)blockIdx.x < ntiles) {
-        const int64_t it0 = (int64_t)blockIdx.x * TILE_ITEMS + wave * 32 + n;
-        load16(a.y + (it0 < a.B ? it0 : a.B - 1) * D + 16 * h, rnext);
-    }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t item = tile * TILE_ITEMS + wave * 32 + n;
         const bool valid = item < a.B;
         const int64_t src = valid ? item : a.B - 1;
         float r[16];
-        if (PREF) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) r[j] = rnext[j];
-            const int64_t tn = tile + gridDim.x;
-            if (tn < ntiles) {
-                const int64_t itn = tn * TILE_ITEMS + wave * 32 + n;
-                load16(a.y + (itn < a.B ? itn : a.B - 1) * D + 16 * h, rnext);
-            }
-        } else {
-            load16(a.y + src * D + 16 * h, r);
-        }
+        load16(a.y + src * D + 16 * h, r);
         if (a.normalize_input) {
             const float den = fmaxf(sqrtf(dotH(r, r)), 1e-12f);
 #pragma unroll
@@ -954,6 +643,7 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
         if (!IDS && a.z != nullptr && valid) store16(a.z + item * D + 16 * h, r);
         float loss = 0.0f;
         float esum[16];
+        bool undecided_any = false;  // some level of this item was too close to call: the exact kernel redoes the item
         for (int i = 0; i < a.L; i++) {
             if (!IDS && a.res_cat != nullptr && valid) store16(a.res_cat + item * (a.L * D) + i * D + 16 * h, r);
             const float xx = dotH(r, r);
@@ -1037,10 +727,8 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
                 if (o1 < best1 || (o1 == best1 && oi < idx1)) { best1 = o1; idx1 = oi; }
             }
             const float delta = 6.103515625e-05f * (xx + __uint_as_float(ccmax_bits[i]));  // 2^-14 (|x|^2 + max |c|^2)
-            int bidx = idx1;
-            const bool undecided = !(best2 - best1 > delta);
-            if (__ballot(undecided) != 0ull)
-                bidx = pf32_confirm<NT>(a, i, Ch, Cl, ccs, off_p0, off_p1, h, lane, r, xx, undecided ? best1 + delta : -INFINITY, idx1);
+            undecided_any |= !(best2 - best1 > delta);  // (NaN-safe: anything not provably apart is undecided)
+            const int bidx = idx1;                      // decided items: the exact argmin; undecided ones: tentative, redone by the exact kernel
             if (IDS) {
                 if (valid && h == 0) a.ids[item * a.L + i] = (int64_t)bidx;
                 if (i + 1 < a.L) {  // eval: o = e, the next level searches r - e (quantize.py:146-148, h_rqvae.py:552)
@@ -1067,6 +755,15 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
             for (int j = 0; j < 16; j++) {
                 esum[j] = (i == 0) ? o[j] : esum[j] + o[j];
                 r[j] = r[j] - o[j];
+            }
+        }
+        {   // the wave's undecided items join the list the exact kernel works through: one atomic per wave that has any
+            const unsigned long long m = __ballot(undecided_any && valid && h == 0);
+            if (m != 0ull) {
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(a.fix_count, (unsigned)__popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (undecided_any && valid && h == 0) a.fix_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (int)item;
             }
         }
         if (IDS) continue;
@@ -1670,7 +1367,7 @@ extern "C" int hidvae_codebook_prepare_adamw(const float *const *E_host, const i
 extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input, const float *cb_eff, const float *cc,
                                  int L, int64_t K, int mode, int training, float beta, float *z, int64_t *ids,
                                  float *emb_cat, int64_t ld_cat, float *emb_sum, float *res_cat, float *qloss,
-                                 void *stream) {
+                                 void *workspace, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "rq_forward: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
     HV_REQUIRE(B >= 1 && K >= 1, "rq_forward: empty batch or codebook (B=%lld K=%lld)", (long long)B, (long long)K);
     HV_REQUIRE(y && cb_eff && cc && ids, "rq_forward: null pointer");
@@ -1701,72 +1398,58 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     const int64_t gcap = (csplit && !resident) ? 2048 : 256;  // one workgroup per CU when LDS-limited; the streamed kernel holds no codes in LDS
     const int grid = (int)(ntiles < gcap ? ntiles : gcap);  // grid-stride over tiles
     hipStream_t s = (hipStream_t)stream;
-    // large batches whose codebooks fit as bf16 hi/lo images: split-bf16 prefilter + exact confirmation (bit-identical results)
-    // HIDVAE_RQ_PREFILTER: 0 = exact kernel only, 16 = the 16-item prefilter only, 32 = the 32-item kernel from 65536 items on
-    static const int pf_env = getenv("HIDVAE_RQ_PREFILTER") ? atoi(getenv("HIDVAE_RQ_PREFILTER")) : -1;
-    const bool prefilter_on = pf_env != 0;
+    // large batches whose codebooks fit as bf16 hi/lo images: split-bf16 prefilter, then the exact kernel over the items it could not
+    // decide (bit-identical results; needs the caller's workspace for that list).  HIDVAE_RQ_PREFILTER=0: exact kernels only.
+    static const int pf_env = getenv("HIDVAE_RQ_PREFILTER") ? atoi(getenv("HIDVAE_RQ_PREFILTER")) : 1;
     const int KCp = (int)(hv_cdiv(K, 32) * 32);
     const size_t pf32_bytes = pf32_level_bytes(KCp) * (size_t)L;
-    const bool ids_only = !training && !z && !emb_cat && !emb_sum && !res_cat && !qloss;  // eval, every output but ids NULL
-    if (prefilter_on && pf_env != 16 && B >= ((pf_env == 32 || ids_only) ? 256 * 256 : 128 * 1024) && pf32_bytes <= 152 * 1024) {
+    if (pf_env != 0 && workspace != nullptr && B >= 256 * 256 && B < (1ll << 31) && pf32_bytes <= 152 * 1024) {
+        const bool ids_only = !training && !z && !emb_cat && !emb_sum && !res_cat && !qloss;  // eval, every output but ids NULL
         FwdArgs p = a;
         p.KC = KCp;
         p.nchunks = 1;
-        constexpr int PF32_NW = 12;  // waves per workgroup: three per SIMD, up to 170 VGPRs each (measured at 1M items: 16 waves / 128 VGPRs
-                                     // with spills 480-500 us, 12 waves 436-448 us, 8 waves 457 us)
-        // ping-pong accumulators (8 waves): 131,072 items 79.5 -> 67.9 us, 524,288 232 -> 217, 1,048,576 388 -> 386 (HIDVAE_RQ_PF32_PIPE=0: off)
-        static const int pipe_env = getenv("HIDVAE_RQ_PF32_PIPE") ? atoi(getenv("HIDVAE_RQ_PF32_PIPE")) : 1;
-        const bool pipe = pipe_env != 0 && KCp == 256;
-        const int pnw = pipe ? 8 : PF32_NW;
+        p.fix_count = reinterpret_cast<unsigned *>(workspace);  // 16-byte header, then the list
+        p.fix_list = reinterpret_cast<int *>(workspace) + 4;
+        if (hipMemsetAsync(workspace, 0, 16, s) != hipSuccess) return hv_fail(HIDVAE_ELAUNCH, "rq_forward: clearing the undecided-item counter failed");
+        const bool pipe = KCp == 256;  // ping-pong accumulators need the tile count at compile time
+        // waves per workgroup (one workgroup per CU: the LDS images take 101 KB at 3 x 256): 16 = four per SIMD where the registers allow
+        // it (ids-only: 128 per lane), 8 with the output rows live
+        static const int ids_nw_env = getenv("HIDVAE_RQ_IDS_NW") ? atoi(getenv("HIDVAE_RQ_IDS_NW")) : 16;
+        static const int full_nw_env = getenv("HIDVAE_RQ_PF32_NW") ? atoi(getenv("HIDVAE_RQ_PF32_NW")) : 8;
+        const int want = ids_only ? ids_nw_env : full_nw_env;
+        const int pnw = !pipe ? 12 : (want >= 16 ? 16 : (want >= 12 ? 12 : 8));
         const int64_t nt = hv_cdiv(B, 32 * pnw);
         const int pgrid = (int)(nt < 256 ? nt : 256);
-#define HV_PF32(M, T)                                                                                                          \
+#define HV_PF32_GO(M, T, W, NTI, PP, II)                                                                                       \
     {                                                                                                                          \
-        auto kern = pipe ? rq_forward_pf32_kernel<M, T, 8, 8, true>                                                             \
-                         : (KCp == 256 ? rq_forward_pf32_kernel<M, T, PF32_NW, 8> : rq_forward_pf32_kernel<M, T, PF32_NW, 0>);  \
+        auto kern = rq_forward_pf32_kernel<M, T, W, NTI, PP, II>;                                                              \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf32_bytes); \
-        hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * pnw), pf32_bytes, s, p);                                               \
+        hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * W), pf32_bytes, s, p);                                                 \
     }
-        // ids only: the tokenizer's corpus pass
-        static const int ids_nw_env = getenv("HIDVAE_RQ_IDS_NW") ? atoi(getenv("HIDVAE_RQ_IDS_NW")) : 16;
-        if (ids_only && KCp == 256 && ids_nw_env != 0) {
-            const int inw = ids_nw_env == 8 ? 8 : (ids_nw_env == 12 ? 12 : 16);
-            const int64_t nti = hv_cdiv(B, 32 * inw);
-            const int igrid = (int)(nti < 256 ? nti : 256);
-            auto kern = inw == 8 ? rq_forward_pf32_kernel<HIDVAE_MODE_STE, false, 8, 8, true, true>
-                                 : (inw == 12 ? rq_forward_pf32_kernel<HIDVAE_MODE_STE, false, 12, 8, true, true>
-                                              : rq_forward_pf32_kernel<HIDVAE_MODE_STE, false, 16, 8, true, true>);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf32_bytes);
-            hipLaunchKernelGGL(kern, dim3(igrid), dim3(64 * inw), pf32_bytes, s, p);
-            HV_LAUNCH_CHECK("rq_forward ids-only");
-            return HIDVAE_OK;
-        }
-        if (!training) HV_PF32(HIDVAE_MODE_STE, false)
-        else if (mode == HIDVAE_MODE_STE) HV_PF32(HIDVAE_MODE_STE, true)
-        else HV_PF32(HIDVAE_MODE_ROTATION, true)
+#define HV_PF32(M, T, II)                                                         \
+    {                                                                             \
+        if (!pipe) HV_PF32_GO(M, T, 12, 0, false, II)                             \
+        else if (pnw == 16) HV_PF32_GO(M, T, 16, 8, true, II)                     \
+        else if (pnw == 12) HV_PF32_GO(M, T, 12, 8, true, II)                     \
+        else HV_PF32_GO(M, T, 8, 8, true, II)                                     \
+    }
+        if (ids_only) HV_PF32(HIDVAE_MODE_STE, false, true)
+        else if (!training) HV_PF32(HIDVAE_MODE_STE, false, false)
+        else if (mode == HIDVAE_MODE_STE) HV_PF32(HIDVAE_MODE_STE, true, false)
+        else HV_PF32(HIDVAE_MODE_ROTATION, true, false)
 #undef HV_PF32
-        HV_LAUNCH_CHECK("rq_forward prefilter32");
-        return HIDVAE_OK;
-    }
-    const size_t pf_lds_bytes = pf_level_bytes(KCp) * (size_t)L;
-    if (prefilter_on && B >= 256 * 256 && pf_lds_bytes <= 152 * 1024) {
-        FwdArgs p = a;
-        p.KC = KCp;
-        p.nchunks = 1;
-        const int64_t nt = hv_cdiv(B, ITEMS_PER_WAVE * 16);
-        const int pgrid = (int)(nt < 256 ? nt : 256);
-#define HV_PF(M, T)                                                                                                            \
-    {                                                                                                                          \
-        auto kern = rq_forward_prefilter_kernel<M, T, 16>;                                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_lds_bytes); \
-        hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * 16), pf_lds_bytes, s, p);                                              \
-    }
-        if (!training) HV_PF(HIDVAE_MODE_STE, false)
-        else if (mode == HIDVAE_MODE_STE) HV_PF(HIDVAE_MODE_STE, true)
-        else HV_PF(HIDVAE_MODE_ROTATION, true)
-#undef HV_PF
+#undef HV_PF32_GO
         HV_LAUNCH_CHECK("rq_forward prefilter");
-        return HIDVAE_OK;
+        // the exact search over the listed items (streamed code-split form: 16 items per workgroup, no LDS staging, so workgroups
+        // beyond the list's end cost nothing); it rewrites every output of those items
+        FwdArgs f = a;
+        f.list = p.fix_list;
+        f.list_count = p.fix_count;
+        const int64_t ft = hv_cdiv(B, ITEMS_PER_WAVE);
+        const int fgrid = (int)(ft < 1024 ? ft : 1024);
+        if (!training) return launch_fwd<HIDVAE_MODE_STE, false>(f, false, true, 4, fgrid, 0, s);
+        if (mode == HIDVAE_MODE_STE) return launch_fwd<HIDVAE_MODE_STE, true>(f, false, true, 4, fgrid, 0, s);
+        return launch_fwd<HIDVAE_MODE_ROTATION, true>(f, false, true, 4, fgrid, 0, s);
     }
     if (!training) return launch_fwd<HIDVAE_MODE_STE, false>(a, resident, csplit, nw, grid, lds, s);
     if (mode == HIDVAE_MODE_STE) return launch_fwd<HIDVAE_MODE_STE, true>(a, resident, csplit, nw, grid, lds, s);

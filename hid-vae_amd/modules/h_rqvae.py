@@ -308,9 +308,9 @@ class HRqVae(nn.Module, _HubMixin):
         return RQFn.apply(y.contiguous(), normalize_input, self._fused_mode(), self.training, self.commitment_weight,
                           self._normalize_flags(), want_res, getattr(self, "_prepared", None), *self._tables())
 
-    def _tag_heads(self, emb_cat, tags_emb, tags_indices):
+    def _tag_heads(self, emb_cat, tags_emb, tags_indices, defer_join=False):
         from ..tagpath import tag_heads_forward
-        return tag_heads_forward(self, emb_cat, tags_emb, tags_indices)
+        return tag_heads_forward(self, emb_cat, tags_emb, tags_indices, defer_join=defer_join)
 
     def get_semantic_ids(self, encoded_x: Tensor, tags_emb: Optional[Tensor] = None, tags_indices: Optional[Tensor] = None,
                          gumbel_t: float = 0.001) -> HRqVaeOutput:
@@ -369,7 +369,8 @@ class HRqVae(nn.Module, _HubMixin):
         self._cut_pairs = [] if self._cutting else None
         y_dec = None
         embs_norm = p_unique = None  # (the fused middle launch produces them itself when it can)
-        if self._bottleneck_ok(x):
+        fused = self._bottleneck_ok(x)
+        if fused:
             # small batches: encoder[-2:] + the L levels + decoder[:2] are one launch (ops.BottleneckFn); the stacks either side
             # hand over (pre-activation, activation) pairs so no elementwise launch appears at the cuts
             from ..ops import BottleneckFn, MLPBackFn, MLPFrontFn
@@ -378,17 +379,24 @@ class HRqVae(nn.Module, _HubMixin):
             z, ids, emb_cat, emb_sum, qloss, pre_d1, d1, embs_norm, p_unique = BottleneckFn.apply(
                 pre1, h1, We[-2], We[-1], Wd[0], Wd[1], self.codebook_normalize, self._fused_mode(), self.commitment_weight,
                 self._normalize_flags(), self._prepared, (lambda: self._census("fused", x.shape[0], x.device)), *self._tables())
-            dec_in = self._cut_here(pre_d1)
-            y_dec = MLPBackFn.apply(dec_in, d1, *Wd[2:])
         else:
             y = self.encoder.body(x)  # the encoder's l2norm (codebook_normalize) happens in the RQ prologue
             z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)
-            y_dec = self.decoder.body(self._cut_here(emb_sum))
         self._prepared = None
 
-        tag_scalars = ()
+        # the tag heads need only emb_cat: their per-level branches fork off HERE, on streams of their own, and the decoder is issued
+        # on the caller's stream beside them (round 2 issued the decoder first and made the branches wait for it); the join is
+        # deferred to just before the loss launch
+        tag_scalars, tag_join = (), None
         if tagged:
-            tag_scalars = self._tag_heads(emb_cat, tags_emb.float(), tags_indices)  # (A_0.., P_0.., acc_0..) device scalars
+            tag_scalars, tag_join = self._tag_heads(emb_cat, tags_emb.float(), tags_indices, defer_join=True)  # (A_0.., P_0.., acc_0..)
+        if fused:
+            dec_in = self._cut_here(pre_d1)
+            y_dec = MLPBackFn.apply(dec_in, d1, *Wd[2:])
+        else:
+            y_dec = self.decoder.body(self._cut_here(emb_sum))
+        if tag_join is not None:
+            tag_join()
         if getattr(self, "_cutting", False):  # everything else the loss launch differentiates is cut too (see _cut_here)
             n_t = len(tag_scalars) // 3
             qloss, z = self._cut_here(qloss), self._cut_here(z)

@@ -547,13 +547,16 @@ def tag_heads_forward_grouped(model, emb_cat, tags_emb, tags_indices):
     return tuple(aligns) + tuple(preds) + tuple(accs)
 
 
-def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
-    """-> tuple (A_0..A_{L-1}, P_0..P_{L-1}, acc_0..acc_{L-1}) of 0-d device tensors."""
+def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False):
+    """-> tuple (A_0..A_{L-1}, P_0..P_{L-1}, acc_0..acc_{L-1}) of 0-d device tensors.
+    defer_join: -> (that tuple, join) where join() makes the caller's stream wait for the level branches; the caller issues its own
+    work (the decoder) in between, so it runs beside the branches."""
     # HIDVAE_TAG_GROUPED=1: the lockstep form with grouped launches (119 launches per amazon-shaped step instead of 211).  Measured on
     # MI355X it is NOT faster than the per-level branches below (B=1024: 2.00 vs 1.97 ms; B=2048: 3.24 vs 3.16 ms): these GEMMs are
     # bound by L2->CU operand traffic (4.5-6 TB/s in every variant, see DESIGN.md), not by launch latency, so it stays opt-in.
     if os.environ.get("HIDVAE_TAG_GROUPED", "0") == "1" and 1 < model.n_layers <= 4:
-        return tag_heads_forward_grouped(model, emb_cat, tags_emb, tags_indices)
+        out = tag_heads_forward_grouped(model, emb_cat, tags_emb, tags_indices)
+        return (out, (lambda: None)) if defer_join else out
     L, D = model.n_layers, model.embed_dim
     rand = model._rand()
     training = model.training
@@ -610,7 +613,14 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices):
         aligns.append(align)
         preds.append(loss)
         accs.append(acc)
-    if branch is not None:
-        for st in branch[1:]:
-            main.wait_stream(st)
-    return tuple(aligns) + tuple(preds) + tuple(accs)
+    out = tuple(aligns) + tuple(preds) + tuple(accs)
+
+    def join():
+        if branch is not None:
+            for st in branch[1:]:
+                main.wait_stream(st)
+
+    if defer_join:
+        return out, join
+    join()
+    return out

@@ -69,6 +69,7 @@ const char *hidvae_last_error(void);
 #define HIDVAE_WS_ID_CENSUS 9            /* B  -> `scratch` of hidvae_id_stats / `census_scratch` of hidvae_bottleneck_fwd (zero-fill once) */
 #define HIDVAE_WS_KMEANS 10              /* N, K                      -> shift_scratch of hidvae_kmeans_iter             */
 #define HIDVAE_WS_TAG_LOSS 11            /* B, C                      -> row_loss + row_hit + zbuf of hidvae_tag_loss_fwd */
+#define HIDVAE_WS_RQ_FORWARD 13           /* B, L, K                   -> hidvae_rq_forward workspace (0 below 65536 items)          */
 #define HIDVAE_WS_LINEAR_BWD_ZEROED 12   /* B, n_out, n_in, has_bias  -> leading bytes of the hidvae_linear_bwd workspace that must be ZERO
                                             on entry (arrival counters of the balanced kernel; left zero on return).  Non-zero means: hand
                                             hidvae_linear_bwd a workspace that no launch running CONCURRENTLY shares (one per stream). */
@@ -181,12 +182,18 @@ int hidvae_codebook_prepare(const float *const *E_host, const int32_t *normalize
  * outputs (any may be NULL except ids):
  *   z [B,32] level-0 input; ids [B,L] int64; emb_cat [B, ld_cat>=L*32] per-level o_i side by side
  *   (level-i concat_emb of h_rqvae.py:526 is the first (i+1)*32 columns); emb_sum [B,32] = sum_i o_i
- *   (decoder input, h_rqvae.py:607); res_cat [B, L*32] level inputs r_i; qloss [B] = sum_i loss_i. */
+ *   (decoder input, h_rqvae.py:607); res_cat [B, L*32] level inputs r_i; qloss [B] = sum_i loss_i.
+ * With every output but ids NULL and training == 0 the launch is the corpus tokenisation of
+ * HSemanticIdTokenizer.precompute_corpus_ids (modules/tokenizer/h_semids.py:109-195): only 8 L bytes per item leave it.
+ *   workspace  hidvae_query_workspace(HIDVAE_WS_RQ_FORWARD, {B, L, K}) bytes, or NULL.  Batches from 65536 items on run a
+ *   split-bf16 prefilter on bf16 MFMA first and then the exact fp32 search over the items the prefilter could not decide (their list
+ *   lives in the workspace: 3 stream operations -- a 16-byte memset, the prefilter, the exact kernel -- all capturable); results are
+ *   bit-identical to the exact kernel alone, which is what runs without a workspace (about 2x slower at corpus sizes). */
 int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
                       const float *cb_eff, const float *cc, int L, int64_t K,
                       int mode, int training, float beta,
                       float *z, int64_t *ids, float *emb_cat, int64_t ld_cat,
-                      float *emb_sum, float *res_cat, float *qloss, void *stream);
+                      float *emb_sum, float *res_cat, float *qloss, void *workspace, void *stream);
 
 /* ---- a2 (last two layers) + a5-a7 + a3 (first two layers) in ONE launch, for small batches (B <= 4096; codebooks + 34 KB of
  * activations must fit in LDS: L*(33*Kp+64)*4 bytes with Kp = K rounded up to 128, e.g. 3x256 or 2x512).  Training only.

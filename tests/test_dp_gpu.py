@@ -1,8 +1,9 @@
 """GPU: the PRODUCT's data-parallel step (hidvae_amd.step.GraphedTrainStep with hidvae_amd.parallel.DataParallel).
 
-* one rank, RCCL: the three-graph overlapped exchange (graph[fwd + backward part 1] -> all-reduce(bucket 1) || graph[backward part 2]
-  -> all-reduce(bucket 2) -> graph[AdamW]) must equal the plain single-GPU step bit for bit -- the split backward, the bucket-first
-  flat gradient buffer and the in-place gradient writes change no arithmetic;
+* one rank, RCCL: the overlapped exchange -- captured INSIDE the step's one graph (graph[fwd, backward part 1, all-reduce(bucket 1) ||
+  backward part 2, all-reduce(bucket 2), AdamW], the default over RCCL) and in the three-graph form host-side backends get --
+  must equal the plain single-GPU step bit for bit: the split backward, the bucket-first flat gradient buffer and the in-place
+  gradient writes change no arithmetic;
 * two ranks sharing this box's one GPU (backend gloo, which moves device tensors through the host; RCCL refuses two ranks on one
   device): after several graphed steps on different per-rank batches the replicas are bit-identical, and equal to ONE process
   stepping on the concatenated batch (mean of per-rank gradients == gradient of the per-item-mean loss over the union)."""
@@ -50,8 +51,10 @@ def _batch(cfg, B, seed, tagged):
     return b
 
 
-def _run(tagged, dp_mode, steps=6, B=128):
-    """dp_mode None: plain step; 'overlap': DataParallel over a one-rank RCCL group, collectives issued anyway"""
+def _run(tagged, dp_mode, steps=6, B=128, in_graph=True):
+    """dp_mode None: plain step; 'overlap': DataParallel over a one-rank RCCL group, collectives issued anyway.  in_graph: the
+    collectives are captured inside the step's ONE graph (the default over RCCL); False: kept between three graphs (what host-side
+    backends get)"""
     from hidvae_amd.optim import HidvaeAdamW
     from hidvae_amd.parallel import DataParallel
     from hidvae_amd.step import GraphedTrainStep
@@ -65,15 +68,19 @@ def _run(tagged, dp_mode, steps=6, B=128):
         dp = DataParallel(m, opt.grad_buffer)
         dp.always = True
     st = GraphedTrainStep(m, opt, [_batch(cfg, B, 500, tagged)], dp=dp, gumbel_t=0.2, warmup=2, overlap=True if multi else None)
+    if multi and not in_graph:
+        st._collectives_capturable = lambda: False
     rows = []
     for it in range(steps):
         rows.append(st([_batch(cfg, B, 500 + it, tagged)]).clone())
-    assert st.graphs is not None and len(st.graphs) == (3 if multi else 1)
+    assert st.graphs is not None and len(st.graphs) == (3 if (multi and not in_graph) else 1)
+    assert st.in_graph == (multi and in_graph)
     return torch.stack(rows).cpu(), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
 
 
+@pytest.mark.parametrize("in_graph", [True, False], ids=["collectives_in_the_graph", "collectives_between_graphs"])
 @pytest.mark.parametrize("tagged", [False, True], ids=["untagged", "tagged"])
-def test_overlapped_dp_step_equals_the_plain_step_bit_for_bit(tagged):
+def test_overlapped_dp_step_equals_the_plain_step_bit_for_bit(tagged, in_graph):
     import torch.distributed as dist
     created = False
     if not dist.is_initialized():
@@ -81,7 +88,7 @@ def test_overlapped_dp_step_equals_the_plain_step_bit_for_bit(tagged):
         dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL, one rank: the --dist 1 rehearsal as a test
         created = True
     try:
-        rows1, sd1 = _run(tagged, "overlap")
+        rows1, sd1 = _run(tagged, "overlap", in_graph=in_graph)
         rows0, sd0 = _run(tagged, None)
     finally:
         if created:
