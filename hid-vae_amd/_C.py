@@ -128,6 +128,50 @@ class LaunchStamps:
         return [(n, v, dm) for (n, v), dm in zip(rows, dims)], base
 
 
+class PhaseMarks:
+    """A handful of single device timestamps at phase boundaries of the step (each one hidvae_timestamp launch on the stream that is
+    current where phase_mark() is called), also inside a graph capture.  Unlike LaunchStamps -- two extra launches around EVERY launch,
+    which stretches the replay and re-times the streams against each other -- ~30 marks leave the step's structure as it is, so
+    rows() shows where the un-instrumented step really is at each boundary (tools/step_phases.py)."""
+
+    def __init__(self, device, capacity=512):
+        self.buf = torch.zeros((capacity,), dtype=torch.int64, device=device)
+        self.labels = []
+
+    def rows(self):
+        t = self.buf[: len(self.labels)].cpu().double() * LaunchStamps.TICK_US
+        t0 = float(t.min()) if len(self.labels) else 0.0
+        return [(lab, st, float(v) - t0) for (lab, st), v in zip(self.labels, t.tolist())]
+
+
+_PHASES = None
+
+
+def phases_begin(device, capacity=512):
+    global _PHASES
+    _PHASES = PhaseMarks(device, capacity)
+    return _PHASES
+
+
+def phases_end():
+    global _PHASES
+    p, _PHASES = _PHASES, None
+    return p
+
+
+def phase_mark(label):
+    """no-op unless phases_begin() is active: one device timestamp on the current stream, remembered under `label`"""
+    p = _PHASES
+    if p is None:
+        return
+    i = len(p.labels)
+    if i >= p.buf.numel():
+        raise RuntimeError("PhaseMarks: capacity exceeded")
+    st = torch.cuda.current_stream().cuda_stream
+    p.labels.append((label, int(st)))
+    lib()._L.hidvae_timestamp(ctypes.c_void_p(p.buf.data_ptr() + 8 * i), ctypes.c_void_p(st))
+
+
 _STAMPS = None
 _NOT_LAUNCHES = ("hidvae_last_error", "hidvae_version", "hidvae_query_workspace", "hidvae_timestamp")
 

@@ -12,11 +12,15 @@ def _runtime_defaults():
     process, so `import hidvae_amd` must come before the first torch.cuda call; later is harmless but has no effect).
 
     DEBUG_HIP_FORCE_GRAPH_QUEUES: the number of hardware queues hipGraphLaunch spreads a graph's parallel branches over.  The tagged
-    step forks into one branch per level (plus the decoder on the caller's stream and RCCL's stream under data parallelism); with the
-    runtime's default the branches largely run one after the other.  Measured on MI355X / ROCm 7.2 (bench.py --tagged 1, B = 1024):
-    default 1.745 ms, 3 queues 1.528, 8 queues 1.511, 12 queues 1.498 ms; B = 2048: 2.81 -> 2.45 ms; the untagged step (one branch)
-    is unchanged.  An explicit setting in the environment wins."""
-    os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "12")
+    step forks into one branch per level (plus the decoder on the caller's stream and RCCL's stream under data parallelism).  Measured
+    on MI355X / ROCm 7.2 (bench.py --tagged 1, B = 1024, same box): the runtime's default and an explicit 4 give 1.79 ms -- two of the
+    heavy branches end up behind each other --, 3 queues 1.507-1.514 ms, 5 / 6 / 8 / 12 queues 1.52-1.56 ms; B = 2048: 2.81 -> 2.46 ms;
+    the untagged step (one branch) is unchanged.  More than 4 is NOT safe: a process that instantiates many graphs (the GPU test
+    suite) segfaults inside hipGraphLaunch with 5, 6 and 12 queues unless GPU_MAX_HW_QUEUES is raised too; 3 passes the whole suite.
+    An explicit DEBUG_HIP_FORCE_GRAPH_QUEUES in the environment wins; HIDVAE_GRAPH_QUEUES=0 leaves the runtime's default alone."""
+    q = os.environ.get("HIDVAE_GRAPH_QUEUES", "3")
+    if q != "0":
+        os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", q)
 
 
 _runtime_defaults()

@@ -1412,12 +1412,10 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
         p.fix_list = reinterpret_cast<int *>(workspace) + 4;
         if (hipMemsetAsync(workspace, 0, 16, s) != hipSuccess) return hv_fail(HIDVAE_ELAUNCH, "rq_forward: clearing the undecided-item counter failed");
         const bool pipe = KCp == 256;  // ping-pong accumulators need the tile count at compile time
-        // waves per workgroup (one workgroup per CU: the LDS images take 101 KB at 3 x 256): 16 = four per SIMD where the registers allow
-        // it (ids-only: 128 per lane), 8 with the output rows live
-        static const int ids_nw_env = getenv("HIDVAE_RQ_IDS_NW") ? atoi(getenv("HIDVAE_RQ_IDS_NW")) : 16;
-        static const int full_nw_env = getenv("HIDVAE_RQ_PF32_NW") ? atoi(getenv("HIDVAE_RQ_PF32_NW")) : 8;
-        const int want = ids_only ? ids_nw_env : full_nw_env;
-        const int pnw = !pipe ? 12 : (want >= 16 ? 16 : (want >= 12 ? 12 : 8));
+        // waves per workgroup (one workgroup per CU: the LDS images take 101 KB at 3 x 256).  ids-only: 16 = four per SIMD at 124
+        // registers per lane from 131,072 items on (1M items: 248 us against 258 at 8; 65,536 items: 52 against 45, the launch is
+        // then 128 workgroups); the full forms keep their output rows live, 8 waves at 158-166 registers (12 waves: no faster)
+        const int pnw = !pipe ? 12 : ((ids_only && B >= 128 * 1024) ? 16 : 8);
         const int64_t nt = hv_cdiv(B, 32 * pnw);
         const int pgrid = (int)(nt < 256 ? nt : 256);
 #define HV_PF32_GO(M, T, W, NTI, PP, II)                                                                                       \
@@ -1426,18 +1424,20 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf32_bytes); \
         hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * W), pf32_bytes, s, p);                                                 \
     }
-#define HV_PF32(M, T, II)                                                         \
-    {                                                                             \
-        if (!pipe) HV_PF32_GO(M, T, 12, 0, false, II)                             \
-        else if (pnw == 16) HV_PF32_GO(M, T, 16, 8, true, II)                     \
-        else if (pnw == 12) HV_PF32_GO(M, T, 12, 8, true, II)                     \
-        else HV_PF32_GO(M, T, 8, 8, true, II)                                     \
-    }
-        if (ids_only) HV_PF32(HIDVAE_MODE_STE, false, true)
-        else if (!training) HV_PF32(HIDVAE_MODE_STE, false, false)
-        else if (mode == HIDVAE_MODE_STE) HV_PF32(HIDVAE_MODE_STE, true, false)
-        else HV_PF32(HIDVAE_MODE_ROTATION, true, false)
-#undef HV_PF32
+        if (ids_only) {
+            if (!pipe) HV_PF32_GO(HIDVAE_MODE_STE, false, 12, 0, false, true)
+            else if (pnw == 16) HV_PF32_GO(HIDVAE_MODE_STE, false, 16, 8, true, true)
+            else HV_PF32_GO(HIDVAE_MODE_STE, false, 8, 8, true, true)
+        } else if (!training) {
+            if (!pipe) HV_PF32_GO(HIDVAE_MODE_STE, false, 12, 0, false, false)
+            else HV_PF32_GO(HIDVAE_MODE_STE, false, 8, 8, true, false)
+        } else if (mode == HIDVAE_MODE_STE) {
+            if (!pipe) HV_PF32_GO(HIDVAE_MODE_STE, true, 12, 0, false, false)
+            else HV_PF32_GO(HIDVAE_MODE_STE, true, 8, 8, true, false)
+        } else {
+            if (!pipe) HV_PF32_GO(HIDVAE_MODE_ROTATION, true, 12, 0, false, false)
+            else HV_PF32_GO(HIDVAE_MODE_ROTATION, true, 8, 8, true, false)
+        }
 #undef HV_PF32_GO
         HV_LAUNCH_CHECK("rq_forward prefilter");
         // the exact search over the listed items (streamed code-split form: 16 items per workgroup, no LDS staging, so workgroups

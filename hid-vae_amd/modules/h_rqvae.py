@@ -361,6 +361,7 @@ class HRqVae(nn.Module, _HubMixin):
                 mix = torch.is_grad_enabled() and lm.use_mixup and x.shape[0] > 1 and hasattr(r, "prepare_mixup")
                 if not (hasattr(r, "_arena") and early_rand(r, tags_indices[:, :self.n_layers], x.device, self.n_layers, mix)):
                     r.begin_step(x.device)
+        _C.phase_mark("fwd:start")
         self._prepared = self._prepare_codebooks_async()  # effective codebooks + |c|^2 on the helper stream, beside the encoder
         # data-parallel overlap (step.GraphedTrainStep): with `dp_cut` set the backward is split in two at the inputs of the decoder's
         # tail and of the loss launch, so the gradients of the decoder's last layers -- final first -- go on the wire while the rest of
@@ -383,6 +384,7 @@ class HRqVae(nn.Module, _HubMixin):
             y = self.encoder.body(x)  # the encoder's l2norm (codebook_normalize) happens in the RQ prologue
             z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)
         self._prepared = None
+        _C.phase_mark("fwd:quantised")
 
         # the tag heads need only emb_cat: their per-level branches fork off HERE, on streams of their own, and the decoder is issued
         # on the caller's stream beside them (round 2 issued the decoder first and made the branches wait for it); the join is
@@ -395,8 +397,10 @@ class HRqVae(nn.Module, _HubMixin):
             y_dec = MLPBackFn.apply(dec_in, d1, *Wd[2:])
         else:
             y_dec = self.decoder.body(self._cut_here(emb_sum))
+        _C.phase_mark("fwd:decoder done")
         if tag_join is not None:
             tag_join()
+        _C.phase_mark("fwd:heads joined")
         if getattr(self, "_cutting", False):  # everything else the loss launch differentiates is cut too (see _cut_here)
             n_t = len(tag_scalars) // 3
             qloss, z = self._cut_here(qloss), self._cut_here(z)
@@ -422,6 +426,7 @@ class HRqVae(nn.Module, _HubMixin):
                                                     self.tag_prediction_weight, self.sem_id_uniqueness_weight, n_tag,
                                                     float(self.n_layers), *tag_scalars)
         main.wait_stream(side)  # the statistics above were computed beside the decoder
+        _C.phase_mark("fwd:loss done")
         self.last_summary = summary  # device [6]: loss, mean recon, mean rqvae, tag align, tag pred, tag accuracy (training log row)
         zero = self._zero_scalar(x.device)
         if tagged:

@@ -140,6 +140,7 @@ class MLPFrontFn(Function):
             return (None,) * (1 + len(ctx.weights))
         gx, gws, _ = mlp_body_backward(ctx.saved, ctx.weights, g_pre.contiguous(), ctx.need_x)
         ctx.saved = None
+        _C.phase_mark("bwd:encoder front done")
         return (gx,) + tuple(gws)
 
 
@@ -157,7 +158,9 @@ class MLPBackFn(Function):
     def backward(ctx, g_y):
         if g_y is None:
             return (None,) * (2 + len(ctx.weights))
+        _C.phase_mark("bwd:decoder tail start")
         gx, gws, _ = mlp_body_backward(ctx.saved, ctx.weights, g_y.contiguous(), ctx.need_x, in_pre=ctx.pre_in)
+        _C.phase_mark("bwd:decoder tail done")
         ctx.saved = None
         return (gx, None) + tuple(gws)
 

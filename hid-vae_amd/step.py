@@ -126,7 +126,10 @@ class GraphedTrainStep:
         self._fwd_bwd()
         if self.dp is not None:
             self.opt.grad_scale, _ = self.dp.allreduce()
+        from . import _C
+        _C.phase_mark("backward done")
         self.opt.step()
+        _C.phase_mark("adamw done")
 
     def _capture(self):
         if self.dp is not None and self._collectives_capturable():

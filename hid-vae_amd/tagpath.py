@@ -38,6 +38,7 @@ class ConcatViewsFn(Function):
         live = [g.contiguous() for g in grads if g is not None]
         if not live:
             return None, None, None, None
+        _C.phase_mark("bwd:heads joined (concat views)")
         return _C.sum_prefix_slices(live, ctx.shape[0], ctx.shape[1]), None, None, None
 
 
@@ -119,6 +120,7 @@ class BatchNormFn(Function):
         if not training:
             raise RuntimeError("BatchNorm1d in eval mode is not differentiated on the HIP path")
         gx, gg, gb = _C.batchnorm_bwd(gy.contiguous(), x, gamma, beta, sm, sr, relu, mask, mask_scale, need_gx=ctx.needs_input_grad[0])
+        _C.phase_mark(f"bwd:projector batchnorm done (then its first Linear)")
         return (gx, gg, gb) + (None,) * 9
 
 
@@ -164,6 +166,7 @@ class InfoNCEFn(Function):
             return None, None, None, None
         tau, scale = ctx.cfg
         gc = gt = None
+        _C.phase_mark(f"bwd:infonce w={ctx.saved_tensors[0].shape[1]} start")
         if ctx.chunked:
             cn, nc, tn, nt, lse = ctx.saved_tensors
             B, w = cn.shape
@@ -209,6 +212,7 @@ class TagPredLossFn(Function):
         if g is None:
             return (None,) * 10
         dmix, dkl, target, inverse, lam, nv = ctx.stash
+        _C.phase_mark(f"bwd:level C={dmix.shape[1] if dmix is not None else '?'} predictor start")
         return (_C.tag_loss_bwd(dmix, dkl, target, inverse, lam, g.contiguous(), nv),) + (None,) * 9
 
 
@@ -603,10 +607,13 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False):
         st = lvl_stream(i)
         with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
             c_nce, c_att, c_gate = views[3 * i], views[3 * i + 1], views[3 * i + 2]
+            _C.phase_mark(f"fwd:level {i} start")
             proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
             align = model.tag_alignment_loss(c_nce, proj, i)
+            _C.phase_mark(f"fwd:level {i} projector+infonce done")
             logits = tag_predictor_forward(model.tag_predictors[i], c_att, c_gate, rand)
             loss, acc = tag_prediction_loss(model.tag_prediction_loss, logits, tags_indices[:, i].contiguous(), 0, rand, level=i)
+            _C.phase_mark(f"fwd:level {i} done")
         if st is not None:
             for t in (align, loss, acc):
                 t.record_stream(main)  # consumed by the total-loss launch on the caller's stream
