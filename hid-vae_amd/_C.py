@@ -23,7 +23,11 @@ _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_floa
 
 _SIGNATURES = {
     "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _i, _vp, _i, _vp],
-    "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _i, _vp, _vp],
+    "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _f, _vp, _i, _vp, _vp],
+    "hidvae_layernorm_bwd_partial": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _f, _vp, _vp, _vp],
+    "hidvae_layernorm_param_final_many": [_vp, _i, _vp],
+    "hidvae_gate_fwd": [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_gate_bwd": [_vp, _i64, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
@@ -428,8 +432,10 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
     return out
 
 
-def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accumulate=False, bias=False, db=None, accumulate_db=False):
-    """backward of y = x W^T in one launch -> (dW [n_out,n_in], dX [B,n_in] or None); dX = epilogue(g W) with a D* code + aux."""
+def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accumulate=False, bias=False, db=None, accumulate_db=False,
+               dx_scale=1.0):
+    """backward of y = x W^T in one launch -> (dW [n_out,n_in], dX [B,n_in] or None); dX = epilogue(g W) with a D* code + aux.
+    dx_scale multiplies the EPI_DRELU result: the backward through ReLU -> Dropout(keep_scale) read off that layer's saved output."""
     _f32(g, "g"), _f32(x, "x")
     B, n_out = g.shape
     n_in = x.shape[1]
@@ -457,8 +463,8 @@ def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accu
         ws = _ws(WS_LINEAR_BWD, g.device, B, n_out, n_in, int(bool(bias)))
     _check(lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
                                    _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, int(bool(accumulate)), _p(dX), n_in,
-                                   int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, _p(db if bias else None),
-                                   int(bool(accumulate_db)), _p(ws), _stream()), "hidvae_linear_bwd")
+                                   int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, float(dx_scale),
+                                   _p(db if bias else None), int(bool(accumulate_db)), _p(ws), _stream()), "hidvae_linear_bwd")
     if bias:
         return dW, dX, db
     return dW, dX
@@ -821,6 +827,61 @@ def layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, ne
                                           float(mask_scale), _p(gx), _p(gg), _p(gb), int(bool(accumulate)), _p(ws), _stream()),
            "hidvae_layernorm_bwd_all")
     return gx, gg, gb
+
+
+def layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y_out, keep_scale, in_relu_scale=0.0, need_gx=True):
+    """LayerNorm backward up to its seam: -> (gx or None, partials).  The affine gradients follow from `partials` in
+    layernorm_param_final_many (one launch for many LayerNorms).  y_out: the forward output (ReLU -> Dropout gate, no mask needed);
+    in_relu_scale != 0: gx is returned already taken through the ReLU -> Dropout that produced the LayerNorm's input."""
+    M, N = x.shape
+    gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if need_gx else None
+    part = _ws(WS_LAYERNORM_BWD_ALL, x.device, M, N)
+    _check(lib().hidvae_layernorm_bwd_partial(_p(gy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), M, N, int(relu), _p(y_out),
+                                              float(keep_scale), float(in_relu_scale), _p(gx), _p(part), _stream()),
+           "hidvae_layernorm_bwd_partial")
+    return gx, part
+
+
+class LnFinal(ctypes.Structure):  # hidvae_ln_final
+    _fields_ = [("partials", _vp), ("M", _i64), ("N", _i64), ("ggamma", _vp), ("gbeta", _vp), ("accumulate", _i)]
+
+
+def layernorm_param_final_many(problems):
+    """problems: list of (partials, M, N, ggamma, gbeta, accumulate): the affine gradients of all of them from ONE launch"""
+    arr = (LnFinal * len(problems))()
+    for q, (part, M, N, gg, gb, acc) in zip(arr, problems):
+        q.partials, q.M, q.N, q.ggamma, q.gbeta, q.accumulate = part.data_ptr(), int(M), int(N), gg.data_ptr(), gb.data_ptr(), int(bool(acc))
+    _check(lib().hidvae_layernorm_param_final_many(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_layernorm_param_final_many")
+
+
+def gate_fwd(x, W0, b0, W2, b2, W4, b4, normalize, eps=1e-12):
+    """TagPredictor's attention gate in one launch -> (h, saved = (a1, pre2, a2, a3, nrm))"""
+    _f32(x, "x")
+    B, E = x.shape
+    dev = x.device
+    f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    a1, pre2, a2, a3, h = f(B, E // 4), f(B, E // 2), f(B, E // 2), f(B, E), f(B, E)
+    nrm = f(B) if normalize else None
+    for t in (W0, b0, W2, b2, W4, b4):
+        if not t.is_contiguous():
+            raise RuntimeError("gate_fwd: parameters must be contiguous")
+    if tuple(W0.shape) != (E // 4, E) or tuple(W2.shape) != (E // 2, E // 4) or tuple(W4.shape) != (E, E // 2):
+        raise RuntimeError(f"gate_fwd: weight shapes {tuple(W0.shape)} {tuple(W2.shape)} {tuple(W4.shape)} do not fit E={E}")
+    _check(lib().hidvae_gate_fwd(_p(x), _row_stride(x, "x"), B, E, _p(W0), _p(b0), _p(W2), _p(b2), _p(W4), _p(b4), int(bool(normalize)),
+                                 float(eps), _p(a1), _p(pre2), _p(a2), _p(a3), _p(h), _p(nrm), _stream()), "hidvae_gate_fwd")
+    return h, (a1, pre2, a2, a3, nrm)
+
+
+def gate_bwd(gh, x, W0, W2, W4, normalize, saved, eps=1e-12):
+    """-> (gx through both uses of x, g3, g2, g1: the gradients at the three pre-activations)"""
+    a1, pre2, _a2, a3, nrm = saved
+    B, E = x.shape
+    dev = x.device
+    f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    gx, g3, g2, g1 = f(B, E), f(B, E), f(B, E // 2), f(B, E // 4)
+    _check(lib().hidvae_gate_bwd(_p(gh), _row_stride(gh, "gh"), _p(x), _row_stride(x, "x"), B, E, _p(W0), _p(W2), _p(W4), int(bool(normalize)),
+                                 float(eps), _p(a1), _p(pre2), _p(a3), _p(nrm), _p(gx), _p(g3), _p(g2), _p(g1), _stream()), "hidvae_gate_bwd")
+    return gx, g3, g2, g1
 
 
 def batchnorm_fwd(x, gamma, beta, eps, momentum, training, running_mean, running_var, relu, mask, mask_scale, num_batches=None):

@@ -42,14 +42,16 @@ struct GemmArgs {
     float mask_scale;
 };
 
-__device__ __forceinline__ float apply_epilogue(int epi, float v, const float *aux, int64_t off) {
+// `scale` matters to DRELU only: the backward through ReLU -> Dropout(keep_scale) read off the layer's OUTPUT y = relu(.) * keep * scale
+// (y > 0 exactly where the unit was active AND kept, so neither the keep-mask nor the pre-activation is needed)
+__device__ __forceinline__ float apply_epilogue(int epi, float v, const float *aux, int64_t off, float scale = 1.0f) {
     switch (epi) {
         case HIDVAE_EPI_SILU: return hv_silu(v);
         case HIDVAE_EPI_RELU: return fmaxf(v, 0.0f);
         case HIDVAE_EPI_GELU: return hv_gelu(v);
         case HIDVAE_EPI_SIGMOID: return hv_sigmoid(v);
         case HIDVAE_EPI_DSILU: return v * hv_dsilu(aux[off]);
-        case HIDVAE_EPI_DRELU: return aux[off] > 0.0f ? v : 0.0f;
+        case HIDVAE_EPI_DRELU: return aux[off] > 0.0f ? v * scale : 0.0f;
         case HIDVAE_EPI_DGELU: return v * hv_dgelu(aux[off]);
         case HIDVAE_EPI_DSIGMOID: { const float s = aux[off]; return v * (s * (1.0f - s)); }
         default: return v;
@@ -271,7 +273,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs &g, int bx, int by, int
             float v = acc[r] + bias;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE)
                 g.aux[row * g.ldaux + col] = v;
-            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
             if (g.mask != nullptr) v = v * (g.mask[row * g.ldmask + col] * g.mask_scale);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int spli
     for (int s = 1; s < splits; s++) v += g.partial[(int64_t)s * g.M * g.N + idx];
     v += g.bias != nullptr ? g.bias[col] : 0.0f;
     if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-    v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+    v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
     if (g.mask != nullptr) v = v * (g.mask[row * g.ldmask + col] * g.mask_scale);
     float *dst = g.C + row * g.ldc + col;
     *dst = g.accumulate ? *dst + v : v;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_direct16_kernel(GemmArgs g) {
             if (row >= g.M) continue;
             float v = acc[r] + bias;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
             if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_direct16_kernel(GemmArgs g) {
             if (row >= g.M || col >= g.N) continue;
             v += g.bias != nullptr ? g.bias[col] : 0.0f;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
             if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
@@ -585,7 +587,7 @@ __device__ __forceinline__ void direct16_body(const GemmArgs &g, int split, int6
         if (row >= g.M || col >= g.N) continue;
         v += g.bias != nullptr ? g.bias[col] : 0.0f;
         if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
         if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
         float *dst = g.C + row * g.ldc + col;
         *dst = g.accumulate ? *dst + v : v;
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(64 * SPLIT * NWN) void gemm_direct_kernel(GemmArgs 
             if (row >= g.M) continue;
             float v = acc[r] + bias;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
             if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(64 * SPLIT * NWN) void gemm_direct_kernel(GemmArgs 
             if (row >= g.M || col >= g.N) continue;
             v += g.bias != nullptr ? g.bias[col] : 0.0f;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
             if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
@@ -924,7 +926,7 @@ __device__ __forceinline__ void direct32_body(const GemmArgs &g, int split, int6
         if (row >= g.M || col >= g.N) continue;
         v += g.bias != nullptr ? g.bias[col] : 0.0f;
         if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
         if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
         float *dst = g.C + row * g.ldc + col;
         *dst = g.accumulate ? *dst + v : v;
@@ -1094,7 +1096,7 @@ __device__ __forceinline__ void sk_output(const GemmArgs &g, int64_t m0, int64_t
 #pragma unroll
         for (int e = 0; e < 4; e++)
             if (col + e < g.N) {
-                o[e] = apply_epilogue(g.epilogue, o[e], g.aux, row * g.ldaux + col + e);
+                o[e] = apply_epilogue(g.epilogue, o[e], g.aux, row * g.ldaux + col + e, g.mask_scale);
                 if (g.accumulate) o[e] = dst[e] + o[e];
             }
         if (vec && col + 4 <= g.N) *reinterpret_cast<f32x4 *>(dst) = o;
@@ -1251,7 +1253,7 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_directL_kernel(GemmArgs g) {
             if (row >= g.M) continue;
             float v = acc[r] + bias;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
             if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
@@ -1269,7 +1271,7 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_directL_kernel(GemmArgs g) {
             if (row >= g.M || col >= g.N) continue;
             v += g.bias != nullptr ? g.bias[col] : 0.0f;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+            v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
             if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
@@ -1371,7 +1373,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_directL16_kernel(GemmArgs g) 
         if (row >= g.M) continue;
         float v = acc[r] + bias;
         if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
         if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
         float *dst = g.C + row * g.ldc + col;
         *dst = g.accumulate ? *dst + v : v;
@@ -1498,7 +1500,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile16_kernel(GemmArgs g) {
         if (row >= g.M) continue;
         float v = acc[r] + bias;
         if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
-        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col);
+        v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
         if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
         float *dstp = g.C + row * g.ldc + col;
         *dstp = g.accumulate ? *dstp + v : v;
@@ -1852,7 +1854,7 @@ extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, 
 // per-problem fallback passes false -- its workspaces are plain scratch
 static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
                            int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
-                           int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
+                           int dx_epilogue, float *aux, int64_t ldaux, float dx_scale, float *db, int accumulate_db, float *workspace,
                            void *stream, bool balanced_ok) {
     HV_REQUIRE(g && x && dW && B >= 1 && n_out >= 1 && n_in >= 1, "linear_bwd: bad arguments");
     HV_REQUIRE(ldg >= n_out && ldx >= n_in && lddw >= n_in, "linear_bwd: leading dimension too small");
@@ -1883,7 +1885,7 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         a.n0 = (int)hv_cdiv(B, BKS);
         if (dX != nullptr) {
             p.g1.M = B; p.g1.N = n_in; p.g1.K = n_out; p.g1.A = g; p.g1.lda = ldg; p.g1.B = W; p.g1.ldb = ldw; p.g1.C = dX; p.g1.ldc = lddx;
-            p.g1.epilogue = dx_epilogue; p.g1.aux = aux; p.g1.ldaux = aux ? ldaux : 0; p.g1.mask_scale = 1.0f;
+            p.g1.epilogue = dx_epilogue; p.g1.aux = aux; p.g1.ldaux = aux ? ldaux : 0; p.g1.mask_scale = dx_scale;
             p.nbx1 = (int)hv_cdiv(n_in, 64);
             p.nb1 = p.nbx1 * (int)hv_cdiv(B, 64);
             a.n1 = (int)hv_cdiv(n_out, BKS);
@@ -1931,14 +1933,14 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
             rc = hidvae_gemm_f32(HIDVAE_GEMM_TN, n_out, n_in, B, g, ldg, x, ldx, nullptr, dW, lddw, HIDVAE_EPI_NONE, nullptr, 0, nullptr, 0,
                                  1.0f, 0, workspace, accumulate_dw, stream);
         if (rc != HIDVAE_OK || dX == nullptr) return rc;
-        return hidvae_gemm_f32(HIDVAE_GEMM_NN, B, n_in, n_out, g, ldg, W, ldw, nullptr, dX, lddx, dx_epilogue, aux, ldaux, nullptr, 0, 1.0f, 0,
+        return hidvae_gemm_f32(HIDVAE_GEMM_NN, B, n_in, n_out, g, ldg, W, ldw, nullptr, dX, lddx, dx_epilogue, aux, ldaux, nullptr, 0, dx_scale, 0,
                                nullptr, 0, stream);
     }
     PairArgs p{};
     p.g0.M = n_out; p.g0.N = n_in; p.g0.K = B; p.g0.A = g; p.g0.lda = ldg; p.g0.B = x; p.g0.ldb = ldx; p.g0.C = dW; p.g0.ldc = lddw;
     p.g0.epilogue = HIDVAE_EPI_NONE; p.g0.mask_scale = 1.0f; p.g0.accumulate = accumulate_dw;
     p.g1.M = B; p.g1.N = n_in; p.g1.K = n_out; p.g1.A = g; p.g1.lda = ldg; p.g1.B = W; p.g1.ldb = ldw; p.g1.C = dX; p.g1.ldc = lddx;
-    p.g1.epilogue = dx_epilogue; p.g1.aux = aux; p.g1.ldaux = aux ? ldaux : 0; p.g1.mask_scale = 1.0f;
+    p.g1.epilogue = dx_epilogue; p.g1.aux = aux; p.g1.ldaux = aux ? ldaux : 0; p.g1.mask_scale = dx_scale;
     const int T = pair16 ? 16 : 32;
     p.split0 = pair16 ? pick_split16(n_out, n_in, B, 0) : s32_0;
     p.split1 = pair16 ? pick_split16(B, n_in, n_out, 0) : s32_1;
@@ -1968,9 +1970,9 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
 
 extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
                                  int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
-                                 int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
+                                 int dx_epilogue, float *aux, int64_t ldaux, float dx_scale, float *db, int accumulate_db, float *workspace,
                                  void *stream) {
-    return linear_bwd_impl(g, ldg, x, ldx, W, ldw, B, n_out, n_in, dW, lddw, accumulate_dw, dX, lddx, dx_epilogue, aux, ldaux, db,
+    return linear_bwd_impl(g, ldg, x, ldx, W, ldw, B, n_out, n_in, dW, lddw, accumulate_dw, dX, lddx, dx_epilogue, aux, ldaux, dx_scale, db,
                            accumulate_db, workspace, stream, true);
 }
 
@@ -2060,7 +2062,7 @@ extern "C" int hidvae_linear_bwd_group(const hidvae_linear_bwd_problem *pr, int 
         for (int i = 0; i < n; i++) {
             const hidvae_linear_bwd_problem &q = pr[i];
             const int rc = linear_bwd_impl(q.g, q.ldg, q.x, q.ldx, q.W, q.ldw, q.B, q.n_out, q.n_in, q.dW, q.lddw, q.accumulate_dw, q.dX, q.lddx,
-                                           q.dx_epilogue, q.aux, q.ldaux, q.db, q.accumulate_db, q.workspace, stream, false);
+                                           q.dx_epilogue, q.aux, q.ldaux, 1.0f, q.db, q.accumulate_db, q.workspace, stream, false);
             if (rc != HIDVAE_OK) return rc;
         }
         return HIDVAE_OK;

@@ -249,10 +249,14 @@ __global__ __launch_bounds__(256) void layernorm_param_partial_kernel(const floa
 // the four waves' sums are combined in LDS and written as one partial per workgroup (summed by layernorm_param_final_kernel in
 // ascending order).  N <= 64*LNF_NV.
 constexpr int LNF_ROWS = 4, LNF_NV = 16;  // one row per wave: rows in flight, not in sequence, hide the two dependent phases
+// yout (optional, replaces mask): the forward OUTPUT y = relu(h) * keep * scale -- y > 0 exactly where the unit was active and kept, so
+//   the gate of ReLU -> Dropout needs neither the keep-mask nor h.
+// in_relu_scale (0 = off): this LayerNorm's INPUT x was itself relu(.) * keep * in_relu_scale (Linear -> ReLU -> Dropout -> LayerNorm,
+//   h_rqvae.py:157-162): gx leaves the launch already taken through that ReLU / Dropout, gx * (x > 0 ? in_relu_scale : 0).
 __device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*red)[3][64 * LNF_NV], const float *gy, const float *x,
                                                          const float *gamma, const float *beta, const float *mean, const float *rstd,
                                                          int64_t M, int64_t N, int relu, const float *mask, float scale, float *gx,
-                                                         float *part) {
+                                                         float *part, const float *yout = nullptr, float in_relu_scale = 0.0f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ga[LNF_NV], be[LNF_NV], sg[LNF_NV], sb[LNF_NV];
 #pragma unroll
@@ -269,16 +273,23 @@ __device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*re
         const float mu = mean[row], rs = rstd[row];
         float g[LNF_NV], xh[LNF_NV];
         float s1 = 0.0f, s2 = 0.0f;
+        unsigned xpos = 0u;  // bit j: the LayerNorm input of column lane + 64 j is > 0 (in_relu_scale)
 #pragma unroll
         for (int j = 0; j < LNF_NV; j++) {
             const int64_t c = lane + 64 * j;
             g[j] = 0.0f;
             xh[j] = 0.0f;
             if (c < N) {
-                xh[j] = (x[row * N + c] - mu) * rs;
+                const float xraw = x[row * N + c];
+                if (xraw > 0.0f) xpos |= 1u << j;
+                xh[j] = (xraw - mu) * rs;
                 float gv = gy[row * N + c];
-                if (mask != nullptr) gv = gv * (mask[row * N + c] * scale);
-                if (relu && !(xh[j] * ga[j] + be[j] > 0.0f)) gv = 0.0f;
+                if (yout != nullptr) {
+                    if (relu) gv = yout[row * N + c] > 0.0f ? gv * scale : 0.0f;
+                } else {
+                    if (mask != nullptr) gv = gv * (mask[row * N + c] * scale);
+                    if (relu && !(xh[j] * ga[j] + be[j] > 0.0f)) gv = 0.0f;
+                }
                 g[j] = gv;
                 const float dy = gv * ga[j];
                 s1 += dy;
@@ -291,7 +302,11 @@ __device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*re
         for (int j = 0; j < LNF_NV; j++) {
             const int64_t c = lane + 64 * j;
             if (c < N) {
-                if (gx != nullptr) gx[row * N + c] = rs * ((g[j] * ga[j] - s1) - xh[j] * s2);
+                if (gx != nullptr) {
+                    float o = rs * ((g[j] * ga[j] - s1) - xh[j] * s2);
+                    if (in_relu_scale != 0.0f) o = ((xpos >> j) & 1u) ? o * in_relu_scale : 0.0f;
+                    gx[row * N + c] = o;
+                }
                 sg[j] += g[j] * xh[j];
                 sb[j] += g[j];
             }
@@ -319,9 +334,10 @@ __device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*re
 
 __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *gy, const float *x, const float *gamma, const float *beta,
                                                                   const float *mean, const float *rstd, int64_t M, int64_t N, int relu,
-                                                                  const float *mask, float scale, float *gx, float *part) {
+                                                                  const float *mask, float scale, float *gx, float *part,
+                                                                  const float *yout, float in_relu_scale) {
     __shared__ float red[2][3][64 * LNF_NV];
-    layernorm_bwd_fused_body((int64_t)blockIdx.x, red, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, part);
+    layernorm_bwd_fused_body((int64_t)blockIdx.x, red, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, part, yout, in_relu_scale);
 }
 __global__ __launch_bounds__(256) void layernorm_bwd_fused_group_kernel(LnGroupArgs a) {
     __shared__ float red[2][3][64 * LNF_NV];
@@ -365,6 +381,25 @@ __global__ __launch_bounds__(1024) void layernorm_param_final_kernel(const float
                                                                      float *gbeta, int accumulate) {
     __shared__ float red[2][32][33];
     layernorm_param_final_body((int64_t)blockIdx.x, red, part, chunks, N, ggamma, gbeta, accumulate);
+}
+// the affine-gradient finish of MANY LayerNorms in one launch (all the tag heads' LayerNorms of a step: their partials are complete
+// long before anyone needs gamma / beta gradients, so the 21 finishing launches of a step -- each a 5 us node on its level's chain --
+// become one at the end of the backward)
+constexpr int LN_FINAL_MAX = 32;
+struct LnFinalArgs {
+    int n;
+    int nb[LN_FINAL_MAX];
+    hidvae_ln_final p[LN_FINAL_MAX];
+};
+__global__ __launch_bounds__(1024) void layernorm_param_final_many_kernel(LnFinalArgs a) {
+    __shared__ float red[2][32][33];
+    int bid = blockIdx.x, p = 0;
+    while (p + 1 < a.n && bid >= a.nb[p]) {
+        bid -= a.nb[p];
+        p++;
+    }
+    const hidvae_ln_final &q = a.p[p];
+    layernorm_param_final_body((int64_t)bid, red, q.partials, (q.M + LNF_ROWS - 1) / LNF_ROWS, q.N, q.ggamma, q.gbeta, q.accumulate);
 }
 __global__ __launch_bounds__(1024) void layernorm_param_final_group_kernel(LnGroupArgs a) {
     __shared__ float red[2][32][33];
@@ -1071,11 +1106,43 @@ extern "C" int hidvae_layernorm_bwd_all(const float *gy, const float *x, const f
     const int64_t chunks = hv_cdiv(M, LNF_ROWS);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(layernorm_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 0, s, gy, x, gamma, beta, mean, rstd, M, N, relu,
-                       keep_mask, keep_scale, gx, workspace);
+                       keep_mask, keep_scale, gx, workspace, (const float *)nullptr, 0.0f);
     HV_LAUNCH_CHECK("layernorm_bwd_fused");
     hipLaunchKernelGGL(layernorm_param_final_kernel, dim3((unsigned)hv_cdiv(N, 32)), dim3(1024), 0, s, workspace, chunks, N, ggamma,
                        gbeta, accumulate);
     HV_LAUNCH_CHECK("layernorm_param_final");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_layernorm_bwd_partial(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
+                                            const float *rstd, int64_t M, int64_t N, int relu, const float *y_out, float keep_scale,
+                                            float in_relu_scale, float *gx, float *partials, void *stream) {
+    HV_REQUIRE(gy && x && gamma && beta && mean && rstd && partials && M >= 1 && N >= 1, "layernorm_bwd_partial: bad arguments");
+    HV_REQUIRE(N <= 64 * LNF_NV, "layernorm_bwd_partial: N=%lld exceeds the register-resident form (%d)", (long long)N, 64 * LNF_NV);
+    HV_REQUIRE(!relu || y_out != nullptr, "layernorm_bwd_partial: the ReLU gate is read off the forward output");
+    const int64_t chunks = hv_cdiv(M, LNF_ROWS);
+    hipLaunchKernelGGL(layernorm_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, gy, x, gamma, beta, mean, rstd,
+                       M, N, relu, (const float *)nullptr, keep_scale, gx, partials, y_out, in_relu_scale);
+    HV_LAUNCH_CHECK("layernorm_bwd_partial");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_layernorm_param_final_many(const hidvae_ln_final *pr, int n, void *stream) {
+    HV_REQUIRE(pr != nullptr && n >= 1, "layernorm_param_final_many: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += LN_FINAL_MAX) {
+        LnFinalArgs a{};
+        a.n = (n - i0 < LN_FINAL_MAX) ? n - i0 : LN_FINAL_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.n; i++) {
+            const hidvae_ln_final &q = pr[i0 + i];
+            HV_REQUIRE(q.partials && q.ggamma && q.gbeta && q.M >= 1 && q.N >= 1 && q.N <= 64 * LNF_NV, "layernorm_param_final_many: problem %d is malformed", i0 + i);
+            a.p[i] = q;
+            a.nb[i] = (int)hv_cdiv(q.N, 32);
+            blocks += a.nb[i];
+        }
+        hipLaunchKernelGGL(layernorm_param_final_many_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, a);
+        HV_LAUNCH_CHECK("layernorm_param_final_many");
+    }
     return HIDVAE_OK;
 }
 

@@ -454,10 +454,16 @@ class SqDiffRowsFn(Function):
 class LinearFn(Function):
     """y = act(x W^T + b) [* keep_mask * keep_scale]  -- nn.Linear with the activation (and dropout) fused into the GEMM
     epilogue.  act is an _C.EPI_* forward code.  Backward: g_pre = g * act'(.) through the elementwise kernel, then the
-    input gradient (NN GEMM) and weight gradient (TN GEMM, split-K) in one paired launch, bias gradient (column sums)."""
+    input gradient (NN GEMM) and weight gradient (TN GEMM, split-K) in one paired launch, bias gradient (column sums).
+    Two statically wired fusions for chains (the caller, who composes the chain, sets them -- both need the tensor in question to
+    have exactly ONE consumer):
+      act_bwd_done  the incoming gradient was already taken through THIS layer's activation / dropout by whoever produced it (the
+                    next layer's input-gradient epilogue, or the LayerNorm backward that follows): no elementwise launch here;
+      dx_gate       scale s: the INPUT x of this layer is relu(.) * keep * s (the previous Linear -> ReLU -> Dropout), and the input
+                    gradient leaves this launch already through that gate, (g W) * (x > 0 ? s : 0)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, keep_mask=None, keep_scale=1.0):
+    def forward(ctx, x, w, b, act, keep_mask=None, keep_scale=1.0, act_bwd_done=False, dx_gate=None):
         ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad)
         pre = None
@@ -468,26 +474,28 @@ class LinearFn(Function):
         ctx.has_bias = b is not None
         ctx.w_param, ctx.b_param = w, b  # (the objects themselves: a flat-gradient slot hangs off the Parameter)
         ctx.need_x = ctx.needs_input_grad[0]
+        ctx.act_bwd_done, ctx.dx_gate = bool(act_bwd_done), dx_gate
         ctx.save_for_backward(x, w, pre if pre is not None else y, keep_mask)
         return y
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return None, None, None, None, None, None
+            return (None,) * 8
         x, w, ref, keep_mask = ctx.saved_tensors
         g = g.contiguous()
-        if ctx.act != _C.EPI_NONE or keep_mask is not None:
+        if not ctx.act_bwd_done and (ctx.act != _C.EPI_NONE or keep_mask is not None):
             g = _C.act_bwd(g, ref, ctx.act, keep_mask, ctx.keep_scale)
+        epi, aux, dxs = (_C.EPI_DRELU, x, float(ctx.dx_gate)) if (ctx.dx_gate is not None and ctx.need_x) else (_C.EPI_NONE, None, 1.0)
         dst, acc = grad_sink(ctx.w_param)
         if ctx.has_bias:  # weight, input and bias gradients share one launch
             bdst, bacc = grad_sink(ctx.b_param)
-            gw, gx, gb = _C.linear_bwd(g, x, w, ctx.need_x, dW=dst, accumulate=acc, bias=True, db=bdst, accumulate_db=bacc)
+            gw, gx, gb = _C.linear_bwd(g, x, w, ctx.need_x, epi, aux, dW=dst, accumulate=acc, bias=True, db=bdst, accumulate_db=bacc, dx_scale=dxs)
             if bdst is not None:
                 gb = None
         else:
-            gw, gx = _C.linear_bwd(g, x, w, ctx.need_x, dW=dst, accumulate=acc)
+            gw, gx = _C.linear_bwd(g, x, w, ctx.need_x, epi, aux, dW=dst, accumulate=acc, dx_scale=dxs)
             gb = None
         if dst is not None:
             gw = None
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None, None

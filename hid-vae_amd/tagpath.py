@@ -68,35 +68,144 @@ class AddFn(Function):
         return g, g
 
 
+_LN_PENDING = []  # (stream, partials, M, N, gamma Parameter, beta Parameter) of LayerNorm backwards whose affine gradients are not finished yet
+
+
+def _param_grad_slot(p):
+    """-> (dst, accumulate): where a parameter's gradient is written directly -- its flat-buffer slot (ops.grad_sink), else its .grad
+    (created here on first use: these gradients do not travel through autograd's AccumulateGrad)"""
+    from .ops import grad_sink
+    dst, acc = grad_sink(p)
+    if dst is not None:
+        return dst, acc
+    if p.grad is None:
+        p.grad = torch.empty_like(p)
+        return p.grad, False
+    return p.grad, True
+
+
+def flush_layernorm_finals():
+    """ONE launch finishing the affine gradients (d gamma, d beta) of every LayerNorm backward issued since the last flush
+    (hidvae_layernorm_param_final_many).  Queued as an end-of-backward callback by LayerNormFn; runs on the stream backward() was
+    called on, after making it wait for the streams the partial sums were produced on."""
+    global _LN_PENDING
+    pend, _LN_PENDING = _LN_PENDING, []
+    if not pend:
+        return
+    main = torch.cuda.current_stream()
+    seen = set()
+    for st, part, *_ in pend:
+        if st.cuda_stream != main.cuda_stream and st.cuda_stream not in seen:
+            seen.add(st.cuda_stream)
+            main.wait_stream(st)
+        part.record_stream(main)
+    # one launch per ROUND: a parameter that several backward nodes contribute to (gradient accumulation: the same LayerNorm in two
+    # micro-batches' graphs) is written by one problem per launch, in arrival order -- two problems of one launch adding into the same
+    # destination would race
+    rounds = []
+    seen_in_round = []
+    with torch.no_grad():
+        for _, part, M, N, gp, bp in pend:
+            r = 0
+            while r < len(rounds) and id(gp) in seen_in_round[r]:
+                r += 1
+            if r == len(rounds):
+                rounds.append([])
+                seen_in_round.append(set())
+            seen_in_round[r].add(id(gp))
+            rounds[r].append((part, M, N, gp, bp))
+        for probs in rounds:
+            launch = []
+            for part, M, N, gp, bp in probs:
+                gdst, gacc = _param_grad_slot(gp)
+                bdst, bacc = _param_grad_slot(bp)
+                if gacc != bacc:  # (cannot happen for a LayerNorm's own pair; kept exact anyway)
+                    (gdst if not gacc else bdst).zero_()
+                    gacc = bacc = True
+                launch.append((part, M, N, gdst, bdst, gacc))
+            _C.layernorm_param_final_many(launch)
+
+
 class LayerNormFn(Function):
-    """y = dropout(relu?(LayerNorm(x))) + residual in one launch."""
+    """y = dropout(relu?(LayerNorm(x))) + residual in one launch.
+    Backward: ONE launch for gx and the per-4-row partial sums of (d gamma, d beta); the partials of all LayerNorms of a backward pass
+    are finished by one launch at its end (flush_layernorm_finals) and written straight into the parameters' gradient slots.  The
+    ReLU -> Dropout gate is read off the saved OUTPUT y (> 0 exactly where the unit was active and kept), so no keep-mask is kept for
+    the backward.  in_relu_scale != 0: the input x is itself the output of Linear -> ReLU -> Dropout(in_relu_scale) with this
+    LayerNorm as its only consumer, and gx is returned already taken through that gate (that Linear is built with act_bwd_done)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, mask, mask_scale, residual):
+    def forward(ctx, x, gamma, beta, eps, relu, mask, mask_scale, residual, in_relu_scale=0.0):
         ctx.set_materialize_grads(False)
         y, mean, rstd = _C.layernorm_fwd(x, gamma, beta, eps, relu, mask, mask_scale, residual)
-        ctx.save_for_backward(x, gamma, beta, mean, rstd, mask)
-        ctx.cfg = (relu, mask_scale, residual is not None)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, y if relu else None)
+        ctx.cfg = (relu, float(mask_scale) if mask is not None else 1.0, residual is not None, float(in_relu_scale))
         ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
 
     @staticmethod
     def backward(ctx, gy):
         if gy is None:
-            return (None,) * 8
-        x, gamma, beta, mean, rstd, mask = ctx.saved_tensors
-        relu, mask_scale, has_res = ctx.cfg
+            return (None,) * 9
+        x, gamma, beta, mean, rstd, y = ctx.saved_tensors
+        relu, scale, has_res, in_relu_scale = ctx.cfg
         gy = gy.contiguous()
+        if x.shape[1] > 1024:  # rows too wide for the register-resident kernel: the two-launch form, gradients through autograd
+            from .ops import grad_sink
+            gdst, gacc = grad_sink(ctx.gamma_param)
+            bdst, bacc = grad_sink(ctx.beta_param)
+            if gdst is None or bdst is None or gacc != bacc:
+                gdst = bdst = None
+            gate = None if y is None else (y > 0).to(x.dtype)
+            gx, gg, gb = _C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, gate, scale, need_gx=ctx.needs_input_grad[0],
+                                              gg=gdst, gb=bdst, accumulate=gacc)
+            if in_relu_scale != 0.0 and gx is not None:
+                gx = _C.act_bwd(gx, x, _C.EPI_RELU, x, in_relu_scale)
+            if gdst is not None:
+                gg = gb = None
+            return gx, gg, gb, None, None, None, None, (gy if has_res else None), None
+        gx, part = _C.layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y, scale, in_relu_scale, need_gx=ctx.needs_input_grad[0])
+        if not _LN_PENDING:
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(flush_layernorm_finals)
+        _LN_PENDING.append((torch.cuda.current_stream(), part, x.shape[0], x.shape[1], ctx.gamma_param, ctx.beta_param))
+        return gx, None, None, None, None, None, None, (gy if has_res else None), None
+
+
+class GateFn(Function):
+    """TagPredictor's attention gate (h_rqvae.py:128-139, :196-206) as one launch each way (_C.gate_fwd / _C.gate_bwd) plus one grouped
+    launch for the three Linears' weight and bias gradients.  x: the level's concat-embedding view [B, E] (a column prefix of
+    emb_cat); the returned gradient covers BOTH uses of x (attention input and gate input)."""
+
+    @staticmethod
+    def forward(ctx, x, W0, b0, W2, b2, W4, b4, normalize):
+        ctx.set_materialize_grads(False)
+        h, saved = _C.gate_fwd(x, W0, b0, W2, b2, W4, b4, normalize)
+        a1, pre2, a2, a3, nrm = saved
+        ctx.save_for_backward(x, W0, W2, W4, a1, pre2, a2, a3, nrm)
+        ctx.normalize = bool(normalize)
+        ctx.params = (W0, b0, W2, b2, W4, b4)
+        ctx.need_x = ctx.needs_input_grad[0]
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        if gh is None:
+            return (None,) * 8
         from .ops import grad_sink
-        gdst, gacc = grad_sink(ctx.gamma_param)
-        bdst, bacc = grad_sink(ctx.beta_param)
-        if gdst is None or bdst is None or gacc != bacc:
-            gdst = bdst = None
-        gx, gg, gb = _C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, need_gx=ctx.needs_input_grad[0],
-                                          gg=gdst, gb=bdst, accumulate=gacc)
-        if gdst is not None:
-            gg = gb = None
-        return gx, gg, gb, None, None, None, None, (gy if has_res else None)
+        x, W0, W2, W4, a1, pre2, a2, a3, nrm = ctx.saved_tensors
+        gx, g3, g2, g1 = _C.gate_bwd(gh.contiguous(), x, W0, W2, W4, ctx.normalize, (a1, pre2, a2, a3, nrm))
+        probs, sunk = [], []
+        for g, inp, wp, bp in ((g1, x, ctx.params[0], ctx.params[1]), (g2, a1, ctx.params[2], ctx.params[3]), (g3, a2, ctx.params[4], ctx.params[5])):
+            dst, acc = grad_sink(wp)
+            bdst, bacc = grad_sink(bp)
+            probs.append(dict(g=g, x=inp, w=wp, need_dx=False, dW=dst, accumulate=acc, bias=True, db=bdst, accumulate_db=bacc))
+            sunk.append((dst is not None, bdst is not None))
+        res = _C.linear_bwd_group(probs)
+        out = [gx if ctx.need_x else None]
+        for (dW, _, db), (ws, bs) in zip(res, sunk):
+            out += [None if ws else dW, None if bs else db]
+        return tuple(out) + (None,)
 
 
 class BatchNormFn(Function):
@@ -216,119 +325,9 @@ class TagPredLossFn(Function):
         return (_C.tag_loss_bwd(dmix, dkl, target, inverse, lam, g.contiguous(), nv),) + (None,) * 9
 
 
-class GroupLinearFn(Function):
-    """The same Linear layer of several heads in ONE launch each way (hidvae_gemm_group / hidvae_linear_bwd_group).
-    apply(cfgs, *flat) with cfgs = [(act, keep_scale)] per problem and flat = (x, w, b, keep_mask) per problem -> tuple of y.
-    Per problem exactly LinearFn's arithmetic: y = act(x W^T + b) [* mask * scale]; backward g' = g * act'(.) * mask*scale (one
-    grouped elementwise launch for the problems that need it), then every dW / dX / db of the group from one grid."""
-
-    @staticmethod
-    def forward(ctx, cfgs, *flat):
-        ctx.set_materialize_grads(False)
-        n = len(cfgs)
-        probs, pres = [], []
-        for i, (act, scale) in enumerate(cfgs):
-            x, w, b, mask = flat[4 * i: 4 * i + 4]
-            need = any(ctx.needs_input_grad[1 + 4 * i: 1 + 4 * i + 3])
-            pre = None
-            if need and act in (_C.EPI_SILU, _C.EPI_GELU):
-                pre = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32)
-            pres.append(pre)
-            probs.append(dict(layout=_C.GEMM_NT, A=x, B=w, bias=b, epilogue=act, aux=pre, mask=mask, mask_scale=scale))
-        ys = _C.gemm_group(probs)
-        ctx.cfgs = cfgs
-        ctx.params = [(flat[4 * i + 1], flat[4 * i + 2]) for i in range(n)]  # (the objects: a flat-gradient slot hangs off the Parameter)
-        ctx.need_x = [ctx.needs_input_grad[1 + 4 * i] for i in range(n)]
-        saved = []
-        for i in range(n):
-            x, w, b, mask = flat[4 * i: 4 * i + 4]
-            saved += [x, w, pres[i] if pres[i] is not None else ys[i], mask]
-        ctx.save_for_backward(*saved)
-        return tuple(ys)
-
-    @staticmethod
-    def backward(ctx, *gs):
-        from .ops import grad_sink
-        n = len(ctx.cfgs)
-        saved = ctx.saved_tensors
-        live = [i for i in range(n) if gs[i] is not None]
-        g = {i: gs[i].contiguous() for i in live}
-        todo = [i for i in live if ctx.cfgs[i][0] != _C.EPI_NONE or saved[4 * i + 3] is not None]
-        if todo:
-            outs = _C.act_bwd_group([(g[i], saved[4 * i + 2], ctx.cfgs[i][0], saved[4 * i + 3], ctx.cfgs[i][1]) for i in todo])
-            for i, o in zip(todo, outs):
-                g[i] = o
-        probs, sinks = [], []
-        for i in live:
-            x, w = saved[4 * i], saved[4 * i + 1]
-            wp, bp = ctx.params[i]
-            dst, acc = grad_sink(wp)
-            pr = dict(g=g[i], x=x, w=w, need_dx=ctx.need_x[i], dW=dst, accumulate=acc)
-            bdst = None
-            if bp is not None:
-                bdst, bacc = grad_sink(bp)
-                pr.update(bias=True, db=bdst, accumulate_db=bacc)
-            probs.append(pr)
-            sinks.append((dst is not None, bdst is not None))
-        res = _C.linear_bwd_group(probs) if probs else []
-        out = [None] * (1 + 4 * n)
-        for i, (dW, dX, db), (wsunk, bsunk) in zip(live, res, sinks):
-            out[1 + 4 * i] = dX
-            out[2 + 4 * i] = None if wsunk else dW
-            out[3 + 4 * i] = None if (bsunk or ctx.params[i][1] is None) else db
-        return tuple(out)
-
-
-class GroupLayerNormFn(Function):
-    """LayerNormFn for several heads at once: y = dropout(relu?(LN(x))) + residual, one launch forward, two backward.
-    apply(cfgs, *flat): cfgs = [(eps, relu, mask_scale)], flat = (x, gamma, beta, keep_mask, residual) per problem."""
-
-    @staticmethod
-    def forward(ctx, cfgs, *flat):
-        ctx.set_materialize_grads(False)
-        n = len(cfgs)
-        outs = _C.layernorm_fwd_group([(flat[5 * i], flat[5 * i + 1], flat[5 * i + 2], cfgs[i][0], cfgs[i][1], flat[5 * i + 3], cfgs[i][2],
-                                        flat[5 * i + 4]) for i in range(n)])
-        saved = []
-        for i in range(n):
-            saved += [flat[5 * i], flat[5 * i + 1], flat[5 * i + 2], outs[i][1], outs[i][2], flat[5 * i + 3]]
-        ctx.save_for_backward(*saved)
-        ctx.cfgs = cfgs
-        ctx.params = [(flat[5 * i + 1], flat[5 * i + 2]) for i in range(n)]
-        ctx.has_res = [flat[5 * i + 4] is not None for i in range(n)]
-        ctx.need_x = [ctx.needs_input_grad[1 + 5 * i] for i in range(n)]
-        return tuple(o[0] for o in outs)
-
-    @staticmethod
-    def backward(ctx, *gys):
-        from .ops import grad_sink
-        n = len(ctx.cfgs)
-        saved = ctx.saved_tensors
-        live = [i for i in range(n) if gys[i] is not None]
-        probs, sunk, gyc = [], [], {}
-        for i in live:
-            x, gamma, beta, mean, rstd, mask = saved[6 * i: 6 * i + 6]
-            gyc[i] = gys[i].contiguous()
-            gdst, gacc = grad_sink(ctx.params[i][0])
-            bdst, bacc = grad_sink(ctx.params[i][1])
-            if gdst is None or bdst is None or gacc != bacc:
-                gdst = bdst = None
-            probs.append(dict(gy=gyc[i], x=x, gamma=gamma, beta=beta, mean=mean, rstd=rstd, relu=ctx.cfgs[i][1], mask=mask,
-                              mask_scale=ctx.cfgs[i][2], need_gx=ctx.need_x[i], gg=gdst, gb=bdst, accumulate=gacc))
-            sunk.append(gdst is not None)
-        res = _C.layernorm_bwd_all_group(probs) if probs else []
-        out = [None] * (1 + 5 * n)
-        for i, (gx, gg, gb), sk in zip(live, res, sunk):
-            out[1 + 5 * i] = gx
-            out[2 + 5 * i] = None if sk else gg
-            out[3 + 5 * i] = None if sk else gb
-            out[5 + 5 * i] = gyc[i] if ctx.has_res[i] else None
-        return tuple(out)
-
-
 # ------------------------------------------------------------------------------------------------ compositions
-def _lin(x, m, act=_C.EPI_NONE, mask=None, scale=1.0):
-    return LinearFn.apply(x, m.weight, m.bias, act, mask, scale)
+def _lin(x, m, act=_C.EPI_NONE, mask=None, scale=1.0, act_bwd_done=False, dx_gate=None):
+    return LinearFn.apply(x, m.weight, m.bias, act, mask, scale, act_bwd_done, dx_gate)
 
 
 def _mask(rand, shape, p, device, training):
@@ -337,12 +336,13 @@ def _mask(rand, shape, p, device, training):
     return rand.dropout_keep(shape, p, device), _keep_scale(p)
 
 
-def _lin_norm_relu_drop(x, lin, norm, p, rand, training):
-    """Linear -> (LayerNorm) -> ReLU -> Dropout as two launches (GEMM+bias, LN+ReLU+mask) or one (GEMM+bias+ReLU+mask)."""
+def _lin_norm_relu_drop(x, lin, norm, p, rand, training, in_gate=None):
+    """Linear -> (LayerNorm) -> ReLU -> Dropout as two launches (GEMM+bias, LN+ReLU+mask) or one (GEMM+bias+ReLU+mask).
+    -> (y, scale): y = relu(.) * keep * scale."""
     mask, scale = _mask(rand, (x.shape[0], lin.out_features), p, x.device, training)
     if isinstance(norm, nn.LayerNorm):
-        return LayerNormFn.apply(_lin(x, lin), norm.weight, norm.bias, norm.eps, True, mask, scale, None)
-    return _lin(x, lin, _C.EPI_RELU, mask, scale)
+        return LayerNormFn.apply(_lin(x, lin, dx_gate=in_gate), norm.weight, norm.bias, norm.eps, True, mask, scale, None), scale
+    return _lin(x, lin, _C.EPI_RELU, mask, scale, dx_gate=in_gate), scale
 
 
 def tag_projector_forward(seq, t, training, rand):
@@ -360,34 +360,40 @@ def tag_projector_forward(seq, t, training, rand):
 
 
 def tag_predictor_forward(pred, x, x_gate=None, rand=None):
-    """pred: modules.h_rqvae.TagPredictor; x (and x_gate, the same data as a second autograd leaf of the fan-out)."""
+    """pred: modules.h_rqvae.TagPredictor; x: [batch, embed_dim] (x_gate: accepted for older callers, the same data as x).
+    Launches per call, forward: the gate 1, then GEMM (+ LayerNorm) per layer; backward: every activation / dropout gate rides in the
+    launch that produces the gradient it applies to (LayerNorm backward or the next layer's input-gradient epilogue), and the
+    LayerNorms' affine gradients are finished by one launch per backward pass."""
     from .rand import DeviceRand
     rand = rand or pred.rand or DeviceRand()
     training = pred.training
     if x.dim() != 2:
         raise RuntimeError("TagPredictor expects [batch, embed_dim]")
-    x_gate = x if x_gate is None else x_gate
     att = pred.attention
-    a = _lin(_lin(_lin(x, att[0], _C.EPI_RELU), att[2], _C.EPI_GELU), att[4], _C.EPI_SIGMOID)
-    h = MulFn.apply(x_gate, a)
-    if pred.apply_norm:
-        h = L2NormFn.apply(h, 1e-12)
+    E = x.shape[1]
+    if E % 4 == 0 and E <= 128:
+        h = GateFn.apply(x, att[0].weight, att[0].bias, att[2].weight, att[2].bias, att[4].weight, att[4].bias, bool(pred.apply_norm))
+    else:  # widths the row-local gate kernel does not take: the layer-by-layer form
+        a = _lin(_lin(_lin(x, att[0], _C.EPI_RELU), att[2], _C.EPI_GELU), att[4], _C.EPI_SIGMOID)
+        h = MulFn.apply(x if x_gate is None else x_gate, a)
+        if pred.apply_norm:
+            h = L2NormFn.apply(h, 1e-12)
     p = pred.dropout_p
     fe = pred.feature_extractor
-    f = _lin_norm_relu_drop(h, fe[0], fe[1], p, rand, training)
+    f, _ = _lin_norm_relu_drop(h, fe[0], fe[1], p, rand, training)
     for rb in (pred.residual_block1, pred.residual_block2):
-        r = _lin_norm_relu_drop(f, rb[0], rb[1], p, rand, training)
+        r, _ = _lin_norm_relu_drop(f, rb[0], rb[1], p, rand, training)
         mask, scale = _mask(rand, (r.shape[0], rb[4].out_features), p, r.device, training)
-        r = _lin(r, rb[4], _C.EPI_RELU, mask, scale)
-        if isinstance(rb[7], nn.LayerNorm):
-            f = LayerNormFn.apply(r, rb[7].weight, rb[7].bias, rb[7].eps, False, None, 1.0, f)  # LN(r) + f in one launch
+        if isinstance(rb[7], nn.LayerNorm):  # Linear -> ReLU -> Dropout -> LayerNorm (+ f): the LayerNorm backward applies the gate
+            r = _lin(r, rb[4], _C.EPI_RELU, mask, scale, act_bwd_done=True)
+            f = LayerNormFn.apply(r, rb[7].weight, rb[7].bias, rb[7].eps, False, None, 1.0, f, scale)  # LN(r) + f in one launch
         else:
-            f = AddFn.apply(f, r)
+            f = AddFn.apply(f, _lin(r, rb[4], _C.EPI_RELU, mask, scale))
     cl = pred.classifier
-    c = _lin_norm_relu_drop(f, cl[0], cl[1], p, rand, training)
+    c, _ = _lin_norm_relu_drop(f, cl[0], cl[1], p, rand, training)
     mask, scale = _mask(rand, (c.shape[0], cl[4].out_features), p * 0.5, c.device, training)
-    c = _lin(c, cl[4], _C.EPI_RELU, mask, scale)
-    return _lin(c, cl[7])
+    c = _lin(c, cl[4], _C.EPI_RELU, mask, scale, act_bwd_done=True)  # its gate rides in the classifier head's input gradient
+    return _lin(c, cl[7], dx_gate=scale)
 
 
 def tag_prediction_loss(loss_mod, logits, target, layer_idx=0, rand=None, level=None):
@@ -430,7 +436,7 @@ def early_rand(rand, targets, device, n_levels, want_mixup):
     generator is advanced in the same order as before (masks, then pairing), so the draws are the same numbers.
     Only with every level on a stream of its own (HIDVAE_TAG_STREAMS=2); tag_heads_forward makes the other levels wait for them.
     -> True if the draws were issued here."""
-    if os.environ.get("HIDVAE_TAG_STREAMS", "2") != "2" or os.environ.get("HIDVAE_TAG_GROUPED", "0") == "1" or n_levels < 2 or n_levels > 4:
+    if os.environ.get("HIDVAE_TAG_STREAMS", "2") != "2" or n_levels < 2 or n_levels > 4:
         return False
     st = _tag_streams(device, n_levels + 1)
     main = torch.cuda.current_stream()
@@ -451,121 +457,17 @@ def early_rand(rand, targets, device, n_levels, want_mixup):
     return True
 
 
-def _glin(xs, mods, act=_C.EPI_NONE, masks=None, scales=None):
-    """the same Linear of every head in one launch: xs / mods / masks lists over the heads"""
-    n = len(xs)
-    masks = masks or [None] * n
-    scales = scales or [1.0] * n
-    flat = []
-    for x, m, k in zip(xs, mods, masks):
-        flat += [x, m.weight, m.bias, k]
-    return list(GroupLinearFn.apply([(act, sc) for sc in scales], *flat))
-
-
-def _glin_norm_relu_drop(xs, lins, norms, masks, scales):
-    """Linear -> (LayerNorm) -> ReLU -> Dropout of every head: two grouped launches (GEMM+bias, LN+ReLU+mask) or one"""
-    if isinstance(norms[0], nn.LayerNorm):
-        hs = _glin(xs, lins)
-        flat = []
-        for h, nm, k in zip(hs, norms, masks):
-            flat += [h, nm.weight, nm.bias, k, None]
-        return list(GroupLayerNormFn.apply([(nm.eps, True, sc) for nm, sc in zip(norms, scales)], *flat))
-    return _glin(xs, lins, _C.EPI_RELU, masks, scales)
-
-
-def tag_heads_forward_grouped(model, emb_cat, tags_emb, tags_indices):
-    """tag_heads_forward with the L levels advanced in LOCKSTEP on one stream: every layer position is ONE grouped launch for all
-    levels (hidvae_gemm_group / hidvae_linear_bwd_group / hidvae_layernorm_*_group) instead of one launch per level.  The levels'
-    heads are structurally identical chains of different widths (h_rqvae.py:108-227, 322-331), small problems whose launch and
-    drain latencies then hide under the widest level's arithmetic.  Random draws are requested level by level in the reference's
-    order first (dropout masks in forward order, then the mixup pairing), so injected / replayed randomness is unchanged."""
-    L, D = model.n_layers, model.embed_dim
-    rand = model._rand()
-    training = model.training
-    B = emb_cat.shape[0]
-    dev = emb_cat.device
-    views = ConcatViewsFn.apply(emb_cat, L, D, 3)
-    te = tags_emb.reshape(B, -1)
-    E = model.tag_embed_dim
-    lm = model.tag_prediction_loss
-    preds_m, projs_m = list(model.tag_predictors), list(model.tag_projectors)
-    if training and torch.is_grad_enabled() and lm.use_mixup and B > 1 and hasattr(rand, "prepare_mixup"):
-        rand.prepare_mixup(tags_indices[:, :L], dev)
-    # ---- the step's random draws, level by level in the reference's order
-    plan = []
-    for i in range(L):
-        pj, pd = projs_m[i], preds_m[i]
-        p = pd.dropout_p
-        mid, hid, half = pd.residual_block1[0].out_features, pd.feature_extractor[0].out_features, pd.classifier[4].out_features
-        sites = [("proj", pj[0].out_features, pj[3].p), ("fe", hid, p), ("rb1a", mid, p), ("rb1b", hid, p), ("rb2a", mid, p), ("rb2b", hid, p),
-                 ("cla", mid, p), ("clb", half, p * 0.5)]
-        plan.append({name: _mask(rand, (B, width), pp, dev, training) for name, width, pp in sites})
-    mk = lambda name: ([plan[i][name][0] for i in range(L)], [plan[i][name][1] for i in range(L)])
-    # ---- projectors (Linear -> BatchNorm1d -> ReLU -> Dropout -> Linear -> LayerNorm)
-    tes = [te[:, i * E:(i + 1) * E] for i in range(L)]
-    masks, scales = mk("proj")
-    if isinstance(projs_m[0][1], nn.BatchNorm1d):
-        hs = _glin(tes, [pj[0] for pj in projs_m])
-        hs = [BatchNormFn.apply(h, pj[1].weight, pj[1].bias, pj[1].running_mean, pj[1].running_var, pj[1].num_batches_tracked, pj[1].momentum,
-                                pj[1].eps, training, True, k, sc) for h, pj, k, sc in zip(hs, projs_m, masks, scales)]
-    else:
-        hs = _glin(tes, [pj[0] for pj in projs_m], _C.EPI_RELU, masks, scales)
-    hs = _glin(hs, [pj[4] for pj in projs_m])
-    if isinstance(projs_m[0][5], nn.LayerNorm):
-        flat = []
-        for h, pj in zip(hs, projs_m):
-            flat += [h, pj[5].weight, pj[5].bias, None, None]
-        hs = list(GroupLayerNormFn.apply([(pj[5].eps, False, 1.0) for pj in projs_m], *flat))
-    aligns = [model.tag_alignment_loss(views[3 * i], hs[i], i) for i in range(L)]
-    # ---- predictors
-    for pd in preds_m:
-        if views[0].dim() != 2:
-            raise RuntimeError("TagPredictor expects [batch, embed_dim]")
-    c_att = [views[3 * i + 1] for i in range(L)]
-    a = _glin(c_att, [pd.attention[0] for pd in preds_m], _C.EPI_RELU)
-    a = _glin(a, [pd.attention[2] for pd in preds_m], _C.EPI_GELU)
-    a = _glin(a, [pd.attention[4] for pd in preds_m], _C.EPI_SIGMOID)
-    hh = [MulFn.apply(views[3 * i + 2], a[i]) for i in range(L)]
-    hh = [L2NormFn.apply(h, 1e-12) if pd.apply_norm else h for h, pd in zip(hh, preds_m)]
-    f = _glin_norm_relu_drop(hh, [pd.feature_extractor[0] for pd in preds_m], [pd.feature_extractor[1] for pd in preds_m], *mk("fe"))
-    for rb_name, ka, kb in (("residual_block1", "rb1a", "rb1b"), ("residual_block2", "rb2a", "rb2b")):
-        rbs = [getattr(pd, rb_name) for pd in preds_m]
-        r = _glin_norm_relu_drop(f, [rb[0] for rb in rbs], [rb[1] for rb in rbs], *mk(ka))
-        r = _glin(r, [rb[4] for rb in rbs], _C.EPI_RELU, *mk(kb))
-        if isinstance(rbs[0][7], nn.LayerNorm):
-            flat = []
-            for ri, rb, fi in zip(r, rbs, f):
-                flat += [ri, rb[7].weight, rb[7].bias, None, fi]  # LN(r) + f in one launch
-            f = list(GroupLayerNormFn.apply([(rb[7].eps, False, 1.0) for rb in rbs], *flat))
-        else:
-            f = [AddFn.apply(fi, ri) for fi, ri in zip(f, r)]
-    cls = [pd.classifier for pd in preds_m]
-    c = _glin_norm_relu_drop(f, [cl[0] for cl in cls], [cl[1] for cl in cls], *mk("cla"))
-    c = _glin(c, [cl[4] for cl in cls], _C.EPI_RELU, *mk("clb"))
-    logits = _glin(c, [cl[7] for cl in cls])
-    preds, accs = [], []
-    for i in range(L):
-        loss, acc = tag_prediction_loss(lm, logits[i], tags_indices[:, i].contiguous(), 0, rand, level=i)
-        preds.append(loss)
-        accs.append(acc)
-    return tuple(aligns) + tuple(preds) + tuple(accs)
-
-
 def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False):
     """-> tuple (A_0..A_{L-1}, P_0..P_{L-1}, acc_0..acc_{L-1}) of 0-d device tensors.
     defer_join: -> (that tuple, join) where join() makes the caller's stream wait for the level branches; the caller issues its own
     work (the decoder) in between, so it runs beside the branches."""
-    # HIDVAE_TAG_GROUPED=1: the lockstep form with grouped launches (119 launches per amazon-shaped step instead of 211).  Measured on
-    # MI355X it is NOT faster than the per-level branches below (B=1024: 2.00 vs 1.97 ms; B=2048: 3.24 vs 3.16 ms): these GEMMs are
-    # bound by L2->CU operand traffic (4.5-6 TB/s in every variant, see DESIGN.md), not by launch latency, so it stays opt-in.
-    if os.environ.get("HIDVAE_TAG_GROUPED", "0") == "1" and 1 < model.n_layers <= 4:
-        out = tag_heads_forward_grouped(model, emb_cat, tags_emb, tags_indices)
-        return (out, (lambda: None)) if defer_join else out
+    # (round 2 also carried a lockstep form with grouped launches -- 119 launches per step instead of 211 -- which was never faster
+    #  than the per-level branches below, 1.96 vs 1.53 ms in round 3: one stream means the sum of the kernel times; it was removed)
     L, D = model.n_layers, model.embed_dim
     rand = model._rand()
     training = model.training
     B = emb_cat.shape[0]
-    views = ConcatViewsFn.apply(emb_cat, L, D, 3)  # three consumers per level: InfoNCE, attention input, gate input
+    views = ConcatViewsFn.apply(emb_cat, L, D, 2)  # two consumers per level: InfoNCE, the predictor (its gate launch covers both uses)
     te = tags_emb.reshape(B, -1)  # [B, L_tags*768]: level i is the column block i (a strided view, no copy)
     E = model.tag_embed_dim
     aligns, preds, accs = [], [], []
@@ -606,12 +508,12 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False):
     for i in range(L):
         st = lvl_stream(i)
         with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
-            c_nce, c_att, c_gate = views[3 * i], views[3 * i + 1], views[3 * i + 2]
+            c_nce, c_att = views[2 * i], views[2 * i + 1]
             _C.phase_mark(f"fwd:level {i} start")
             proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
             align = model.tag_alignment_loss(c_nce, proj, i)
             _C.phase_mark(f"fwd:level {i} projector+infonce done")
-            logits = tag_predictor_forward(model.tag_predictors[i], c_att, c_gate, rand)
+            logits = tag_predictor_forward(model.tag_predictors[i], c_att, None, rand)
             loss, acc = tag_prediction_loss(model.tag_prediction_loss, logits, tags_indices[:, i].contiguous(), 0, rand, level=i)
             _C.phase_mark(f"fwd:level {i} done")
         if st is not None:

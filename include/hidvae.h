@@ -117,10 +117,12 @@ int hidvae_gemm_bf16(int layout, int64_t M, int64_t N, int64_t K, const float *A
  * accumulate_dw: dW += g^T x (gradient accumulation straight into a flat gradient buffer's slot).
  * db (optional): the bias gradient db[n_out] = column sums of g, from the same launch (fixed summation order; the fallback
  * uses hidvae_colsum and needs its workspace of ceil(B/64)*n_out floats when B > 16384).  workspace (optional) is also what lets the
- * unpaired dW product of a LARGE batch (B >= 4096) run as K-slabs on the LDS-tiled kernel: give it max(that, 16*n_out*n_in) floats. */
+ * unpaired dW product of a LARGE batch (B >= 4096) run as K-slabs on the LDS-tiled kernel: give it max(that, 16*n_out*n_in) floats.
+ *   dx_scale  multiplies the HIDVAE_EPI_DRELU result (1.0 elsewhere): the backward through ReLU -> Dropout(keep_scale) read off that
+ *             layer's saved OUTPUT (aux = y = relu(.) * keep * keep_scale; y > 0 exactly where the unit was active and kept). */
 int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
                       int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
-                      int dx_epilogue, float *aux, int64_t ldaux, float *db, int accumulate_db, float *workspace,
+                      int dx_epilogue, float *aux, int64_t ldaux, float dx_scale, float *db, int accumulate_db, float *workspace,
                       void *stream);
 
 /* ---- grouped launches: the SAME layer of several independent heads in one grid (the three tag-head levels of h_rqvae.py:526-549
@@ -359,6 +361,34 @@ int hidvae_layernorm_param_grad(const float *gy, const float *x, const float *ga
 int hidvae_layernorm_bwd_all(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
                              const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask, float keep_scale,
                              float *gx, float *ggamma, float *gbeta, int accumulate, float *workspace, void *stream);
+/* The same backward split at its natural seam, for chains of LayerNorms (the tag heads run 21 per step):
+ *   hidvae_layernorm_bwd_partial       gx + the per-4-row partials of (ggamma, gbeta) into `partials` (2 * ceil(M/4) * N floats, N <= 1024);
+ *                                      y_out (required when relu): the forward OUTPUT y = relu(h) * keep * keep_scale, off which the
+ *                                      ReLU -> Dropout gate is read (y > 0 exactly where the unit was active and kept: no mask, no h);
+ *                                      in_relu_scale != 0: the LayerNorm's INPUT was itself relu(.) * keep * in_relu_scale (Linear -> ReLU ->
+ *                                      Dropout -> LayerNorm, h_rqvae.py:157-162) and gx is returned already taken through that gate
+ *   hidvae_layernorm_param_final_many  the fixed-order finish of MANY such partial sets in ONE launch (n <= 32 per launch; more are
+ *                                      issued in slices): ggamma / gbeta (+)= column sums, same order as hidvae_layernorm_bwd_all */
+typedef struct {
+    const float *partials; int64_t M, N;
+    float *ggamma, *gbeta;
+    int accumulate;
+} hidvae_ln_final;
+int hidvae_layernorm_bwd_partial(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
+                                 const float *rstd, int64_t M, int64_t N, int relu, const float *y_out, float keep_scale,
+                                 float in_relu_scale, float *gx, float *partials, void *stream);
+int hidvae_layernorm_param_final_many(const hidvae_ln_final *problems_host, int n, void *stream);
+/* The attention gate of TagPredictor (h_rqvae.py:128-139, :196-206) as ONE row-local launch each way (E = 32 (i+1) <= 128, a multiple of 4):
+ *   a1 = relu(x W0^T + b0) [B,E/4], a2 = gelu(pre2 = a1 W2^T + b2) [B,E/2], a3 = sigmoid(a2 W4^T + b4) [B,E],
+ *   h = x * a3, divided by max(|h|, eps) per row when normalize (nrm receives |h|)
+ * backward: gx = d/dx through BOTH uses of x (the gate input and the attention input), and g3 / g2 / g1 = the gradients at the three
+ * pre-activations, from which dW_k = g_k^T in_k and db_k = colsum g_k follow (hidvae_linear_bwd_group). */
+int hidvae_gate_fwd(const float *x, int64_t ldx, int64_t B, int E, const float *W0, const float *b0, const float *W2,
+                    const float *b2, const float *W4, const float *b4, int normalize, float eps, float *a1, float *pre2,
+                    float *a2, float *a3, float *h, float *nrm, void *stream);
+int hidvae_gate_bwd(const float *gh, int64_t ldgh, const float *x, int64_t ldx, int64_t B, int E, const float *W0,
+                    const float *W2, const float *W4, int normalize, float eps, const float *a1, const float *pre2,
+                    const float *a3, const float *nrm, float *gx, float *g3, float *g2, float *g1, void *stream);
 /* grouped forms of the three ops above (up to 4 problems per launch; fields as the arguments of hidvae_act_bwd /
  * hidvae_layernorm_fwd / hidvae_layernorm_bwd_all; `workspace` per problem as hidvae_layernorm_bwd_all wants it).  Same arithmetic
  * and summation order per problem as the single-problem entry points: bit-identical results. */

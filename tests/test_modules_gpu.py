@@ -177,3 +177,85 @@ def test_warm_up_forward_at_20000_tagged_items_stays_under_a_gigabyte():
     peak = torch.cuda.max_memory_allocated() - base
     assert torch.isfinite(out.loss) and float(out.tag_align_loss) > 0
     assert peak < 1 << 30, f"warm-up forward peaked {peak / 2**20:.0f} MiB above its inputs"
+
+
+@pytest.mark.parametrize("E,normalize,B", [(32, False, 37), (64, True, 128), (96, True, 1000), (128, True, 9)])
+def test_gate_launch_matches_the_layer_by_layer_gate(E, normalize, B):
+    """TagPredictor's attention gate as ONE row-local launch each way (hidvae_gate_fwd / hidvae_gate_bwd + one grouped launch for the
+    weight gradients) against the composition it replaces (three Linear launches with ReLU / GELU / sigmoid epilogues, the product,
+    F.normalize -- and autograd through them) and against float64 torch: reference h_rqvae.py:128-139, 196-206."""
+    from hidvae_amd.ops import L2NormFn, LinearFn
+    from hidvae_amd.tagpath import GateFn, MulFn
+    from hidvae_amd import _C
+    g = torch.Generator().manual_seed(E + B)
+    mk = lambda *s_: (torch.randn(*s_, generator=g) * 0.3).cuda().requires_grad_()
+    cat = torch.randn(B, 128, generator=g).cuda()  # x is a column-prefix VIEW of a wider buffer, as in the step
+    W0, b0, W2, b2, W4, b4 = mk(E // 4, E), mk(E // 4), mk(E // 2, E // 4), mk(E // 2), mk(E, E // 2), mk(E)
+    gout = torch.randn(B, E, generator=g).cuda()
+
+    def run(fused):
+        for t in (W0, b0, W2, b2, W4, b4):
+            t.grad = None
+        x = cat[:, :E].detach().requires_grad_()  # (a view with row stride 128)
+        xv = x
+        if fused:
+            h = GateFn.apply(xv, W0, b0, W2, b2, W4, b4, normalize)
+        else:
+            a = LinearFn.apply(LinearFn.apply(LinearFn.apply(xv, W0, b0, _C.EPI_RELU), W2, b2, _C.EPI_GELU), W4, b4, _C.EPI_SIGMOID)
+            h = MulFn.apply(xv, a)
+            if normalize:
+                h = L2NormFn.apply(h, 1e-12)
+        h.backward(gout)
+        return h.detach(), x.grad.clone(), [t.grad.clone() for t in (W0, b0, W2, b2, W4, b4)]
+
+    hf, gxf, gpf = run(True)
+    hu, gxu, gpu = run(False)
+    # float64 reference
+    x64 = cat[:, :E].double().cpu().requires_grad_()
+    P64 = [t.detach().double().cpu().requires_grad_() for t in (W0, b0, W2, b2, W4, b4)]
+    a1 = torch.relu(x64 @ P64[0].t() + P64[1])
+    a2 = torch.nn.functional.gelu(a1 @ P64[2].t() + P64[3])
+    a3 = torch.sigmoid(a2 @ P64[4].t() + P64[5])
+    h64 = x64 * a3
+    if normalize:
+        h64 = torch.nn.functional.normalize(h64, dim=-1, eps=1e-12)
+    h64.backward(gout.double().cpu())
+    close = lambda a, b, tol: float((a.double().cpu() - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    assert close(hf, h64.detach(), 2e-6) and close(hu, h64.detach(), 2e-6)
+    assert close(gxf, x64.grad, 5e-6), float((gxf.double().cpu() - x64.grad).abs().max())
+    for got, want in zip(gpf, P64):
+        assert close(got, want.grad, 2e-5 * max(1.0, (B / 256) ** 0.5)), float((got.double().cpu() - want.grad).abs().max())
+    assert close(gxf, gxu.double().cpu(), 5e-6)
+
+
+@pytest.mark.parametrize("M,N,relu,in_gate", [(1000, 691, True, 0.0), (128, 768, False, 1.0 / 0.6), (37, 64, True, 2.0), (4096, 230, False, 0.0)])
+def test_layernorm_backward_split_at_its_seam(M, N, relu, in_gate):
+    """hidvae_layernorm_bwd_partial + hidvae_layernorm_param_final_many (one finishing launch for MANY LayerNorms) against the
+    one-LayerNorm-at-a-time hidvae_layernorm_bwd_all: the ReLU -> Dropout gate read off the forward OUTPUT instead of the keep-mask
+    gives the same bits; the input-side gate (in_relu_scale) equals hidvae_act_bwd applied to gx; the affine gradients are
+    bit-identical (same partials, same summation order), also accumulated into an existing gradient."""
+    from hidvae_amd import _C
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, N, device="cuda", generator=g)
+    if in_gate:
+        x = torch.relu(x) * (torch.rand(M, N, device="cuda", generator=g) < 0.6) * in_gate  # a ReLU -> Dropout output
+    gamma, beta = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    mask = (torch.rand(M, N, device="cuda", generator=g) < 0.6).float() if relu else None
+    scale = 1.0 / 0.6 if relu else 1.0
+    y, mean, rstd = _C.layernorm_fwd(x, gamma, beta, 1e-5, relu, mask, scale, None)
+    gy = torch.randn(M, N, device="cuda", generator=g)
+    gx0, gg0, gb0 = _C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, scale)
+    if in_gate:
+        gx0 = _C.act_bwd(gx0, x, _C.EPI_RELU, x, in_gate)  # (mask pointer only switches the scale on: x > 0 is the gate)
+    gx1, part = _C.layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y if relu else None, scale, in_gate)
+    gg1, gb1 = torch.full((N,), 3.0, device="cuda"), torch.full((N,), -2.0, device="cuda")
+    other = torch.randn(8, 40, device="cuda", generator=g)  # a second, unrelated LayerNorm finished by the same launch
+    oy, om, orr = _C.layernorm_fwd(other, torch.ones(40, device="cuda"), torch.zeros(40, device="cuda"), 1e-5, False, None, 1.0, None)
+    ogy = torch.randn(8, 40, device="cuda", generator=g)
+    _, opart = _C.layernorm_bwd_partial(ogy, other, torch.ones(40, device="cuda"), torch.zeros(40, device="cuda"), om, orr, False, None, 1.0, 0.0)
+    ogg, ogb = torch.empty(40, device="cuda"), torch.empty(40, device="cuda")
+    _C.layernorm_param_final_many([(part, M, N, gg1, gb1, True), (opart, 8, 40, ogg, ogb, False)])
+    assert torch.equal(gx1, gx0)
+    assert torch.equal(gg1, gg0 + 3.0) and torch.equal(gb1, gb0 - 2.0)
+    _, wg, wb = _C.layernorm_bwd_all(ogy, other, torch.ones(40, device="cuda"), torch.zeros(40, device="cuda"), om, orr, False, None, 1.0)
+    assert torch.equal(ogg, wg) and torch.equal(ogb, wb)
