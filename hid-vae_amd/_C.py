@@ -19,10 +19,10 @@ EPI_DSILU, EPI_DRELU, EPI_DGELU, EPI_DSIGMOID = 16, 17, 18, 19
 MAX_LEVELS = 8
 EMBED_DIM = 32
 
-_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_vp, _i, _i64, _f, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
 
 _SIGNATURES = {
-    "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _i, _vp, _i, _vp],
+    "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _vp, _u32, _u32, _i, _vp, _i, _vp],
     "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _f, _vp, _i, _vp, _vp],
     "hidvae_layernorm_bwd_partial": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _f, _vp, _vp, _vp],
     "hidvae_layernorm_param_final_many": [_vp, _i, _vp],
@@ -46,18 +46,20 @@ _SIGNATURES = {
     "hidvae_act_bwd": [_vp, _vp, _i64, _i, _vp, _f, _vp, _vp],
     "hidvae_binary": [_i, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "hidvae_sum_prefix_slices": [_vp, _vp, _i, _i64, _i64, _vp, _vp],
-    "hidvae_layernorm_fwd": [_vp, _i64, _i64, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp],
+    "hidvae_layernorm_fwd": [_vp, _i64, _i64, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _u32, _u32, _vp],
+    "hidvae_rng_advance": [_vp, _vp],
+    "hidvae_dropout_mask": [_vp, _i64, _vp, _u32, _u32, _vp],
     "hidvae_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp],
     "hidvae_layernorm_param_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _i, _vp, _vp],
     "hidvae_layernorm_bwd_all": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp],
-    "hidvae_batchnorm_fwd": [_vp, _i64, _i64, _i64, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp],
-    "hidvae_batchnorm_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp],
+    "hidvae_batchnorm_fwd": [_vp, _i64, _i64, _i64, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _u32, _u32, _vp, _vp],
+    "hidvae_batchnorm_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "hidvae_infonce_rows": [_vp, _i64, _f, _f, _vp, _vp, _vp],
     "hidvae_infonce_dlogits": [_vp, _i64, _f, _f, _vp, _vp],
     "hidvae_infonce_lse_chunk": [_vp, _i64, _i64, _i64, _i64, _f, _vp, _vp, _vp, _i, _vp],
     "hidvae_infonce_lse_finish": [_vp, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp],
     "hidvae_infonce_dlogits_chunk": [_vp, _i64, _i64, _i64, _i64, _f, _f, _vp, _vp, _vp],
-    "hidvae_mixup_plan": [_vp, _i64, _i, _i64, _vp, _f, _vp, _vp, _vp, _vp],
+    "hidvae_mixup_plan": [_vp, _i64, _i, _i64, _vp, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_fwd": [_vp, _i64, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "hidvae_kmeans_iter": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -80,11 +82,7 @@ _SIGNATURES = {
     "hidvae_gumbel_softmax_rows": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
     "hidvae_timestamp": [_vp, _vp],
     "hidvae_gemm_bf16": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _vp, _i64, _i, _vp],
-    "hidvae_gemm_group": [_vp, _i, _vp],
     "hidvae_linear_bwd_group": [_vp, _i, _vp],
-    "hidvae_act_bwd_group": [_vp, _i, _vp],
-    "hidvae_layernorm_fwd_group": [_vp, _i, _vp],
-    "hidvae_layernorm_bwd_all_group": [_vp, _i, _vp],
 }
 WS_GEMM, WS_LINEAR_BWD, WS_COLSUM, WS_CODEBOOK_GRAD, WS_LAYERNORM_PARAM_GRAD, WS_LAYERNORM_BWD_ALL = 1, 2, 3, 4, 5, 6
 WS_BATCHNORM_FWD, WS_BATCHNORM_BWD, WS_ID_CENSUS, WS_KMEANS, WS_TAG_LOSS, WS_LINEAR_BWD_ZEROED, WS_RQ_FORWARD = 7, 8, 9, 10, 11, 12, 13
@@ -400,6 +398,37 @@ def gemm_bf16(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, ac
     return out
 
 
+class DropSpec:
+    """Dropout evaluated INSIDE the launch that produces the activation (include/hidvae.h, hidvae_rng_advance): stands where a keep-mask
+    tensor would.  state: device int64[2] {seed, step}; site: the dropout layer's number within the forward pass; p: drop probability."""
+    __slots__ = ("state", "site", "p")
+
+    def __init__(self, state, site, p):
+        self.state, self.site, self.p = state, int(site), float(p)
+
+    @property
+    def threshold(self):
+        return min(0xFFFFFFFF, int(round(self.p * 4294967296.0)))
+
+
+def _mask_args(mask):
+    """(keep_mask pointer, rng_state pointer, site, threshold) for an entry point that takes either a keep-mask tensor or a DropSpec"""
+    if isinstance(mask, DropSpec):
+        return None, _p(mask.state), mask.site, mask.threshold
+    return _p(mask), None, 0, 0
+
+
+def rng_advance(state):
+    _check(lib().hidvae_rng_advance(_p(state), _stream()), "hidvae_rng_advance")
+
+
+def dropout_mask(spec, shape):
+    """the 0/1 keep-mask a launch given `spec` applies to an activation of this shape (tests; element index = row-major position)"""
+    out = torch.empty(tuple(shape), device=spec.state.device, dtype=torch.float32)
+    _check(lib().hidvae_dropout_mask(_p(out), out.numel(), _p(spec.state), spec.site, spec.threshold, _stream()), "hidvae_dropout_mask")
+    return out
+
+
 def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k=1, accumulate=False, mask=None,
          mask_scale=1.0):
     """C = epilogue(op(A) op(B) + bias).  NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
@@ -407,6 +436,8 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
         Mq, Nq = (A.shape[1] if layout == GEMM_TN else A.shape[0]), (B.shape[0] if layout == GEMM_NT else B.shape[1])
         Kq = A.shape[0] if layout == GEMM_TN else A.shape[1]
         if ((Mq + 31) // 32) * ((Nq + 31) // 32) >= 2048 and Kq >= 64:
+            if isinstance(mask, DropSpec):
+                mask = dropout_mask(mask, (Mq, Nq))
             return gemm_bf16(layout, A, B, out=out, bias=bias, epilogue=epilogue, aux=aux, accumulate=accumulate, mask=mask, mask_scale=mask_scale)
     _f32(A, "A"), _f32(B, "B")
     lda, ldb = _row_stride(A, "A"), _row_stride(B, "B")
@@ -425,9 +456,10 @@ def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k
         out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     ws = _ws(WS_GEMM, A.device, M, N, K, split_k)  # slabs of the LDS-tiled (large-batch) path / deep-K weight gradients
     ldaux = _row_stride(aux, "aux") if aux is not None else 0
-    ldmask = _row_stride(mask, "mask") if mask is not None else 0
+    mp, rs, site, thr = _mask_args(mask)
+    ldmask = _row_stride(mask, "mask") if mp is not None else 0
     _check(lib().hidvae_gemm_f32(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(out), _row_stride(out, "C"),
-                                 epilogue, _p(aux), ldaux, _p(mask), ldmask, float(mask_scale), split_k, _p(ws),
+                                 epilogue, _p(aux), ldaux, mp, ldmask, float(mask_scale), rs, site, thr, split_k, _p(ws),
                                  int(accumulate), _stream()), "hidvae_gemm_f32")
     return out
 
@@ -791,8 +823,9 @@ def layernorm_fwd(x, gamma, beta, eps, relu, mask, mask_scale, residual):
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
     mean = torch.empty((M,), device=x.device, dtype=torch.float32)
     rstd = torch.empty((M,), device=x.device, dtype=torch.float32)
-    _check(lib().hidvae_layernorm_fwd(_p(x), M, N, _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd), int(relu), _p(mask),
-                                      float(mask_scale), _p(residual), _stream()), "hidvae_layernorm_fwd")
+    mp, rs, site, thr = _mask_args(mask)
+    _check(lib().hidvae_layernorm_fwd(_p(x), M, N, _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd), int(relu), mp,
+                                      float(mask_scale), _p(residual), rs, site, thr, _stream()), "hidvae_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -890,20 +923,23 @@ def batchnorm_fwd(x, gamma, beta, eps, momentum, training, running_mean, running
     sm = torch.empty((N,), device=x.device, dtype=torch.float32) if training else None
     sr = torch.empty((N,), device=x.device, dtype=torch.float32) if training else None
     ws = _ws(WS_BATCHNORM_FWD, x.device, M, N) if training else None
+    mp, rs, site, thr = _mask_args(mask)
     _check(lib().hidvae_batchnorm_fwd(_p(x), _row_stride(x, "x"), M, N, _p(gamma), _p(beta), float(eps), float(momentum), int(training),
-                                      _p(running_mean), _p(running_var), _p(num_batches), _p(y), _p(sm), _p(sr), int(relu), _p(mask),
-                                      float(mask_scale), _p(ws), _stream()), "hidvae_batchnorm_fwd")
+                                      _p(running_mean), _p(running_var), _p(num_batches), _p(y), _p(sm), _p(sr), int(relu), mp,
+                                      float(mask_scale), rs, site, thr, _p(ws), _stream()), "hidvae_batchnorm_fwd")
     return y, sm, sr
 
 
-def batchnorm_bwd(gy, x, gamma, beta, save_mean, save_rstd, relu, mask, mask_scale, need_gx=True):
+def batchnorm_bwd(gy, x, gamma, beta, save_mean, save_rstd, relu, mask, mask_scale, need_gx=True, y_out=None):
+    """y_out (instead of mask): the forward output, off which the ReLU -> Dropout gate is read"""
     M, N = x.shape
     gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if need_gx else None
     gg = torch.empty((N,), device=x.device, dtype=torch.float32)
     gb = torch.empty((N,), device=x.device, dtype=torch.float32)
     ws = _ws(WS_BATCHNORM_BWD, x.device, M, N)
     _check(lib().hidvae_batchnorm_bwd(_p(gy), _p(x), _row_stride(x, "x"), _p(gamma), _p(beta), _p(save_mean), _p(save_rstd), M, N,
-                                      int(relu), _p(mask), float(mask_scale), _p(gx), _p(gg), _p(gb), 0, _p(ws), _stream()), "hidvae_batchnorm_bwd")
+                                      int(relu), _p(mask if y_out is None else None), float(mask_scale), _p(y_out), _p(gx), _p(gg), _p(gb), 0,
+                                      _p(ws), _stream()), "hidvae_batchnorm_bwd")
     return gx, gg, gb
 
 
@@ -946,18 +982,24 @@ def infonce_dlogits_chunk(Sc, col0, tau, scale, lse, g):
 MIXUP_PLAN_MAX_B = 4096
 
 
-def mixup_plan(targets, uniforms, alpha):
-    """targets [B, L] int64, uniforms [L, B+64] -> partner [L,B], inverse [L,B] (int64), lam [L]: one launch for all levels"""
+def mixup_plan(targets, uniforms, alpha, rng_state=None):
+    """targets [B, L] int64, uniforms [L, B+64] (or None with rng_state: the kernel draws them from the counter-based generator)
+    -> partner [L,B], inverse [L,B] (int64), lam [L]: one launch for all levels"""
     B, L = targets.shape
-    if targets.dtype != torch.int64 or targets.stride(1) != 1 or tuple(uniforms.shape) != (L, B + 64) or not uniforms.is_contiguous():
-        raise RuntimeError("mixup_plan: expected int64 targets [B,L] with contiguous rows and float32 uniforms [L,B+64]")
-    _f32(uniforms, "uniforms")
+    if targets.dtype != torch.int64 or targets.stride(1) != 1:
+        raise RuntimeError("mixup_plan: expected int64 targets [B,L] with contiguous rows")
+    if uniforms is not None:
+        if tuple(uniforms.shape) != (L, B + 64) or not uniforms.is_contiguous():
+            raise RuntimeError("mixup_plan: expected float32 uniforms [L,B+64]")
+        _f32(uniforms, "uniforms")
+    elif rng_state is None:
+        raise RuntimeError("mixup_plan: uniforms or rng_state")
     dev = targets.device
     partner = torch.empty((L, B), device=dev, dtype=torch.int64)
     inverse = torch.empty((L, B), device=dev, dtype=torch.int64)
     lam = torch.empty((L,), device=dev, dtype=torch.float32)
     _check(lib().hidvae_mixup_plan(_p(targets), B, L, targets.stride(0) if B > 1 else L, _p(uniforms), float(alpha), _p(partner), _p(inverse),
-                                   _p(lam), _stream()), "hidvae_mixup_plan")
+                                   _p(lam), _p(rng_state if uniforms is None else None), _stream()), "hidvae_mixup_plan")
     return partner, inverse, lam
 
 
@@ -1021,62 +1063,14 @@ def gumbel_finish(g_x, x, emb, g_xx, g_l, beta, g_cb, cb, gS_colsum):
 
 
 # ------------------------------------------------------------------------------------------------ grouped launches
-class GemmProblem(ctypes.Structure):  # hidvae_gemm_problem
-    _fields_ = [("layout", _i), ("M", _i64), ("N", _i64), ("K", _i64), ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("bias", _vp),
-                ("C", _vp), ("ldc", _i64), ("epilogue", _i), ("aux", _vp), ("ldaux", _i64), ("mask", _vp), ("ldmask", _i64),
-                ("mask_scale", _f), ("accumulate", _i), ("workspace", _vp)]
-
-
 class LinearBwdProblem(ctypes.Structure):  # hidvae_linear_bwd_problem
     _fields_ = [("g", _vp), ("ldg", _i64), ("x", _vp), ("ldx", _i64), ("W", _vp), ("ldw", _i64), ("B", _i64), ("n_out", _i64),
                 ("n_in", _i64), ("dW", _vp), ("lddw", _i64), ("accumulate_dw", _i), ("dX", _vp), ("lddx", _i64), ("dx_epilogue", _i),
                 ("aux", _vp), ("ldaux", _i64), ("db", _vp), ("accumulate_db", _i), ("workspace", _vp)]
 
 
-class ActBwdProblem(ctypes.Structure):  # hidvae_act_bwd_problem
-    _fields_ = [("g", _vp), ("ref", _vp), ("numel", _i64), ("act", _i), ("mask", _vp), ("mask_scale", _f), ("out", _vp)]
-
-
-class LayerNormProblem(ctypes.Structure):  # hidvae_layernorm_problem
-    _fields_ = [("x", _vp), ("M", _i64), ("N", _i64), ("gamma", _vp), ("beta", _vp), ("eps", _f), ("y", _vp), ("mean", _vp), ("rstd", _vp),
-                ("relu", _i), ("keep_mask", _vp), ("keep_scale", _f), ("residual", _vp), ("gy", _vp), ("gx", _vp), ("ggamma", _vp),
-                ("gbeta", _vp), ("accumulate", _i), ("workspace", _vp)]
-
-
 def _dp(t):
     return t.data_ptr() if t is not None else None
-
-
-def gemm_group(problems):
-    """problems: list of dicts with the keyword arguments of gemm() (layout, A, B, out, bias, epilogue, aux, mask, mask_scale,
-    accumulate); ONE launch for all of them (hidvae_gemm_group).  -> list of outputs"""
-    arr = (GemmProblem * len(problems))()
-    outs = []
-    for q, pr in zip(arr, problems):
-        A, B, layout = pr["A"], pr["B"], pr.get("layout", GEMM_NT)
-        _f32(A, "A"), _f32(B, "B")
-        if layout == GEMM_NT:
-            (M, K), (N, K2) = A.shape, B.shape
-        elif layout == GEMM_NN:
-            (M, K), (K2, N) = A.shape, B.shape
-        else:
-            (K, M), (K2, N) = A.shape, B.shape
-        if K != K2:
-            raise RuntimeError(f"gemm_group: inner dimensions differ ({K} vs {K2})")
-        out = pr.get("out")
-        if out is None:
-            out = torch.empty((M, N), device=A.device, dtype=torch.float32)
-        aux, mask = pr.get("aux"), pr.get("mask")
-        ws = _ws(WS_GEMM, A.device, M, N, K, 0)  # (only read if the call falls back to per-problem launches)
-        q.layout, q.M, q.N, q.K = layout, M, N, K
-        q.A, q.lda, q.B, q.ldb = A.data_ptr(), _row_stride(A, "A"), B.data_ptr(), _row_stride(B, "B")
-        q.bias, q.C, q.ldc, q.epilogue = _dp(pr.get("bias")), out.data_ptr(), _row_stride(out, "C"), int(pr.get("epilogue", EPI_NONE))
-        q.aux, q.ldaux = _dp(aux), (_row_stride(aux, "aux") if aux is not None else 0)
-        q.mask, q.ldmask, q.mask_scale = _dp(mask), (_row_stride(mask, "mask") if mask is not None else 0), float(pr.get("mask_scale", 1.0))
-        q.accumulate, q.workspace = int(bool(pr.get("accumulate", False))), _dp(ws)
-        outs.append((out, ws))
-    _check(lib().hidvae_gemm_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_gemm_group")
-    return [o for o, _ in outs]
 
 
 def linear_bwd_group(problems):
@@ -1111,60 +1105,6 @@ def linear_bwd_group(problems):
         outs.append((dW, dX, db))
         keep.append(ws)
     _check(lib().hidvae_linear_bwd_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_linear_bwd_group")
-    return outs
-
-
-def act_bwd_group(problems):
-    """problems: list of (g, ref, act, mask, mask_scale) -> list of out (one launch)"""
-    arr = (ActBwdProblem * len(problems))()
-    outs = []
-    for q, (g, ref, act, mask, scale) in zip(arr, problems):
-        out = torch.empty_like(g)
-        q.g, q.ref, q.numel, q.act, q.mask, q.mask_scale, q.out = g.data_ptr(), _dp(ref), g.numel(), int(act), _dp(mask), float(scale), out.data_ptr()
-        outs.append(out)
-    _check(lib().hidvae_act_bwd_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_act_bwd_group")
-    return outs
-
-
-def layernorm_fwd_group(problems):
-    """problems: list of (x, gamma, beta, eps, relu, mask, mask_scale, residual) -> list of (y, mean, rstd) (one launch)"""
-    arr = (LayerNormProblem * len(problems))()
-    outs = []
-    for q, (x, gamma, beta, eps, relu, mask, scale, res) in zip(arr, problems):
-        M, N = x.shape
-        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-        mean = torch.empty((M,), device=x.device, dtype=torch.float32)
-        rstd = torch.empty((M,), device=x.device, dtype=torch.float32)
-        q.x, q.M, q.N, q.gamma, q.beta, q.eps = x.data_ptr(), M, N, gamma.data_ptr(), beta.data_ptr(), float(eps)
-        q.y, q.mean, q.rstd, q.relu = y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), int(relu)
-        q.keep_mask, q.keep_scale, q.residual = _dp(mask), float(scale), _dp(res)
-        outs.append((y, mean, rstd))
-    _check(lib().hidvae_layernorm_fwd_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_layernorm_fwd_group")
-    return outs
-
-
-def layernorm_bwd_all_group(problems):
-    """problems: list of dicts(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, need_gx, gg, gb, accumulate)
-    -> list of (gx or None, ggamma, gbeta); two launches for the whole group (row pass + fixed-order finish)"""
-    arr = (LayerNormProblem * len(problems))()
-    outs, keep = [], []
-    for q, pr in zip(arr, problems):
-        x = pr["x"]
-        M, N = x.shape
-        gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if pr.get("need_gx", True) else None
-        gg, gb, acc = pr.get("gg"), pr.get("gb"), bool(pr.get("accumulate", False))
-        if gg is None or gb is None:
-            gg = torch.empty((N,), device=x.device, dtype=torch.float32)
-            gb = torch.empty((N,), device=x.device, dtype=torch.float32)
-            acc = False
-        ws = _ws(WS_LAYERNORM_BWD_ALL, x.device, M, N)
-        q.gy, q.x, q.M, q.N = pr["gy"].data_ptr(), x.data_ptr(), M, N
-        q.gamma, q.beta, q.mean, q.rstd = pr["gamma"].data_ptr(), pr["beta"].data_ptr(), pr["mean"].data_ptr(), pr["rstd"].data_ptr()
-        q.relu, q.keep_mask, q.keep_scale = int(pr["relu"]), _dp(pr.get("mask")), float(pr.get("mask_scale", 1.0))
-        q.gx, q.ggamma, q.gbeta, q.accumulate, q.workspace = _dp(gx), gg.data_ptr(), gb.data_ptr(), int(acc), ws.data_ptr()
-        outs.append((gx, gg, gb))
-        keep.append(ws)
-    _check(lib().hidvae_layernorm_bwd_all_group(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_layernorm_bwd_all_group")
     return outs
 
 

@@ -84,6 +84,36 @@ __device__ __forceinline__ void hv_adamw_prepare(const HvAdamPrepare &a) {
     if (threadIdx.x == 0) a.step[0] = t1;
 }
 
+// ---- counter-based randomness for dropout (and the mixup plan): Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as
+// 1, 2, 3", SC'11; the generator torch's CUDA dropout uses too).  key = the provider's 64-bit seed, counter = (element index lo, hi,
+// site, step): `site` numbers the dropout layers of a forward pass in the order the reference reaches them (h_rqvae.py:147-186,327),
+// `step` is a device counter advanced once per forward pass -- so a replayed HIP graph draws fresh masks every step, every site and
+// element gets an independent stream, and nothing but the 16-byte state lives in memory: the keep-decision is evaluated where the
+// activation is produced, and the backward never needs it (it reads the gate off the forward OUTPUT, y > 0).
+struct HvDrop {
+    const unsigned long long *state;  // [0] seed, [1] step; nullptr: no in-kernel dropout
+    unsigned site;
+    unsigned threshold;               // drop iff word < threshold, threshold = round(p_drop * 2^32)
+};
+__device__ __forceinline__ unsigned hv_philox4x32_10_word0(unsigned long long key, unsigned c0, unsigned c1, unsigned c2, unsigned c3) {
+    unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+__device__ __forceinline__ unsigned hv_rng_word(const unsigned long long *state, unsigned site, unsigned long long idx) {
+    return hv_philox4x32_10_word0(state[0], (unsigned)idx, (unsigned)(idx >> 32), site, (unsigned)state[1]);
+}
+__device__ __forceinline__ bool hv_drop_keep(const HvDrop &d, unsigned long long idx) { return hv_rng_word(d.state, d.site, idx) >= d.threshold; }
+__device__ __forceinline__ float hv_rng_uniform(const unsigned long long *state, unsigned site, unsigned long long idx) {  // [0, 1)
+    return (float)(hv_rng_word(state, site, idx) >> 8) * (1.0f / 16777216.0f);
+}
+
 __device__ __forceinline__ float hv_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

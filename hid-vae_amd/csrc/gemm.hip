@@ -40,7 +40,15 @@ struct GemmArgs {
     const float *mask;    // optional dropout keep-mask multiplied in after the activation (same shape as C)
     int64_t ldmask;
     float mask_scale;
+    HvDrop drop;          // ... or the keep decision evaluated here (counter-based generator, common.h): element index row * N + col
 };
+
+// the factor Dropout applies to output element (row, col): keep-mask * scale (handed in), or the in-kernel decision
+__device__ __forceinline__ bool has_dropout(const GemmArgs &g) { return g.mask != nullptr || g.drop.state != nullptr; }
+__device__ __forceinline__ float dropout_factor(const GemmArgs &g, int64_t row, int64_t col) {
+    if (g.mask != nullptr) return g.mask[row * g.ldmask + col] * g.mask_scale;
+    return hv_drop_keep(g.drop, (unsigned long long)(row * g.N + col)) ? g.mask_scale : 0.0f;
+}
 
 // `scale` matters to DRELU only: the backward through ReLU -> Dropout(keep_scale) read off the layer's OUTPUT y = relu(.) * keep * scale
 // (y > 0 exactly where the unit was active AND kept, so neither the keep-mask nor the pre-activation is needed)
@@ -274,7 +282,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs &g, int bx, int by, int
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE)
                 g.aux[row * g.ldaux + col] = v;
             v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-            if (g.mask != nullptr) v = v * (g.mask[row * g.ldmask + col] * g.mask_scale);
+            if (has_dropout(g)) v = v * dropout_factor(g, row, col);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
         }
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int spli
     v += g.bias != nullptr ? g.bias[col] : 0.0f;
     if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
     v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-    if (g.mask != nullptr) v = v * (g.mask[row * g.ldmask + col] * g.mask_scale);
+    if (has_dropout(g)) v = v * dropout_factor(g, row, col);
     float *dst = g.C + row * g.ldc + col;
     *dst = g.accumulate ? *dst + v : v;
 }
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_direct16_kernel(GemmArgs g) {
             float v = acc[r] + bias;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
             v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            if (has_dropout(g)) v = v * dropout_factor(g, row, col);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
         }
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_direct16_kernel(GemmArgs g) {
             v += g.bias != nullptr ? g.bias[col] : 0.0f;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
             v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            if (has_dropout(g)) v = v * dropout_factor(g, row, col);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
         }
@@ -588,7 +596,7 @@ __device__ __forceinline__ void direct16_body(const GemmArgs &g, int split, int6
         v += g.bias != nullptr ? g.bias[col] : 0.0f;
         if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
         v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-        if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+        if (has_dropout(g)) v = v * dropout_factor(g, row, col);
         float *dst = g.C + row * g.ldc + col;
         *dst = g.accumulate ? *dst + v : v;
     }
@@ -718,7 +726,7 @@ __global__ __launch_bounds__(64 * SPLIT * NWN) void gemm_direct_kernel(GemmArgs 
             float v = acc[r] + bias;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
             v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            if (has_dropout(g)) v = v * dropout_factor(g, row, col);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
         }
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(64 * SPLIT * NWN) void gemm_direct_kernel(GemmArgs 
             v += g.bias != nullptr ? g.bias[col] : 0.0f;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
             v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            if (has_dropout(g)) v = v * dropout_factor(g, row, col);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
         }
@@ -927,7 +935,7 @@ __device__ __forceinline__ void direct32_body(const GemmArgs &g, int split, int6
         v += g.bias != nullptr ? g.bias[col] : 0.0f;
         if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
         v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-        if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+        if (has_dropout(g)) v = v * dropout_factor(g, row, col);
         float *dst = g.C + row * g.ldc + col;
         *dst = g.accumulate ? *dst + v : v;
     }
@@ -1254,7 +1262,7 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_directL_kernel(GemmArgs g) {
             float v = acc[r] + bias;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
             v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            if (has_dropout(g)) v = v * dropout_factor(g, row, col);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
         }
@@ -1272,7 +1280,7 @@ __global__ __launch_bounds__(64 * SPLIT) void gemm_directL_kernel(GemmArgs g) {
             v += g.bias != nullptr ? g.bias[col] : 0.0f;
             if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
             v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-            if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+            if (has_dropout(g)) v = v * dropout_factor(g, row, col);
             float *dst = g.C + row * g.ldc + col;
             *dst = g.accumulate ? *dst + v : v;
         }
@@ -1374,7 +1382,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_directL16_kernel(GemmArgs g) 
         float v = acc[r] + bias;
         if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
         v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-        if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+        if (has_dropout(g)) v = v * dropout_factor(g, row, col);
         float *dst = g.C + row * g.ldc + col;
         *dst = g.accumulate ? *dst + v : v;
     }
@@ -1501,7 +1509,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile16_kernel(GemmArgs g) {
         float v = acc[r] + bias;
         if (g.aux != nullptr && g.epilogue < HIDVAE_EPI_DSILU && g.epilogue != HIDVAE_EPI_NONE) g.aux[row * g.ldaux + col] = v;
         v = apply_epilogue(g.epilogue, v, g.aux, row * g.ldaux + col, g.mask_scale);
-        if (mk != nullptr) v = v * (mk[row * g.ldmask + col] * g.mask_scale);
+        if (has_dropout(g)) v = v * dropout_factor(g, row, col);
         float *dstp = g.C + row * g.ldc + col;
         *dstp = g.accumulate ? *dstp + v : v;
     }
@@ -1730,8 +1738,10 @@ inline int launch_group(GroupArgs &a, hipStream_t s) {
 extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
                                const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int epilogue,
                                float *aux, int64_t ldaux, const float *mask, int64_t ldmask, float mask_scale,
+                               const unsigned long long *rng_state, unsigned rng_site, unsigned drop_threshold,
                                int split_k, float *workspace, int accumulate, void *stream) {
     HV_REQUIRE(layout >= 0 && layout <= 2, "gemm: layout %d", layout);
+    HV_REQUIRE(!(mask && rng_state), "gemm: a keep-mask OR the in-kernel generator, not both");
     HV_REQUIRE(M >= 1 && N >= 1 && K >= 1, "gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     HV_REQUIRE(A && B && C, "gemm: null operand");
     const int64_t a_min = (layout == HIDVAE_GEMM_TN) ? M : K, b_min = (layout == HIDVAE_GEMM_NT) ? K : N;
@@ -1746,6 +1756,7 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
     g.vecA = (lda % 4 == 0) && aligned16(A);
     g.vecB = (ldb % 4 == 0) && aligned16(B);
     g.mask = mask; g.ldmask = ldmask; g.mask_scale = mask_scale;
+    g.drop = HvDrop{rng_state, rng_site, drop_threshold};
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles32 = hv_cdiv(M, 32) * hv_cdiv(N, 32);
     const bool fits32 = fits32bit(layout, M, N, K, lda, ldb);
@@ -1931,10 +1942,10 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         if (db != nullptr) rc = hidvae_colsum(g, B, n_out, ldg, db, accumulate_db, workspace, stream);
         if (rc == HIDVAE_OK)
             rc = hidvae_gemm_f32(HIDVAE_GEMM_TN, n_out, n_in, B, g, ldg, x, ldx, nullptr, dW, lddw, HIDVAE_EPI_NONE, nullptr, 0, nullptr, 0,
-                                 1.0f, 0, workspace, accumulate_dw, stream);
+                                 1.0f, nullptr, 0u, 0u, 0, workspace, accumulate_dw, stream);
         if (rc != HIDVAE_OK || dX == nullptr) return rc;
-        return hidvae_gemm_f32(HIDVAE_GEMM_NN, B, n_in, n_out, g, ldg, W, ldw, nullptr, dX, lddx, dx_epilogue, aux, ldaux, nullptr, 0, dx_scale, 0,
-                               nullptr, 0, stream);
+        return hidvae_gemm_f32(HIDVAE_GEMM_NN, B, n_in, n_out, g, ldg, W, ldw, nullptr, dX, lddx, dx_epilogue, aux, ldaux, nullptr, 0, dx_scale,
+                               nullptr, 0u, 0u, 0, nullptr, 0, stream);
     }
     PairArgs p{};
     p.g0.M = n_out; p.g0.N = n_in; p.g0.K = B; p.g0.A = g; p.g0.lda = ldg; p.g0.B = x; p.g0.ldb = ldx; p.g0.C = dW; p.g0.ldc = lddw;
@@ -1998,36 +2009,6 @@ extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, 
 
 
 // ---- grouped entry points (see gemm_group_kernel) -----------------------------------------------------------------------------
-extern "C" int hidvae_gemm_group(const hidvae_gemm_problem *pr, int n, void *stream) {
-    HV_REQUIRE(pr != nullptr && n >= 1, "gemm_group: bad arguments");
-    GroupArgs a{};
-    bool ok = n <= GROUP_MAX;
-    for (int i = 0; i < n && ok; i++) {
-        const hidvae_gemm_problem &q = pr[i];
-        HV_REQUIRE(q.layout >= 0 && q.layout <= 2 && q.M >= 1 && q.N >= 1 && q.K >= 1 && q.A && q.B && q.C, "gemm_group: problem %d is malformed", i);
-        const int64_t a_min = (q.layout == HIDVAE_GEMM_TN) ? q.M : q.K, b_min = (q.layout == HIDVAE_GEMM_NT) ? q.K : q.N;
-        HV_REQUIRE(q.lda >= a_min && q.ldb >= b_min && q.ldc >= q.N, "gemm_group: problem %d: leading dimension too small", i);
-        HV_REQUIRE(q.epilogue < HIDVAE_EPI_DSILU || (q.aux != nullptr && q.ldaux >= q.N), "gemm_group: problem %d: backward epilogue needs aux", i);
-        HV_REQUIRE(q.mask == nullptr || q.ldmask >= q.N, "gemm_group: problem %d: ldmask", i);
-        GemmArgs g{};
-        g.M = q.M; g.N = q.N; g.K = q.K; g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.bias = q.bias; g.C = q.C; g.ldc = q.ldc;
-        g.epilogue = q.epilogue; g.aux = q.aux; g.ldaux = q.aux ? q.ldaux : 0; g.accumulate = q.accumulate;
-        g.mask = q.mask; g.ldmask = q.ldmask; g.mask_scale = q.mask_scale;
-        ok = group_gemm_sub(a.s[i], q.layout, g);
-    }
-    if (!ok) {  // outside the grouped regime (large batch, or too many problems): one launch per problem, same results as always
-        for (int i = 0; i < n; i++) {
-            const hidvae_gemm_problem &q = pr[i];
-            const int rc = hidvae_gemm_f32(q.layout, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.bias, q.C, q.ldc, q.epilogue, q.aux, q.ldaux, q.mask,
-                                           q.ldmask, q.mask_scale, 0, q.workspace, q.accumulate, stream);
-            if (rc != HIDVAE_OK) return rc;
-        }
-        return HIDVAE_OK;
-    }
-    a.n = n;
-    return launch_group(a, (hipStream_t)stream);
-}
-
 extern "C" int hidvae_linear_bwd_group(const hidvae_linear_bwd_problem *pr, int n, void *stream) {
     HV_REQUIRE(pr != nullptr && n >= 1, "linear_bwd_group: bad arguments");
     GroupArgs a{};

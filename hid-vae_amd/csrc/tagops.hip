@@ -30,34 +30,6 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const floa
     }
 }
 
-struct ActGroupArgs {
-    int n;
-    int nb[4];
-    hidvae_act_bwd_problem p[4];
-};
-__global__ __launch_bounds__(256) void act_bwd_group_kernel(ActGroupArgs a) {
-    int bid = blockIdx.x, p = 0;
-    while (p + 1 < a.n && bid >= a.nb[p]) {
-        bid -= a.nb[p];
-        p++;
-    }
-    const hidvae_act_bwd_problem &q = a.p[p];
-    const int nb = a.nb[p];
-    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < q.numel; i += (int64_t)nb * 256) {
-        float v = q.g[i];
-        const float r = q.ref != nullptr ? q.ref[i] : 0.0f;
-        const float ms = q.mask != nullptr ? q.mask[i] * q.mask_scale : 1.0f;
-        switch (q.act) {
-            case HIDVAE_EPI_RELU: v = r > 0.0f ? v * (q.mask != nullptr ? q.mask_scale : 1.0f) : 0.0f; break;
-            case HIDVAE_EPI_GELU: v = v * hv_dgelu(r) * ms; break;
-            case HIDVAE_EPI_SIGMOID: v = v * (r * (1.0f - r)) * ms; break;
-            case HIDVAE_EPI_SILU: v = v * hv_dsilu(r) * ms; break;
-            default: v = v * ms; break;
-        }
-        q.out[i] = v;
-    }
-}
-
 // out = a * b  (op 0)  or  a + b  (op 1), elementwise, row strides allowed
 __global__ __launch_bounds__(256) void mul_kernel(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M, int64_t N,
                                                   float *out, int64_t ldo, int op) {
@@ -96,7 +68,7 @@ __global__ __launch_bounds__(256) void sum_prefix_slices_kernel(SliceArgs a) {
 template <bool RESIDENT>  // RESIDENT: N <= 1024, the row is read once and kept in registers between the three passes
 __device__ __forceinline__ void layernorm_fwd_body(int64_t blk, const float *x, int64_t M, int64_t N, const float *gamma,
                                                    const float *beta, float eps, float *y, float *mean, float *rstd,
-                                                   int relu, const float *mask, float scale, const float *res) {
+                                                   int relu, const float *mask, float scale, const float *res, HvDrop drop) {
     const int lane = threadIdx.x & 63;
     const int64_t row = blk * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -134,6 +106,7 @@ __device__ __forceinline__ void layernorm_fwd_body(int64_t blk, const float *x, 
                 float o = (xv[j] - mu) * rs * gamma[i] + beta[i];
                 if (relu) o = fmaxf(o, 0.0f);
                 if (mask != nullptr) o = o * (mask[row * N + i] * scale);
+                else if (drop.state != nullptr) o = hv_drop_keep(drop, (unsigned long long)(row * N + i)) ? o * scale : 0.0f;
                 if (res != nullptr) o = o + res[row * N + i];
                 y[row * N + i] = o;
             }
@@ -143,6 +116,7 @@ __device__ __forceinline__ void layernorm_fwd_body(int64_t blk, const float *x, 
             float o = (xr[i] - mu) * rs * gamma[i] + beta[i];
             if (relu) o = fmaxf(o, 0.0f);
             if (mask != nullptr) o = o * (mask[row * N + i] * scale);
+            else if (drop.state != nullptr) o = hv_drop_keep(drop, (unsigned long long)(row * N + i)) ? o * scale : 0.0f;
             if (res != nullptr) o = o + res[row * N + i];
             y[row * N + i] = o;
         }
@@ -153,29 +127,8 @@ __device__ __forceinline__ void layernorm_fwd_body(int64_t blk, const float *x, 
 template <bool RESIDENT>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *x, int64_t M, int64_t N, const float *gamma,
                                                             const float *beta, float eps, float *y, float *mean, float *rstd,
-                                                            int relu, const float *mask, float scale, const float *res) {
-    layernorm_fwd_body<RESIDENT>((int64_t)blockIdx.x, x, M, N, gamma, beta, eps, y, mean, rstd, relu, mask, scale, res);
-}
-
-// grouped launches (the same LayerNorm of several tag-head levels in one grid): sub-problem p owns nb[p] consecutive workgroups
-constexpr int TAG_GROUP_MAX = 4;
-struct LnGroupArgs {
-    int n;
-    int nb[TAG_GROUP_MAX];
-    hidvae_layernorm_problem p[TAG_GROUP_MAX];
-};
-__device__ __forceinline__ int group_find(const int *nb, int n, int &bid) {
-    int p = 0;
-    while (p + 1 < n && bid >= nb[p]) {
-        bid -= nb[p];
-        p++;
-    }
-    return p;
-}
-__global__ __launch_bounds__(256) void layernorm_fwd_group_kernel(LnGroupArgs a) {
-    int bid = blockIdx.x;
-    const hidvae_layernorm_problem &q = a.p[group_find(a.nb, a.n, bid)];
-    layernorm_fwd_body<true>((int64_t)bid, q.x, q.M, q.N, q.gamma, q.beta, q.eps, q.y, q.mean, q.rstd, q.relu, q.keep_mask, q.keep_scale, q.residual);
+                                                            int relu, const float *mask, float scale, const float *res, HvDrop drop) {
+    layernorm_fwd_body<RESIDENT>((int64_t)blockIdx.x, x, M, N, gamma, beta, eps, y, mean, rstd, relu, mask, scale, res, drop);
 }
 
 // gh = gy * mask*scale * (h > 0 if relu), h = xhat*gamma+beta;  dy = gh*gamma
@@ -339,14 +292,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *g
     __shared__ float red[2][3][64 * LNF_NV];
     layernorm_bwd_fused_body((int64_t)blockIdx.x, red, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, part, yout, in_relu_scale);
 }
-__global__ __launch_bounds__(256) void layernorm_bwd_fused_group_kernel(LnGroupArgs a) {
-    __shared__ float red[2][3][64 * LNF_NV];
-    int bid = blockIdx.x;
-    const hidvae_layernorm_problem &q = a.p[group_find(a.nb, a.n, bid)];
-    layernorm_bwd_fused_body((int64_t)bid, red, q.gy, q.x, q.gamma, q.beta, q.mean, q.rstd, q.M, q.N, q.relu, q.keep_mask, q.keep_scale, q.gx,
-                             q.workspace);
-}
-
 // 32 columns x 32 chunk groups per workgroup: group q adds chunks q, q+32, ... in ascending order, then the groups are added
 // in ascending order (the fused backward leaves one partial per 4 rows, so depth matters more than work here)
 __device__ __forceinline__ void layernorm_param_final_body(int64_t blk, float (*red)[32][33], const float *part, int64_t chunks, int64_t N,
@@ -401,13 +346,6 @@ __global__ __launch_bounds__(1024) void layernorm_param_final_many_kernel(LnFina
     const hidvae_ln_final &q = a.p[p];
     layernorm_param_final_body((int64_t)bid, red, q.partials, (q.M + LNF_ROWS - 1) / LNF_ROWS, q.N, q.ggamma, q.gbeta, q.accumulate);
 }
-__global__ __launch_bounds__(1024) void layernorm_param_final_group_kernel(LnGroupArgs a) {
-    __shared__ float red[2][32][33];
-    int bid = blockIdx.x;
-    const hidvae_layernorm_problem &q = a.p[group_find(a.nb, a.n, bid)];
-    layernorm_param_final_body((int64_t)bid, red, q.workspace, (q.M + LNF_ROWS - 1) / LNF_ROWS, q.N, q.ggamma, q.gbeta, q.accumulate);
-}
-
 // ------------------------------------------------------------------------------------------------
 // BatchNorm1d (h_rqvae.py:325).  One workgroup (1024 threads = 32 columns x 32 row-lanes) per 32 columns.
 // training: batch mean / biased variance (two passes), running stats <- (1-mom)*old + mom*{mean, unbiased var};
@@ -433,7 +371,7 @@ __global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float *x, int
                                                              const float *beta, float eps, float momentum, int training,
                                                              float *running_mean, float *running_var, int64_t *num_batches_tracked,
                                                              float *y, float *save_mean, float *save_rstd, int relu,
-                                                             const float *mask, float scale) {
+                                                             const float *mask, float scale, HvDrop drop) {
     __shared__ float red[BN_LANES][BN_COLS];
     if (training && num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const int c = threadIdx.x & (BN_COLS - 1), rl = threadIdx.x / BN_COLS;
@@ -467,8 +405,19 @@ __global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float *x, int
         float o = (x[m * ldx + n] - mu) * rs * ga + be;
         if (relu) o = fmaxf(o, 0.0f);
         if (mask != nullptr) o = o * (mask[m * N + n] * scale);
+        else if (drop.state != nullptr) o = hv_drop_keep(drop, (unsigned long long)(m * N + n)) ? o * scale : 0.0f;
         y[m * N + n] = o;
     }
+}
+
+// the gradient entering the normalisation, taken back through Dropout and ReLU: either from the keep-mask and h = xhat*gamma+beta, or
+// (yout != NULL) read off the forward OUTPUT y = relu(h) * keep * scale, which is > 0 exactly where the unit was active and kept
+__device__ __forceinline__ float bn_gate(float g, float xh, float ga, float be, int relu, const float *mask, const float *yout, int64_t off,
+                                         float scale) {
+    if (yout != nullptr) return relu ? (yout[off] > 0.0f ? g * scale : 0.0f) : g;
+    if (mask != nullptr) g = g * (mask[off] * scale);
+    if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+    return g;
 }
 
 // training-mode backward: gh = gy*mask*scale*(h>0); ggamma = sum gh*xhat; gbeta = sum gh;
@@ -476,7 +425,7 @@ __global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float *x, int
 __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float *gy, const float *x, int64_t ldx, const float *gamma,
                                                              const float *beta, const float *save_mean, const float *save_rstd,
                                                              int64_t M, int64_t N, int relu, const float *mask, float scale,
-                                                             float *gx, float *ggamma, float *gbeta, int accumulate) {
+                                                             float *gx, float *ggamma, float *gbeta, int accumulate, const float *yout) {
     __shared__ float red[BN_LANES][BN_COLS];
     const int c = threadIdx.x & (BN_COLS - 1), rl = threadIdx.x / BN_COLS;
     const int64_t n = (int64_t)blockIdx.x * BN_COLS + c;
@@ -487,9 +436,7 @@ __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float *gy, co
     if (ok)
         for (int64_t m = rl; m < M; m += BN_LANES) {
             const float xh = (x[m * ldx + n] - mu) * rs;
-            float g = gy[m * N + n];
-            if (mask != nullptr) g = g * (mask[m * N + n] * scale);
-            if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+            const float g = bn_gate(gy[m * N + n], xh, ga, be, relu, mask, yout, m * N + n, scale);
             sg += g * xh;
             sb += g;
         }
@@ -504,9 +451,7 @@ __global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float *gy, co
         const float k = ga * rs / (float)M;
         for (int64_t m = rl; m < M; m += BN_LANES) {
             const float xh = (x[m * ldx + n] - mu) * rs;
-            float g = gy[m * N + n];
-            if (mask != nullptr) g = g * (mask[m * N + n] * scale);
-            if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+            const float g = bn_gate(gy[m * N + n], xh, ga, be, relu, mask, yout, m * N + n, scale);
             gx[m * N + n] = k * (((float)M * g - sb) - xh * sg);
         }
     }
@@ -570,7 +515,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *x, int64_t l
                                                        const float *beta, float eps, float momentum, int training, float *running_mean,
                                                        float *running_var, int64_t *num_batches_tracked, const float *part,
                                                        int64_t chunks, float *y, float *save_mean, float *save_rstd, int relu,
-                                                       const float *mask, float scale) {
+                                                       const float *mask, float scale, HvDrop drop) {
     __shared__ float s_mu[64], s_rs[64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * 64 + c;
@@ -620,6 +565,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *x, int64_t l
         float o = (x[m * ldx + n] - mu) * rs * ga + be;
         if (relu) o = fmaxf(o, 0.0f);
         if (mask != nullptr) o = o * (mask[m * N + n] * scale);
+        else if (drop.state != nullptr) o = hv_drop_keep(drop, (unsigned long long)(m * N + n)) ? o * scale : 0.0f;
         y[m * N + n] = o;
     }
 }
@@ -629,7 +575,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *x, int64_t l
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *gy, const float *x, int64_t ldx, const float *gamma,
                                                              const float *beta, const float *save_mean, const float *save_rstd,
                                                              int64_t M, int64_t N, int relu, const float *mask, float scale,
-                                                             float *part) {
+                                                             float *part, const float *yout) {
     __shared__ float red[2][4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * 64 + c;
@@ -642,9 +588,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *gy, co
             const int64_t m = m0 + rl + 4 * j;
             if (m < M) {
                 const float xh = (x[m * ldx + n] - mu) * rs;
-                float g = gy[m * N + n];
-                if (mask != nullptr) g = g * (mask[m * N + n] * scale);
-                if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+                const float g = bn_gate(gy[m * N + n], xh, ga, be, relu, mask, yout, m * N + n, scale);
                 sg += g * xh;
                 sb += g;
             }
@@ -663,7 +607,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *gy, cons
                                                            const float *beta, const float *save_mean, const float *save_rstd,
                                                            int64_t M, int64_t N, int relu, const float *mask, float scale,
                                                            const float *part, int64_t chunks, float *gx, float *ggamma, float *gbeta,
-                                                           int accumulate) {
+                                                           int accumulate, const float *yout) {
     __shared__ float s_g[64], s_b[64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * 64 + c;
@@ -696,9 +640,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *gy, cons
         const int64_t m = (int64_t)blockIdx.y * 16 + rl + 4 * j;
         if (m >= M) continue;
         const float xh = (x[m * ldx + n] - mu) * rs;
-        float g = gy[m * N + n];
-        if (mask != nullptr) g = g * (mask[m * N + n] * scale);
-        if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+        const float g = bn_gate(gy[m * N + n], xh, ga, be, relu, mask, yout, m * N + n, scale);
         gx[m * N + n] = k * (((float)M * g - sb) - xh * sg);
     }
 }
@@ -1051,14 +993,17 @@ extern "C" int hidvae_sum_prefix_slices(const float *const *src_host, const int3
 
 extern "C" int hidvae_layernorm_fwd(const float *x, int64_t M, int64_t N, const float *gamma, const float *beta, float eps, float *y,
                                     float *mean, float *rstd, int relu, const float *keep_mask, float keep_scale,
-                                    const float *residual, void *stream) {
+                                    const float *residual, const unsigned long long *rng_state, unsigned rng_site, unsigned drop_threshold,
+                                    void *stream) {
     HV_REQUIRE(x && gamma && beta && y && mean && rstd && M >= 1 && N >= 1, "layernorm_fwd: bad arguments");
+    HV_REQUIRE(!(keep_mask && rng_state), "layernorm_fwd: a keep-mask OR the in-kernel generator, not both");
+    const HvDrop drop{rng_state, rng_site, drop_threshold};
     if (N <= 1024)
         hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, N, gamma, beta,
-                           eps, y, mean, rstd, relu, keep_mask, keep_scale, residual);
+                           eps, y, mean, rstd, relu, keep_mask, keep_scale, residual, drop);
     else
     hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, N, gamma, beta,
-                       eps, y, mean, rstd, relu, keep_mask, keep_scale, residual);
+                       eps, y, mean, rstd, relu, keep_mask, keep_scale, residual, drop);
     HV_LAUNCH_CHECK("layernorm_fwd");
     return HIDVAE_OK;
 }
@@ -1149,8 +1094,11 @@ extern "C" int hidvae_layernorm_param_final_many(const hidvae_ln_final *pr, int 
 extern "C" int hidvae_batchnorm_fwd(const float *x, int64_t ldx, int64_t M, int64_t N, const float *gamma, const float *beta, float eps,
                                     float momentum, int training, float *running_mean, float *running_var,
                                     int64_t *num_batches_tracked, float *y, float *save_mean, float *save_rstd, int relu,
-                                    const float *keep_mask, float keep_scale, float *workspace, void *stream) {
+                                    const float *keep_mask, float keep_scale, const unsigned long long *rng_state, unsigned rng_site,
+                                    unsigned drop_threshold, float *workspace, void *stream) {
     HV_REQUIRE(x && y && M >= 1 && N >= 1 && ldx >= N, "batchnorm_fwd: bad arguments");
+    HV_REQUIRE(!(keep_mask && rng_state), "batchnorm_fwd: a keep-mask OR the in-kernel generator, not both");
+    const HvDrop drop{rng_state, rng_site, drop_threshold};
     HV_REQUIRE(training ? (save_mean && save_rstd) : (running_mean && running_var), "batchnorm_fwd: statistics buffers missing");
     if (workspace != nullptr || !training) {  // row-parallel form
         hipStream_t s = (hipStream_t)stream;
@@ -1161,36 +1109,37 @@ extern "C" int hidvae_batchnorm_fwd(const float *x, int64_t ldx, int64_t M, int6
         }
         hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)hv_cdiv(N, 64), (unsigned)hv_cdiv(M, 16)), dim3(256), 0, s, x, ldx, M, N, gamma, beta,
                            eps, momentum, training, running_mean, running_var, num_batches_tracked, workspace, chunks, y, save_mean,
-                           save_rstd, relu, keep_mask, keep_scale);
+                           save_rstd, relu, keep_mask, keep_scale, drop);
         HV_LAUNCH_CHECK("batchnorm_fwd apply");
         return HIDVAE_OK;
     }
     hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3((unsigned)hv_cdiv(N, BN_COLS)), dim3(1024), 0, (hipStream_t)stream, x, ldx, M, N, gamma,
                        beta, eps, momentum, training, running_mean, running_var, num_batches_tracked, y, save_mean, save_rstd, relu, keep_mask,
-                       keep_scale);
+                       keep_scale, drop);
     HV_LAUNCH_CHECK("batchnorm_fwd");
     return HIDVAE_OK;
 }
 
 extern "C" int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx, const float *gamma, const float *beta,
                                     const float *save_mean, const float *save_rstd, int64_t M, int64_t N, int relu,
-                                    const float *keep_mask, float keep_scale, float *gx, float *ggamma, float *gbeta, int accumulate,
-                                    float *workspace, void *stream) {
+                                    const float *keep_mask, float keep_scale, const float *y_out, float *gx, float *ggamma, float *gbeta,
+                                    int accumulate, float *workspace, void *stream) {
     HV_REQUIRE(gy && x && gamma && beta && save_mean && save_rstd && ggamma && gbeta && M >= 1 && N >= 1 && ldx >= N,
                "batchnorm_bwd: bad arguments");
+    HV_REQUIRE(!(keep_mask && y_out), "batchnorm_bwd: the gate comes from the keep-mask OR from the forward output, not both");
     if (workspace != nullptr) {  // row-parallel form
         hipStream_t s = (hipStream_t)stream;
         const int64_t chunks = hv_cdiv(M, BN2_ROWS);
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((unsigned)hv_cdiv(N, 64), (unsigned)chunks), dim3(256), 0, s, gy, x, ldx, gamma, beta,
-                           save_mean, save_rstd, M, N, relu, keep_mask, keep_scale, workspace);
+                           save_mean, save_rstd, M, N, relu, keep_mask, keep_scale, workspace, y_out);
         HV_LAUNCH_CHECK("batchnorm_bwd partial");
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)hv_cdiv(N, 64), (unsigned)hv_cdiv(M, 16)), dim3(256), 0, s, gy, x, ldx, gamma,
-                           beta, save_mean, save_rstd, M, N, relu, keep_mask, keep_scale, workspace, chunks, gx, ggamma, gbeta, accumulate);
+                           beta, save_mean, save_rstd, M, N, relu, keep_mask, keep_scale, workspace, chunks, gx, ggamma, gbeta, accumulate, y_out);
         HV_LAUNCH_CHECK("batchnorm_bwd apply");
         return HIDVAE_OK;
     }
     hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((unsigned)hv_cdiv(N, BN_COLS)), dim3(1024), 0, (hipStream_t)stream, gy, x, ldx, gamma, beta,
-                       save_mean, save_rstd, M, N, relu, keep_mask, keep_scale, gx, ggamma, gbeta, accumulate);
+                       save_mean, save_rstd, M, N, relu, keep_mask, keep_scale, gx, ggamma, gbeta, accumulate, y_out);
     HV_LAUNCH_CHECK("batchnorm_bwd");
     return HIDVAE_OK;
 }
@@ -1274,19 +1223,25 @@ __device__ float mix_gamma(float shape, const float *u, int &k) {  // Gamma(shap
     return d * v * boost;
 }
 
+constexpr unsigned MIX_SITE = 0x4d495800u;  // the mixup plan's randomness site (+ level): apart from every dropout site
 __global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets, int64_t B, int64_t ldt, const float *u, float alpha,
-                                                          int64_t *partner, int64_t *inverse, float *lam) {
+                                                          int64_t *partner, int64_t *inverse, float *lam,
+                                                          const unsigned long long *rng_state) {
     __shared__ float key[MIX_MAXB];
     __shared__ int idx[MIX_MAXB];
     __shared__ int inv[MIX_MAXB];
     __shared__ int part[1024];
+    __shared__ float spare[MIX_SPARE];
     const int lvl = blockIdx.x, tid = threadIdx.x;
-    const float *ul = u + (int64_t)lvl * (B + MIX_SPARE);
+    // the level's uniforms: handed in (u, tests / injected draws) or drawn here from the counter-based generator (rng_state)
+    const float *ul = u != nullptr ? u + (int64_t)lvl * (B + MIX_SPARE) : nullptr;
+    if (tid < MIX_SPARE) spare[tid] = ul != nullptr ? ul[B + tid] : hv_rng_uniform(rng_state, MIX_SITE + (unsigned)lvl, (unsigned long long)(B + tid));
     int n2 = 1024;
     while (n2 < B) n2 <<= 1;
     for (int i = tid; i < n2; i += 1024) {
         const bool valid = i < B && targets[(int64_t)i * ldt + lvl] >= 0;
-        key[i] = valid ? ul[i] : (i < B ? 2.0f : 3.0f);  // valid rows first, then the invalid ones, then the padding
+        const float ui = !valid ? 0.0f : (ul != nullptr ? ul[i] : hv_rng_uniform(rng_state, MIX_SITE + (unsigned)lvl, (unsigned long long)i));
+        key[i] = valid ? ui : (i < B ? 2.0f : 3.0f);  // valid rows first, then the invalid ones, then the padding
         idx[i] = i;
         inv[i] = -1;
     }
@@ -1333,7 +1288,7 @@ __global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets
     for (int i = tid; i < B; i += 1024) inverse[(int64_t)lvl * B + i] = inv[i];
     if (tid == 0) {
         int k = 0;
-        const float x = mix_gamma(alpha, ul + B, k), y = mix_gamma(alpha, ul + B, k);
+        const float x = mix_gamma(alpha, spare, k), y = mix_gamma(alpha, spare, k);
         const float s = x + y;
         lam[lvl] = s > 0.0f ? x / s : 0.5f;
     }
@@ -1341,13 +1296,35 @@ __global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets
 }  // namespace
 
 extern "C" int hidvae_mixup_plan(const int64_t *targets, int64_t B, int L, int64_t ld_targets, const float *uniforms, float alpha,
-                                 int64_t *partner, int64_t *inverse, float *lam, void *stream) {
-    HV_REQUIRE(targets && uniforms && partner && inverse && lam && B >= 1 && L >= 1 && ld_targets >= L && alpha > 0.0f,
+                                 int64_t *partner, int64_t *inverse, float *lam, const unsigned long long *rng_state, void *stream) {
+    HV_REQUIRE(targets && (uniforms || rng_state) && partner && inverse && lam && B >= 1 && L >= 1 && ld_targets >= L && alpha > 0.0f,
                "mixup_plan: bad arguments");
     HV_REQUIRE(B <= MIX_MAXB, "mixup_plan: B=%lld rows do not fit the in-LDS sort (max %d)", (long long)B, MIX_MAXB);
     hipLaunchKernelGGL(mixup_plan_kernel, dim3((unsigned)L), dim3(1024), 0, (hipStream_t)stream, targets, B, ld_targets, uniforms, alpha,
-                       partner, inverse, lam);
+                       partner, inverse, lam, rng_state);
     HV_LAUNCH_CHECK("mixup_plan");
+    return HIDVAE_OK;
+}
+
+namespace {
+__global__ void rng_advance_kernel(unsigned long long *state) { state[1] = state[1] + 1ull; }
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float *out, int64_t n, HvDrop d) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = hv_drop_keep(d, (unsigned long long)i) ? 1.0f : 0.0f;
+}
+}  // namespace
+
+extern "C" int hidvae_rng_advance(unsigned long long *state, void *stream) {
+    HV_REQUIRE(state != nullptr, "rng_advance: null state");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    HV_LAUNCH_CHECK("rng_advance");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_dropout_mask(float *out, int64_t numel, const unsigned long long *rng_state, unsigned site, unsigned threshold,
+                                   void *stream) {
+    HV_REQUIRE(out && rng_state && numel >= 1, "dropout_mask: bad arguments");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(numel)), dim3(256), 0, (hipStream_t)stream, out, numel, HvDrop{rng_state, site, threshold});
+    HV_LAUNCH_CHECK("dropout_mask");
     return HIDVAE_OK;
 }
 
@@ -1374,85 +1351,5 @@ extern "C" int hidvae_tag_loss_bwd(const float *dmix, const float *dkl, const in
     hipLaunchKernelGGL(tag_loss_bwd_kernel, dim3(ew_grid(B * C)), dim3(256), 0, (hipStream_t)stream, dmix, dkl, target, inverse, lam_dev, B,
                        C, g_dev, n_valid, g_logits);
     HV_LAUNCH_CHECK("tag_loss_bwd");
-    return HIDVAE_OK;
-}
-
-
-// ---- grouped entry points: the same op of several tag-head levels in one launch (see include/hidvae.h) ------------------------------
-extern "C" int hidvae_act_bwd_group(const hidvae_act_bwd_problem *pr, int n, void *stream) {
-    HV_REQUIRE(pr != nullptr && n >= 1 && n <= 4, "act_bwd_group: 1..4 problems");
-    ActGroupArgs a{};
-    a.n = n;
-    unsigned blocks = 0;
-    for (int i = 0; i < n; i++) {
-        HV_REQUIRE(pr[i].g && pr[i].out && pr[i].numel >= 1, "act_bwd_group: problem %d is malformed", i);
-        a.p[i] = pr[i];
-        a.nb[i] = (int)ew_grid(pr[i].numel);
-        blocks += (unsigned)a.nb[i];
-    }
-    hipLaunchKernelGGL(act_bwd_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    HV_LAUNCH_CHECK("act_bwd_group");
-    return HIDVAE_OK;
-}
-
-extern "C" int hidvae_layernorm_fwd_group(const hidvae_layernorm_problem *pr, int n, void *stream) {
-    HV_REQUIRE(pr != nullptr && n >= 1 && n <= TAG_GROUP_MAX, "layernorm_fwd_group: 1..4 problems");
-    LnGroupArgs a{};
-    a.n = n;
-    unsigned blocks = 0;
-    bool resident = true;
-    for (int i = 0; i < n; i++) {
-        const hidvae_layernorm_problem &q = pr[i];
-        HV_REQUIRE(q.x && q.gamma && q.beta && q.y && q.mean && q.rstd && q.M >= 1 && q.N >= 1, "layernorm_fwd_group: problem %d is malformed", i);
-        resident = resident && q.N <= 1024;
-        a.p[i] = q;
-        a.nb[i] = (int)hv_cdiv(q.M, 4);
-        blocks += (unsigned)a.nb[i];
-    }
-    if (!resident) {  // rows too wide for the register-resident form: one launch per problem
-        for (int i = 0; i < n; i++) {
-            const hidvae_layernorm_problem &q = pr[i];
-            const int rc = hidvae_layernorm_fwd(q.x, q.M, q.N, q.gamma, q.beta, q.eps, q.y, q.mean, q.rstd, q.relu, q.keep_mask, q.keep_scale,
-                                                q.residual, stream);
-            if (rc != HIDVAE_OK) return rc;
-        }
-        return HIDVAE_OK;
-    }
-    hipLaunchKernelGGL(layernorm_fwd_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    HV_LAUNCH_CHECK("layernorm_fwd_group");
-    return HIDVAE_OK;
-}
-
-extern "C" int hidvae_layernorm_bwd_all_group(const hidvae_layernorm_problem *pr, int n, void *stream) {
-    HV_REQUIRE(pr != nullptr && n >= 1 && n <= TAG_GROUP_MAX, "layernorm_bwd_all_group: 1..4 problems");
-    LnGroupArgs a{}, f{};
-    a.n = f.n = n;
-    unsigned blocks = 0, fblocks = 0;
-    bool resident = true;
-    for (int i = 0; i < n; i++) {
-        const hidvae_layernorm_problem &q = pr[i];
-        HV_REQUIRE(q.gy && q.x && q.gamma && q.beta && q.mean && q.rstd && q.ggamma && q.gbeta && q.workspace && q.M >= 1 && q.N >= 1,
-                   "layernorm_bwd_all_group: problem %d is malformed", i);
-        resident = resident && q.N <= 64 * LNF_NV;
-        a.p[i] = f.p[i] = q;
-        a.nb[i] = (int)hv_cdiv(q.M, LNF_ROWS);
-        f.nb[i] = (int)hv_cdiv(q.N, 32);
-        blocks += (unsigned)a.nb[i];
-        fblocks += (unsigned)f.nb[i];
-    }
-    if (!resident) {
-        for (int i = 0; i < n; i++) {
-            const hidvae_layernorm_problem &q = pr[i];
-            const int rc = hidvae_layernorm_bwd_all(q.gy, q.x, q.gamma, q.beta, q.mean, q.rstd, q.M, q.N, q.relu, q.keep_mask, q.keep_scale, q.gx,
-                                                    q.ggamma, q.gbeta, q.accumulate, q.workspace, stream);
-            if (rc != HIDVAE_OK) return rc;
-        }
-        return HIDVAE_OK;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(layernorm_bwd_fused_group_kernel, dim3(blocks), dim3(256), 0, s, a);
-    HV_LAUNCH_CHECK("layernorm_bwd_fused_group");
-    hipLaunchKernelGGL(layernorm_param_final_group_kernel, dim3(fblocks), dim3(1024), 0, s, f);
-    HV_LAUNCH_CHECK("layernorm_param_final_group");
     return HIDVAE_OK;
 }

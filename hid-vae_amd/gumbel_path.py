@@ -65,8 +65,8 @@ def _effective(layer):
 
 
 def gumbel_level(layer, x, temperature, rand=None):
-    from .rand import DeviceRand
-    rand = rand or DeviceRand()
+    from .rand import default_rand
+    rand = rand or default_rand()
     U = rand.gumbel_u((x.shape[0], layer.n_embed), x.device)
     return GumbelLevelFn.apply(x, _effective(layer), U, float(temperature), layer.quantize_loss.commitment_weight)
 

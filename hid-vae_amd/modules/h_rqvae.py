@@ -354,12 +354,12 @@ class HRqVae(nn.Module, _HubMixin):
         if self.training and tagged:
             r = self._rand()
             if hasattr(r, "begin_step"):
-                # all dropout keep-masks of the step from one launch, and the mixup pairing (rand.DeviceRand) -- on the first tag stream,
-                # beside the encoder, when the heads run on streams of their own (tagpath.early_rand)
+                # the generator's step counter and the mixup pairing (rand.DeviceRand) -- on the first tag stream, beside the encoder,
+                # when the heads run on streams of their own (tagpath.early_rand)
                 from ..tagpath import early_rand
                 lm = self.tag_prediction_loss
                 mix = torch.is_grad_enabled() and lm.use_mixup and x.shape[0] > 1 and hasattr(r, "prepare_mixup")
-                if not (hasattr(r, "_arena") and early_rand(r, tags_indices[:, :self.n_layers], x.device, self.n_layers, mix)):
+                if not early_rand(r, tags_indices[:, :self.n_layers], x.device, self.n_layers, mix):
                     r.begin_step(x.device)
         _C.phase_mark("fwd:start")
         self._prepared = self._prepare_codebooks_async()  # effective codebooks + |c|^2 on the helper stream, beside the encoder

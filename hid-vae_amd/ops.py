@@ -475,6 +475,13 @@ class LinearFn(Function):
         ctx.w_param, ctx.b_param = w, b  # (the objects themselves: a flat-gradient slot hangs off the Parameter)
         ctx.need_x = ctx.needs_input_grad[0]
         ctx.act_bwd_done, ctx.dx_gate = bool(act_bwd_done), dx_gate
+        if keep_mask is not None and not torch.is_tensor(keep_mask):  # a _C.DropSpec: decided inside the launch, never stored
+            if act != _C.EPI_RELU:
+                raise NotImplementedError("in-kernel dropout is wired for Linear -> ReLU -> Dropout (the gate is read off the output)")
+            ctx.drop_after_relu = True
+            keep_mask = None
+        else:
+            ctx.drop_after_relu = False
         ctx.save_for_backward(x, w, pre if pre is not None else y, keep_mask)
         return y
 
@@ -485,7 +492,8 @@ class LinearFn(Function):
         x, w, ref, keep_mask = ctx.saved_tensors
         g = g.contiguous()
         if not ctx.act_bwd_done and (ctx.act != _C.EPI_NONE or keep_mask is not None):
-            g = _C.act_bwd(g, ref, ctx.act, keep_mask, ctx.keep_scale)
+            # (ReLU: the kernel gates on ref = y > 0 and only needs a non-NULL mask argument to apply keep_scale)
+            g = _C.act_bwd(g, ref, ctx.act, ref if ctx.drop_after_relu else keep_mask, ctx.keep_scale)
         epi, aux, dxs = (_C.EPI_DRELU, x, float(ctx.dx_gate)) if (ctx.dx_gate is not None and ctx.need_x) else (_C.EPI_NONE, None, 1.0)
         dst, acc = grad_sink(ctx.w_param)
         if ctx.has_bias:  # weight, input and bias gradients share one launch

@@ -8,51 +8,51 @@ import torch
 
 
 class DeviceRand:
-    """Production provider: everything is drawn on the device with no host synchronisation (graph-capturable).
+    """Production provider: nothing is drawn ahead of time and no mask tensor exists.
 
-    A training step asks for ~25 dropout masks of fixed shapes and rates and one mixup pairing per level; drawn one by one that
-    is ~70 tiny launches, each at the ~5 us launch floor.  So the provider learns the step's request list once (begin_step()
-    .. the requests that follow) and from then on draws ALL keep-masks with ONE torch.bernoulli over a cached per-element
-    keep-probability vector and hands out views; the pairings of all levels are computed together (mixup_all)."""
+    Dropout: dropout_keep() hands out a _C.DropSpec -- (generator state, site number, drop probability) -- and the launch that
+    produces the activation evaluates the keep decision per element itself (Philox4x32-10 keyed by the seed, counter = (element,
+    site, step); csrc/common.h).  The backward reads the gate off the forward output, so the decision is never stored.  `step` lives
+    on the device and is advanced by one tiny launch per forward pass (begin_step), which is what makes a REPLAYED HIP graph draw
+    fresh masks; `site` counts the dropout layers of the pass in call order (the order in which the reference's forward reaches
+    them, h_rqvae.py:147-186,327).  (Rounds 1-2 drew all keep-masks of a step with one torch.bernoulli into fp32 tensors: 30-56 us
+    of a foreign kernel per step plus ~45 MB of mask traffic.)
+    Mixup: one launch (hidvae_mixup_plan) computes the pairings and lambdas of all levels from the same generator."""
 
-    def __init__(self, mixup_alpha=0.2):
+    def __init__(self, mixup_alpha=0.2, seed=None):
         self.mixup_alpha = mixup_alpha
+        self.seed = seed
         self._beta = None
-        self._plan = None      # [(numel, shape, p)] learned from the first step
-        self._probs = None     # per-element keep probability of the arena
-        self._record = None    # requests seen since begin_step() while learning
-        self._arena = None
-        self._cursor = 0
+        self._state = {}       # device index -> int64[2] {seed, step}
+        self._site = 0
         self._mix = None       # per-level (partner, inverse, lam) of the current step
 
-    # ---- step protocol (optional: without begin_step() every request is an individual draw)
+    def state(self, device):
+        """the generator state on `device` (created on first use -- before any graph capture: the eager warm-up steps see to that)"""
+        device = torch.device(device)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        st = self._state.get(key)
+        if st is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("DeviceRand: the generator state must exist before a graph capture (run one eager step first)")
+            seed = self.seed if self.seed is not None else (torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
+            st = self._state[key] = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        return st
+
+    # ---- step protocol: once per forward pass (HRqVae.forward).  Without it the sites simply keep counting, which is as good:
+    # (step, site) pairs never repeat either way
     def begin_step(self, device):
+        from . import _C
         self._mix = None
-        if self._record is not None and self._record:  # the previous step was the learning step
-            self._plan = self._record
-            self._probs = torch.cat([torch.full((n,), 1.0 - p, device=device, dtype=torch.float32) for n, _, p in self._plan])
-        self._record = [] if self._plan is None else None
-        if self._plan is not None:
-            self._arena = torch.bernoulli(self._probs)  # one launch for every keep-mask of the step
-            self._cursor, self._offset = 0, 0
+        self._site = 0
+        _C.rng_advance(self.state(device))
         return self
 
     def dropout_keep(self, shape, p, device):
-        shape = tuple(int(d) for d in shape)
-        n = 1
-        for d in shape:
-            n *= d
-        if self._record is not None:
-            self._record.append((n, shape, float(p)))
-        elif self._plan is not None and self._arena is not None and self._cursor < len(self._plan) \
-                and self._plan[self._cursor] == (n, shape, float(p)):
-            view = self._arena[self._offset:self._offset + n].view(shape)
-            self._cursor += 1
-            self._offset += n
-            return view
-        elif self._plan is not None:  # the step changed shape (another batch size, eval in between): learn again
-            self._plan, self._arena, self._record = None, None, None
-        return torch.empty(shape, device=device, dtype=torch.float32).bernoulli_(1.0 - p)
+        from . import _C
+        spec = _C.DropSpec(self.state(device), self._site, p)
+        self._site += 1
+        return spec
 
     def _lam(self, device, n):
         if self._beta is None:  # built once (a host->device scalar copy is not allowed inside a graph capture)
@@ -66,9 +66,9 @@ class DeviceRand:
         partner[b] = row mixed into b, inverse[partner[b]] = b, -1 on invalid rows; lam ~ Beta(alpha, alpha) (device)."""
         B, L = targets.shape
         if targets.is_cuda and B <= 4096 and targets.dtype == torch.int64 and targets.stride(1) == 1:
-            # one launch (csrc/tagops.hip mixup_plan_kernel) on one torch.rand: the torch composition below is ~40 small launches
+            # one launch (csrc/tagops.hip mixup_plan_kernel), its uniforms drawn inside from the counter-based generator
             from . import _C
-            partner, inverse, lam = _C.mixup_plan(targets, torch.rand((L, B + 64), device=device, dtype=torch.float32), self.mixup_alpha)
+            partner, inverse, lam = _C.mixup_plan(targets, None, self.mixup_alpha, rng_state=self.state(device))
             return [(partner[i], inverse[i], lam[i]) for i in range(L)]
         t = targets.t()  # [L, B]
         L, B = t.shape
@@ -95,6 +95,18 @@ class DeviceRand:
 
     def gumbel_u(self, shape, device):
         return torch.rand(tuple(shape), device=device, dtype=torch.float32)
+
+
+_DEFAULTS = {}
+
+
+def default_rand(mixup_alpha=0.2):
+    """the process-wide DeviceRand for callers that were handed none (a TagPredictor / TagPredictionLoss used on its own): ONE
+    generator state, so successive calls keep drawing fresh masks (a fresh DeviceRand per call would restart at step 0 each time)"""
+    r = _DEFAULTS.get(mixup_alpha)
+    if r is None:
+        r = _DEFAULTS[mixup_alpha] = DeviceRand(mixup_alpha)
+    return r
 
 
 class InjectedRand:

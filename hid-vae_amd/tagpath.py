@@ -209,26 +209,30 @@ class GateFn(Function):
 
 
 class BatchNormFn(Function):
-    """y = dropout(relu?(BatchNorm1d(x))) in one launch; training updates the running statistics in place."""
+    """y = dropout(relu?(BatchNorm1d(x))) in one launch; training updates the running statistics in place.  mask: a keep-mask tensor
+    (injected draws) or a _C.DropSpec (decided inside the launch); the backward reads the gate off the saved output either way."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, momentum, eps, training, relu, mask, mask_scale):
         ctx.set_materialize_grads(False)
         y, sm, sr = _C.batchnorm_fwd(x, gamma, beta, eps, momentum, training, running_mean, running_var, relu, mask, mask_scale,
                                      num_batches=num_batches)
-        ctx.save_for_backward(x, gamma, beta, sm, sr, mask)
-        ctx.cfg = (relu, mask_scale, training)
+        gate_from_y = relu  # (Dropout without ReLU does not occur in the reference's heads; a bare mask then stays a tensor)
+        if mask is not None and not relu and not torch.is_tensor(mask):
+            raise NotImplementedError("in-kernel dropout after a BatchNorm without ReLU")
+        ctx.save_for_backward(x, gamma, beta, sm, sr, y if gate_from_y else None, mask if (torch.is_tensor(mask) and not gate_from_y) else None)
+        ctx.cfg = (relu, float(mask_scale) if mask is not None else 1.0, training)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         if gy is None:
             return (None,) * 12
-        x, gamma, beta, sm, sr, mask = ctx.saved_tensors
+        x, gamma, beta, sm, sr, y, mask = ctx.saved_tensors
         relu, mask_scale, training = ctx.cfg
         if not training:
             raise RuntimeError("BatchNorm1d in eval mode is not differentiated on the HIP path")
-        gx, gg, gb = _C.batchnorm_bwd(gy.contiguous(), x, gamma, beta, sm, sr, relu, mask, mask_scale, need_gx=ctx.needs_input_grad[0])
+        gx, gg, gb = _C.batchnorm_bwd(gy.contiguous(), x, gamma, beta, sm, sr, relu, mask, mask_scale, need_gx=ctx.needs_input_grad[0], y_out=y)
         _C.phase_mark(f"bwd:projector batchnorm done (then its first Linear)")
         return (gx, gg, gb) + (None,) * 9
 
@@ -364,8 +368,8 @@ def tag_predictor_forward(pred, x, x_gate=None, rand=None):
     Launches per call, forward: the gate 1, then GEMM (+ LayerNorm) per layer; backward: every activation / dropout gate rides in the
     launch that produces the gradient it applies to (LayerNorm backward or the next layer's input-gradient epilogue), and the
     LayerNorms' affine gradients are finished by one launch per backward pass."""
-    from .rand import DeviceRand
-    rand = rand or pred.rand or DeviceRand()
+    from .rand import default_rand
+    rand = rand or pred.rand or default_rand()
     training = pred.training
     if x.dim() != 2:
         raise RuntimeError("TagPredictor expects [batch, embed_dim]")
@@ -398,8 +402,8 @@ def tag_predictor_forward(pred, x, x_gate=None, rand=None):
 
 def tag_prediction_loss(loss_mod, logits, target, layer_idx=0, rand=None, level=None):
     """TagPredictionLoss.forward of the reference (loss.py:107-228); layer_idx only selects focal_params keys."""
-    from .rand import DeviceRand
-    rand = rand or loss_mod.rand or DeviceRand(loss_mod.mixup_alpha)
+    from .rand import default_rand
+    rand = rand or loss_mod.rand or default_rand(loss_mod.mixup_alpha)
     grad_mode = logits.requires_grad and torch.is_grad_enabled()
     C = logits.shape[1]
     fp = loss_mod.focal_params
@@ -430,21 +434,20 @@ def _tag_streams(device, n):
 
 
 def early_rand(rand, targets, device, n_levels, want_mixup):
-    """The step's random draws need nothing from the model: the keep-masks of every dropout site (one torch.bernoulli, ~30 us) and the
-    mixup pairing (one torch.rand + hidvae_mixup_plan, ~28 us; needs only the tag indices) are issued at the START of the forward on
-    the first tag stream, where they run beside the encoder instead of in front of it / between the quantiser and the heads.  The
-    generator is advanced in the same order as before (masks, then pairing), so the draws are the same numbers.
-    Only with every level on a stream of its own (HIDVAE_TAG_STREAMS=2); tag_heads_forward makes the other levels wait for them.
-    -> True if the draws were issued here."""
-    if os.environ.get("HIDVAE_TAG_STREAMS", "2") != "2" or n_levels < 2 or n_levels > 4:
+    """The step's random draws need nothing from the model: the generator's step counter (one tiny launch) and the mixup pairing (one
+    launch; needs only the tag indices) are issued at the START of the forward on the first tag stream, where they run beside the
+    encoder instead of in front of it / between the quantiser and the heads.  Only with every level on a stream of its own
+    (HIDVAE_TAG_STREAMS=2); tag_heads_forward makes the other levels wait for them.  -> True if the draws were issued here."""
+    if os.environ.get("HIDVAE_TAG_STREAMS", "2") != "2" or n_levels < 2 or n_levels > 4 or not hasattr(rand, "state"):
         return False
+    rand.state(device)  # (exists before anything is queued on the side stream)
     st = _tag_streams(device, n_levels + 1)
     main = torch.cuda.current_stream()
     st[1].wait_stream(main)
     targets.record_stream(st[1])
     with torch.cuda.stream(st[1]):
         rand.begin_step(device)
-        made = [rand._arena] if getattr(rand, "_arena", None) is not None else []
+        made = []
         if want_mixup:
             rand.prepare_mixup(targets, device)
             made += [t for triple in rand._mix for t in triple if torch.is_tensor(t)]

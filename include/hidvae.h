@@ -89,6 +89,7 @@ int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K,
                     const float *bias, float *C, int64_t ldc,
                     int epilogue, float *aux, int64_t ldaux,
                     const float *mask, int64_t ldmask, float mask_scale,
+                    const unsigned long long *rng_state, unsigned rng_site, unsigned drop_threshold,
                     int split_k, float *workspace, int accumulate, void *stream);
 
 /* OPT-IN bf16 throughput mode for large batches (BASELINE config 2 "bf16"; reference train_hidvae.py:77,80,186-189 plumbs mixed
@@ -134,19 +135,6 @@ int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, 
  * >= 2048 output tiles, or more sub-problems than fit) the call falls back to one hidvae_gemm_f32 / hidvae_linear_bwd per problem
  * (`workspace`, optional, is only used there). */
 typedef struct {
-    int layout;
-    int64_t M, N, K;
-    const float *A; int64_t lda;
-    const float *B; int64_t ldb;
-    const float *bias;
-    float *C; int64_t ldc;
-    int epilogue;
-    float *aux; int64_t ldaux;
-    const float *mask; int64_t ldmask; float mask_scale;
-    int accumulate;
-    float *workspace;
-} hidvae_gemm_problem;
-typedef struct {
     const float *g; int64_t ldg;
     const float *x; int64_t ldx;
     const float *W; int64_t ldw;
@@ -158,7 +146,6 @@ typedef struct {
     float *db; int accumulate_db;
     float *workspace;
 } hidvae_linear_bwd_problem;
-int hidvae_gemm_group(const hidvae_gemm_problem *problems_host, int n, void *stream);
 int hidvae_linear_bwd_group(const hidvae_linear_bwd_problem *problems_host, int n, void *stream);
 
 /* out[n] (+)= sum_m X[m,n]   (bias gradients; fixed summation order, bit-reproducible).  One launch for M <= 16384 (no
@@ -344,9 +331,18 @@ int hidvae_sum_prefix_slices(const float *const *src_host, const int32_t *width_
                              float *dst, void *stream);
 /* y = dropout(relu?(LayerNorm(x))) + residual   (nn.LayerNorm eps; h_rqvae.py:145,156,162,181,329) and its backward:
  * gx.  The residual's gradient is gy itself. */
+/* Dropout inside the producing launch: instead of a keep-mask tensor (keep_mask, kept for injected draws) the launches that end in a
+ * Dropout take (rng_state, rng_site, drop_threshold): the keep decision of element i is Philox4x32-10(key = rng_state[0], counter =
+ * (i, site, rng_state[1])) >= drop_threshold, with drop_threshold = round(p_drop * 2^32).  rng_state: 2 x uint64 on the device,
+ * {seed, step}; hidvae_rng_advance bumps `step` (once per forward pass), so replayed graphs draw fresh masks.  The backward never needs
+ * the mask: it reads the gate off the forward OUTPUT (y > 0 exactly where the unit was active and kept).  hidvae_dropout_mask
+ * materialises the 0/1 mask such a launch applies (tests; numel elements of site `site`). */
+int hidvae_rng_advance(unsigned long long *rng_state, void *stream);
+int hidvae_dropout_mask(float *out, int64_t numel, const unsigned long long *rng_state, unsigned site, unsigned threshold, void *stream);
 int hidvae_layernorm_fwd(const float *x, int64_t M, int64_t N, const float *gamma, const float *beta, float eps, float *y,
                          float *mean, float *rstd, int relu, const float *keep_mask, float keep_scale,
-                         const float *residual, void *stream);
+                         const float *residual, const unsigned long long *rng_state, unsigned rng_site, unsigned drop_threshold,
+                         void *stream);
 int hidvae_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
                          const float *rstd, int64_t M, int64_t N, int relu, const float *keep_mask, float keep_scale,
                          float *gx, void *stream);
@@ -389,32 +385,6 @@ int hidvae_gate_fwd(const float *x, int64_t ldx, int64_t B, int E, const float *
 int hidvae_gate_bwd(const float *gh, int64_t ldgh, const float *x, int64_t ldx, int64_t B, int E, const float *W0,
                     const float *W2, const float *W4, int normalize, float eps, const float *a1, const float *pre2,
                     const float *a3, const float *nrm, float *gx, float *g3, float *g2, float *g1, void *stream);
-/* grouped forms of the three ops above (up to 4 problems per launch; fields as the arguments of hidvae_act_bwd /
- * hidvae_layernorm_fwd / hidvae_layernorm_bwd_all; `workspace` per problem as hidvae_layernorm_bwd_all wants it).  Same arithmetic
- * and summation order per problem as the single-problem entry points: bit-identical results. */
-typedef struct {
-    const float *g, *ref;
-    int64_t numel;
-    int act;
-    const float *mask; float mask_scale;
-    float *out;
-} hidvae_act_bwd_problem;
-typedef struct {
-    const float *x; int64_t M, N;
-    const float *gamma, *beta; float eps;
-    float *y, *mean, *rstd;          /* forward outputs (mean / rstd are inputs of the backward) */
-    int relu;
-    const float *keep_mask; float keep_scale;
-    const float *residual;           /* forward only */
-    const float *gy;                 /* backward only from here on */
-    float *gx, *ggamma, *gbeta;
-    int accumulate;
-    float *workspace;
-} hidvae_layernorm_problem;
-int hidvae_act_bwd_group(const hidvae_act_bwd_problem *problems_host, int n, void *stream);
-int hidvae_layernorm_fwd_group(const hidvae_layernorm_problem *problems_host, int n, void *stream);
-int hidvae_layernorm_bwd_all_group(const hidvae_layernorm_problem *problems_host, int n, void *stream);
-
 /* BatchNorm1d (h_rqvae.py:325): y = dropout(relu?(BN(x))).  training != 0: batch statistics (biased variance for the
  * normalisation, unbiased for the running update with `momentum`), saved mean / rstd for the backward;
  * training == 0: running statistics.  num_batches_tracked (optional int64 device scalar) is incremented in training.
@@ -423,11 +393,13 @@ int hidvae_layernorm_bwd_all_group(const hidvae_layernorm_problem *problems_host
 int hidvae_batchnorm_fwd(const float *x, int64_t ldx, int64_t M, int64_t N, const float *gamma, const float *beta, float eps,
                          float momentum, int training, float *running_mean, float *running_var,
                          int64_t *num_batches_tracked, float *y, float *save_mean, float *save_rstd, int relu,
-                         const float *keep_mask, float keep_scale, float *workspace, void *stream);
+                         const float *keep_mask, float keep_scale, const unsigned long long *rng_state, unsigned rng_site,
+                         unsigned drop_threshold, float *workspace, void *stream);
+/* y_out (optional, instead of keep_mask): the forward OUTPUT, off which the ReLU -> Dropout gate is read */
 int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx, const float *gamma, const float *beta,
                          const float *save_mean, const float *save_rstd, int64_t M, int64_t N, int relu,
-                         const float *keep_mask, float keep_scale, float *gx, float *ggamma, float *gbeta, int accumulate,
-                         float *workspace, void *stream);
+                         const float *keep_mask, float keep_scale, const float *y_out, float *gx, float *ggamma, float *gbeta,
+                         int accumulate, float *workspace, void *stream);
 /* InfoNCE (loss.py:54-85) on the similarity matrix S = normalize(c) normalize(t)^T [B,B] produced by hidvae_gemm_f32:
  * rows: loss = scale * mean_b( logsumexp_j(S_bj/tau) - S_bb/tau ), S overwritten by softmax(S/tau);
  * dlogits: P <- (g*scale/(B*tau)) (P - I) in place, g a device scalar -- feed it to two GEMMs for d c / d t. */
@@ -447,10 +419,10 @@ int hidvae_infonce_dlogits_chunk(float *Sc, int64_t B, int64_t C, int64_t ldc, i
 int hidvae_infonce_dlogits(float *P, int64_t B, float tau, float scale, const float *g_dev, void *stream);
 /* The mixup plan of one training step for all L levels (loss.py:139-147: perm = randperm(n_valid), lam ~ Beta(alpha, alpha)):
  * targets [B, ld>=L] int64 (-1 = invalid row); uniforms [L, B+64] in [0,1) from the caller's generator (B sort keys + 64 spare
- * draws for the gamma sampler, per level).  partner [L,B]: partner[l][b] = the row mixed into b, a uniformly random permutation
+ * draws for the gamma sampler, per level), or NULL with rng_state: then the kernel draws them itself (counter-based, see hidvae_rng_advance).  partner [L,B]: partner[l][b] = the row mixed into b, a uniformly random permutation
  * of level l's valid rows among themselves, -1 on invalid rows; inverse [L,B]: inverse[l][partner[l][b]] = b; lam [L].  B <= 4096. */
 int hidvae_mixup_plan(const int64_t *targets, int64_t B, int L, int64_t ld_targets, const float *uniforms, float alpha,
-                      int64_t *partner, int64_t *inverse, float *lam, void *stream);
+                      int64_t *partner, int64_t *inverse, float *lam, const unsigned long long *rng_state, void *stream);
 /* TagPredictionLoss (loss.py:107-265) with the model's layer_idx = 0 call.  target -1 = invalid row.
  * partner[b] (NULL = no mixup): original-index row mixed into row b with weight 1-lam (loss.py:144-154); lam is a
  * DEVICE scalar (it is drawn per step, also under graph replay).

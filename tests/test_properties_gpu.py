@@ -122,44 +122,102 @@ def test_training_step_is_bitwise_reproducible():
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
 
 
-def test_device_rand_provider_properties():
-    """The production randomness provider (no golden can pin a device RNG stream): the mixup pairing is a permutation of the
-    valid rows among themselves with a consistent inverse, lam lies in (0,1), keep-masks are 0/1 with the requested rate, and the
-    one-launch mask arena hands out exactly the shapes the learning step saw (and falls back when the request list changes)."""
+def _philox4x32_10(key, c):
+    """reference Philox4x32-10 (Salmon et al., SC'11) on numpy uint64 lanes: key (k0, k1), counters c [n, 4] -> words [n, 4]"""
+    c = [c[:, i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack(c, 1)
+
+
+def test_device_rand_provider_properties(C):
+    """The production randomness provider (no golden can pin a device RNG stream).  Dropout is decided INSIDE the producing launches
+    by a counter-based generator: the generator is Philox4x32-10 bit for bit (known-answer vector of the Random123 distribution +
+    a numpy restatement on this provider's counters); keep rates are the requested ones; sites, steps and seeds give uncorrelated
+    masks; begin_step advances the device step; a launch given a DropSpec computes exactly what it computes given the materialised
+    mask (LayerNorm, BatchNorm, GEMM epilogue), and the backward -- which never sees the mask -- equals the mask-based backward.
+    Mixup: the pairing is a permutation of the valid rows among themselves with a consistent inverse, lam lies in (0,1)."""
     from hidvae_amd.rand import DeviceRand
     dev = torch.device("cuda")
-    r = DeviceRand(0.2)
-    g = torch.Generator().manual_seed(5)
-    tg = torch.randint(0, 7, (500, 3), generator=g)
-    tg[torch.rand(500, generator=g) < 0.3, 1] = -1
+    assert _philox4x32_10((0, 0), np.zeros((1, 4), np.uint64))[0].tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    r = DeviceRand(0.2, seed=0x1234567855AA33CC)
+    r.begin_step(dev)
+    r.begin_step(dev)
+    assert r.state(dev).tolist() == [0x1234567855AA33CC, 2]
+    spec = r.dropout_keep((300, 257), 0.4, dev)
+    spec2 = r.dropout_keep((300, 257), 0.4, dev)
+    assert (spec.site, spec2.site) == (0, 1)
+    m = C.dropout_mask(spec, (300, 257)).cpu().numpy()
+    n = 300 * 257
+    ctr = np.stack([np.arange(n, dtype=np.uint64), np.zeros(n, np.uint64), np.full(n, spec.site, np.uint64), np.full(n, 2, np.uint64)], 1)
+    words = _philox4x32_10((0x55AA33CC, 0x12345678), ctr)[:, 0]
+    want = (words >= np.uint64(spec.threshold)).astype(np.float32).reshape(300, 257)
+    assert np.array_equal(m, want), "the device generator is not Philox4x32-10 on (element, site, step)"
+    for p in (0.1, 0.4, 0.55):
+        mk = C.dropout_mask(r.dropout_keep((1024, 768), p, dev), (1024, 768))
+        assert set(torch.unique(mk).cpu().tolist()) <= {0.0, 1.0} and abs(float(mk.mean()) - (1 - p)) < 3e-3
+    a = C.dropout_mask(spec, (300, 257))
+    b = C.dropout_mask(spec2, (300, 257))                      # another site
+    r.begin_step(dev)
+    c = C.dropout_mask(C.DropSpec(r.state(dev), spec.site, 0.4), (300, 257))  # the same site, next step
+    d = C.dropout_mask(DeviceRand(0.2, seed=99).dropout_keep((300, 257), 0.4, dev), (300, 257))  # another seed
+    corr = lambda u, v: abs(float(torch.corrcoef(torch.stack([u.flatten(), v.flatten()]))[0, 1]))
+    assert corr(a, b) < 0.02 and corr(a, c) < 0.02 and corr(a, d) < 0.02 and not torch.equal(a, c)
+    # ---- launches: DropSpec == materialised mask, forward and backward
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(256, 691, device="cuda", generator=g)
+    gamma, beta = torch.randn(691, device="cuda", generator=g), torch.randn(691, device="cuda", generator=g)
+    sp = r.dropout_keep(x.shape, 0.4, dev)
+    mask = C.dropout_mask(sp, x.shape)
+    sc = 1.0 / 0.6
+    y0, mean, rstd = C.layernorm_fwd(x, gamma, beta, 1e-5, True, mask, sc, None)
+    y1, _, _ = C.layernorm_fwd(x, gamma, beta, 1e-5, True, sp, sc, None)
+    assert torch.equal(y0, y1)
+    gy = torch.randn_like(x)
+    gx0, _, _ = C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, True, mask, sc)
+    gx1, _ = C.layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, True, y1, sc)
+    assert torch.equal(gx0, gx1)
+    rm, rv = torch.zeros(691, device="cuda"), torch.ones(691, device="cuda")
+    b0, sm, sr = C.batchnorm_fwd(x, gamma, beta, 1e-5, 0.1, True, rm.clone(), rv.clone(), True, mask, sc)
+    b1, _, _ = C.batchnorm_fwd(x, gamma, beta, 1e-5, 0.1, True, rm.clone(), rv.clone(), True, sp, sc)
+    assert torch.equal(b0, b1)
+    h0 = C.batchnorm_bwd(gy, x, gamma, beta, sm, sr, True, mask, sc)
+    h1 = C.batchnorm_bwd(gy, x, gamma, beta, sm, sr, True, None, sc, y_out=b1)
+    assert all(torch.equal(u, v) for u, v in zip(h0, h1))
+    for (Mg, Ng, Kg) in ((256, 691, 768), (1000, 345, 691), (64, 38, 115), (4096, 768, 512)):
+        A, W, bias = torch.randn(Mg, Kg, device="cuda", generator=g), torch.randn(Ng, Kg, device="cuda", generator=g), torch.randn(Ng, device="cuda", generator=g)
+        sg = r.dropout_keep((Mg, Ng), 0.2, dev)
+        mg = C.dropout_mask(sg, (Mg, Ng))
+        o0 = C.gemm(C.GEMM_NT, A, W, bias=bias, epilogue=C.EPI_RELU, mask=mg, mask_scale=1.25, split_k=0)
+        o1 = C.gemm(C.GEMM_NT, A, W, bias=bias, epilogue=C.EPI_RELU, mask=sg, mask_scale=1.25, split_k=0)
+        assert torch.equal(o0, o1), (Mg, Ng, Kg)
+    # ---- mixup
+    gt = torch.Generator().manual_seed(5)
+    tg = torch.randint(0, 7, (500, 3), generator=gt)
+    tg[torch.rand(500, generator=gt) < 0.3, 1] = -1
     tg[:, 2] = -1
     tg[7, 2] = 3  # a level with a single valid row
     tgd = tg.to(dev)
-    for level, (partner, inverse, lam) in enumerate(r.mixup_all(tgd, dev)):
+    plans = r.mixup_all(tgd, dev)
+    for level, (partner, inverse, lam) in enumerate(plans):
         p, inv, t = partner.cpu(), inverse.cpu(), tg[:, level]
         valid = t >= 0
         assert (p[~valid] == -1).all() and (inv[~valid] == -1).all()
         assert sorted(p[valid].tolist()) == sorted(torch.nonzero(valid).flatten().tolist())  # a permutation of the valid rows
         assert (inv[p[valid]] == torch.nonzero(valid).flatten()).all()
         assert 0.0 <= float(lam) <= 1.0
+    r.begin_step(dev)
+    again = r.mixup_all(tgd, dev)
+    assert not torch.equal(again[0][0], plans[0][0]), "the pairing did not change with the step"
     r.prepare_mixup(tgd, dev)
     assert r.mixup_partner(tgd[:, 1], dev, level=1)[0].shape == (500,)
     single = r.mixup_partner(tgd[:, 0], dev)
     assert sorted(single[0].cpu().tolist()) == list(range(500))
-
-    reqs = [((256, 512), 0.1), ((256, 128), 0.3), ((256, 64), 0.05)]
-    for step in range(4):
-        r.begin_step(dev)
-        masks = [r.dropout_keep(s, p, dev) for s, p in reqs]
-        for (s, p), m in zip(reqs, masks):
-            assert tuple(m.shape) == s and m.is_contiguous()
-            assert set(torch.unique(m).cpu().tolist()) <= {0.0, 1.0}
-            assert abs(float(m.mean()) - (1 - p)) < 0.02
-        if step >= 2:  # learnt in step 0, arena from step 1 on: the views tile one buffer
-            assert masks[1].data_ptr() == masks[0].data_ptr() + 4 * masks[0].numel()
-    r.begin_step(dev)
-    odd = r.dropout_keep((100, 512), 0.1, dev)  # a different request list: individual draw, plan dropped
-    assert tuple(odd.shape) == (100, 512) and r._plan is None
 
 
 @pytest.mark.parametrize("mode,training", [(3, True), (2, True), (3, False)])
