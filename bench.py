@@ -2,10 +2,12 @@
 """bench.py -- items/s of one HiD-VAE tokenizer TRAIN step (forward + backward + grad all-reduce + AdamW) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL; per-rank batch fixed => weak scaling)
+    (N > 1: the script starts N rank processes itself -- or is started by torch.distributed.run --, one rank per GPU over RCCL;
+     per-rank batch fixed => weak scaling)
 
 Workload at N=1 = BASELINE.json configs[1]: Amazon-Beauty-shaped synthetic items, 768-d unit-norm inputs,
-hidden [512,256,128], D=32, 3 x 256 codebooks, ROTATION_TRICK, batch 1024 per GPU, amazon-gin hyper-parameters.
+hidden [512,256,128], D=32, 3 x 256 codebooks, ROTATION_TRICK, batch 1024 per GPU, amazon-gin hyper-parameters, WITH the tag heads
+(every h-config of the reference feeds tags: train_hidvae.py:698-709); the untagged core step is carried beside it.
 Inputs are resident in HBM before the timed region (a pool of pre-generated batches, one D2D copy per step).
 One JSON line on rank 0 carrying `roofline` (dominant kernel, timed live with HIP events) and `cpu_baseline`
 (the oracle's torch-CPU restatement of the same step, timed on this host for a bounded sample).
@@ -39,7 +41,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="items per GPU per step")
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--codes", type=int, default=256)
-    ap.add_argument("--tagged", type=int, default=0)
+    ap.add_argument("--tagged", type=int, default=1, help="1 (default): the HiD-VAE step with its tag heads -- every shipped h-config feeds "
+                    "tags (reference train_hidvae.py:698-709); 0: the untagged core step")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--pool", type=int, default=8, help="resident synthetic batches cycled through")
@@ -48,7 +51,8 @@ def parse():
     ap.add_argument("--kernels", type=int, default=1, help="time the dominant kernels for the roofline object (0 = skip, for profiling runs)")
     ap.add_argument("--also-large", type=int, default=8192, help="also time the same step at this per-GPU batch (reported as "
                     "`large_batch_step`; 0 = skip): shows the throughput-bound regime next to the latency-bound headline batch")
-    ap.add_argument("--also-tagged", type=int, default=1, help="also time the tagged step (reported as `tagged_step`)")
+    ap.add_argument("--also-other", type=int, default=1, help="also time the other variant of the step (untagged core when --tagged 1, "
+                    "tagged when --tagged 0), reported as `untagged_core_step` / `tagged_step`")
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the MEDIAN window is reported")
     return ap.parse_args()
 
@@ -146,9 +150,19 @@ def kernel_rooflines(args, m, device):
     pre = torch.randn(B, 512, device=device)
     t = time_kernel(lambda: _C.linear_bwd(gd, xd, wd, True, _C.EPI_DSILU, pre))
     fl2 = 4.0 * B * 768 * 512
-    out.append(dict(entry="hidvae_linear_bwd", kernel="gemm_mid_sk_kernel decoder layer 3 backward: dW [768,512] = g^T x and dX = (g W) * silu'(pre) in one launch (LDS-shared 64x64 tiles, one per workgroup)",
-                    bound="mfma", achieved=fl2 / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl2 / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
-                    us=t, flops=fl2))
+    dec = dict(kernel="gemm_mid_sk_kernel decoder layer 3 backward: dW [768,512] = g^T x and dX = (g W) * silu'(pre) in one launch (LDS-shared 64x64 tiles, one per workgroup)",
+               bound="mfma", achieved=fl2 / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl2 / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
+               us=t, flops=fl2)
+    # the tag heads' widest Linear backward (level 2's residual blocks, 691 <-> 768): dW + dX (through the ReLU -> Dropout gate of the layer
+    # below, read off its output) + db in one launch
+    gt, xt, wt, yt = torch.randn(B, 691, device=device), torch.randn(B, 768, device=device), torch.randn(691, 768, device=device) * 0.03, torch.rand(B, 768, device=device)
+    t = time_kernel(lambda: _C.linear_bwd(gt, xt, wt, True, _C.EPI_DRELU, yt, bias=True, dx_scale=1.6))
+    fl3 = 4.0 * B * 691 * 768
+    head = dict(kernel="gemm_mid_sk_kernel tag-head layer backward 691 x 768: dW = g^T x, dX = (g W) gated by the layer below, db (LDS-shared 64x64 tiles)",
+                bound="mfma", achieved=fl3 / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl3 / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
+                us=t, flops=fl3)
+    (head if args.tagged else dec)["entry"] = "hidvae_linear_bwd"  # the stand-alone figure quoted beside the in-step family of the headline
+    out += [dec, head]
     # the same layer in the throughput regime (LDS-tiled kernel; corpus tokenisation and large-batch training run here)
     bigm = 1 << 16
     xb, ob, ab = torch.randn(bigm, 768, device=device), torch.empty(bigm, 512, device=device), torch.empty(bigm, 512, device=device)
@@ -319,27 +333,6 @@ def cpu_baseline(args, budget_s):
                        + "; ".join(notes))
 
 
-def bf16_agreement(args, device):
-    """one forward + backward of the same model and batch in both precisions: how far the bf16 mode is from the fp32 step"""
-    from hidvae_amd import _C
-    pool_x, _, _ = synth_pool(argparse.Namespace(**{**vars(args), "pool": 1, "tagged": 0}), device, 0)
-    batch = types.SimpleNamespace(x=pool_x[0])
-    res = {}
-    for prec in ("bf16", "f32"):
-        _C.set_gemm_precision(prec)
-        m = build_model(args, device)
-        out = m(batch, gumbel_t=0.2)
-        out.loss.backward()
-        with torch.no_grad():
-            ids = m.get_semantic_ids(m.encode(batch.x), None, None, 0.2).sem_ids
-        res[prec] = (float(out.loss.detach()), ids, {k: float(p.grad.norm()) for k, p in m.named_parameters() if p.grad is not None})
-    _C.set_gemm_precision("f32")
-    (l16, i16, g16), (l32, i32, g32) = res["bf16"], res["f32"]
-    return dict(id_tuple_agreement=float((i16 == i32).all(dim=1).float().mean()), id_agreement_by_level=(i16 == i32).float().mean(0).tolist(),
-                loss_rel_deviation=abs(l16 - l32) / abs(l32),
-                max_grad_norm_rel_deviation=max(abs(g16[k] - g32[k]) / max(g32[k], 1e-12) for k in g32))
-
-
 def run_workload(args, device, rank, world, dist):
     """Build the model + optimizer, capture one full train step in a HIP graph, time K replays.  -> (seconds, model, info)"""
     from hidvae_amd.optim import HidvaeAdamW
@@ -502,48 +495,38 @@ def main():
 
     dt, m, info = run_workload(args, device, rank, world, dist)
     use_graph, final_loss = info["hip_graph"], info["final_loss"]
+    single = world == 1 and dist is None
     timeline = None
-    if rank == 0 and world == 1 and dist is None and use_graph and args.kernels:
+    if rank == 0 and single and use_graph and args.kernels:
         timeline = step_timeline(info["stepper"], info["pool_batch"], device)
-    tagged_extra = None
-    if world == 1 and not args.tagged and args.also_tagged:
-        targs = argparse.Namespace(**{**vars(args), "tagged": 1, "steps": max(20, args.steps // 4), "warmup": max(5, args.warmup // 2)})
-        tdt, _, tinfo = run_workload(targs, device, rank, world, dist)
-        tagged_extra = dict(value=targs.batch * targs.steps / tdt, unit="items/s", ms_per_step=tdt / targs.steps * 1e3, steps=targs.steps,
-                            hip_graph=tinfo["hip_graph"], windows_ms_per_step=tinfo["windows_ms_per_step"],
-                            workload="same shapes + tag heads (projector, InfoNCE, predictor, focal+mixup), amazon gin hyper-parameters")
-        if tinfo["hip_graph"] and args.kernels and dist is None:
-            trows, _ = step_timeline(tinfo["stepper"], tinfo["pool_batch"], device)
-            ttable, ttop, ttotal = summarize_timeline(trows)
-            tagged_extra["launches"] = len(trows)
-            tagged_extra["in_step_by_entry_point"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()} for a in ttable[:8]]
-            tagged_extra["roofline"] = dict(bound="mfma", kernel=describe_launch(ttop), us_per_launch=ttop["us_per_launch"], peak=MFMA_F32_PEAK_TF,
-                                            unit="TFLOP/s", achieved=ttop.get("flops", 0.0) / ttop["us"] * 1e-6,
-                                            frac=ttop.get("flops", 0.0) / ttop["us"] * 1e-6 / MFMA_F32_PEAK_TF, traffic=None, share_of_step=ttop["share"],
-                                            note="kernel family with the largest in-step time of the tagged step (device timestamps around every launch "
-                                                 "inside the replayed graph; the level branches run on 3 streams, so brackets include queueing behind each other)")
-        if args.cpu_seconds > 0:
-            tagged_extra["cpu_baseline"] = cpu_baseline(targs, max(4.0, args.cpu_seconds / 2))
-        del tinfo
 
+    def variant(vargs, label):
+        """the step's other variant (or the large-batch one) as a sub-object of the line: time, launches, in-step shares, own roofline"""
+        vdt, _, vinfo = run_workload(vargs, device, rank, world, dist)
+        ex = dict(value=vargs.batch * vargs.steps / vdt, unit="items/s", ms_per_step=vdt / vargs.steps * 1e3, steps=vargs.steps,
+                  batch=vargs.batch, hip_graph=vinfo["hip_graph"], windows_ms_per_step=vinfo["windows_ms_per_step"], workload=label)
+        if vinfo["hip_graph"] and args.kernels and dist is None and vargs.batch <= 2048:
+            vrows, _ = step_timeline(vinfo["stepper"], vinfo["pool_batch"], device)
+            vtable, vtop, _ = summarize_timeline(vrows)
+            ex["launches"] = len(vrows)
+            ex["in_step_by_entry_point"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()} for a in vtable[:8]]
+            ex["roofline"] = dict(bound="mfma", kernel=describe_launch(vtop), us_per_launch=vtop["us_per_launch"], peak=MFMA_F32_PEAK_TF,
+                                  unit="TFLOP/s", achieved=vtop.get("flops", 0.0) / vtop["us"] * 1e-6,
+                                  frac=vtop.get("flops", 0.0) / vtop["us"] * 1e-6 / MFMA_F32_PEAK_TF, traffic=None, share_of_step=vtop["share"])
+        return ex, vargs
+
+    other_extra = other_args = None
+    if single and args.also_other:
+        oa = argparse.Namespace(**{**vars(args), "tagged": 0 if args.tagged else 1, "steps": max(20, args.steps // (1 if args.tagged else 4)),
+                                   "warmup": max(5, args.warmup // 2)})
+        other_extra, other_args = variant(oa, "untagged core step: encoder, L-level RQ, decoder, reconstruction + commitment losses (no tag heads)" if args.tagged
+                                          else "same shapes + tag heads (projector, InfoNCE, predictor, focal+mixup), amazon gin hyper-parameters")
+        if args.cpu_seconds > 0:
+            other_extra["cpu_baseline"] = cpu_baseline(other_args, max(4.0, args.cpu_seconds / 2))
     large_extra = None
-    if world == 1 and dist is None and not args.tagged and args.also_large and args.kernels:
-        largs = argparse.Namespace(**{**vars(args), "batch": args.also_large, "steps": max(20, args.steps // 5), "warmup": 5, "pool": 2})
-        ldt, _, linfo = run_workload(largs, device, rank, world, dist)
-        large_extra = dict(batch=largs.batch, value=largs.batch * largs.steps / ldt, unit="items/s", ms_per_step=ldt / largs.steps * 1e3,
-                           steps=largs.steps, hip_graph=linfo["hip_graph"], windows_ms_per_step=linfo["windows_ms_per_step"])
-        del linfo
-        # the same step in the OPT-IN bf16 throughput mode (hidvae_gemm_bf16: bf16 MFMA, fp32 accumulate, fp32 master weights and
-        # activations); a second figure -- the headline and every parity claim stay fp32
-        from hidvae_amd import _C as _Cq
-        _Cq.set_gemm_precision("bf16")
-        try:
-            bdt, bm, binfo = run_workload(largs, device, rank, world, dist)
-            large_extra["bf16_mode"] = dict(value=largs.batch * largs.steps / bdt, unit="items/s", ms_per_step=bdt / largs.steps * 1e3,
-                                            windows_ms_per_step=binfo["windows_ms_per_step"], **bf16_agreement(largs, device))
-            del binfo, bm
-        finally:
-            _Cq.set_gemm_precision("f32")
+    if single and args.also_large and args.kernels:
+        la = argparse.Namespace(**{**vars(args), "tagged": 0, "batch": args.also_large, "steps": max(20, args.steps // 5), "warmup": 5, "pool": 2})
+        large_extra, _ = variant(la, f"untagged core step at batch {args.also_large} (the per-GPU shard of BASELINE config 4): the throughput-bound regime")
 
     if rank == 0:
         if not args.kernels:  # profiling run of the step only (rocprofv3 timelines): no roofline object
@@ -560,25 +543,34 @@ def main():
             for key, val in pmc.items():  # a kernel whose name no longer matches a CSV row keeps traffic = null
                 if k["kernel"].startswith(key):
                     k["traffic"] = val
-        # `roofline` = the launch with the largest IN-STEP time (device timestamps inside the replayed graph); the stand-alone warm
-        # figure of the same shape (back-to-back launches on identical operands) is carried separately as us_warm / frac_warm
+        # `roofline` = the kernel family with the largest IN-STEP time (device timestamps inside the replayed graph); the stand-alone
+        # warm figure of the same shape (back-to-back launches on identical operands) is carried separately as us_warm / frac_warm
         roof, in_step = None, None
         if timeline is not None:
             rows, empty_us = timeline
             table, top, total = summarize_timeline(rows)
+            gemm_rows = [r for r in rows if "flops" in r]
             in_step = dict(launches=len(rows), sum_us=total, empty_bracket_us=empty_us,
-                           by_entry_point=[{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()} for a in table],
-                           launches_in_order=[dict(entry=r["entry"], us=round(r["us"], 2)) for r in rows])
+                           gemm_class=dict(launches=len(gemm_rows), us=sum(r["us"] for r in gemm_rows), flops=sum(r["flops"] for r in gemm_rows)),
+                           by_entry_point=[{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()} for a in table[:24]],
+                           note="brackets of launches on different streams overlap (the level branches run side by side): the sum exceeds the step time")
+            # the MFMA roofline is priced on the GEMM-class family with the largest in-step time (a LayerNorm launch has no FLOP count)
+            fam = next((a for a in table if a.get("flops")), None)
+            top = dict(fam) if fam is not None else top
+            top["us_per_launch"] = top["us"] / top["launches"]
+            top["shapes"] = sorted({(r.get("M"), r.get("N"), r.get("K")) for r in rows if r["entry"] == top["entry"] and "M" in r}, key=lambda t: -t[0] * t[1] * t[2])
             ach = top.get("flops", 0.0) / top["us"] * 1e-6
             warm = next((k for k in ks if k.get("entry") == top["entry"]), None)  # the family's largest launch, stand-alone and warm
             roof = dict(kernel=describe_launch(top), bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF,
-                        traffic=None, us=top["us_per_launch"], share_of_step=top["share"],
+                        traffic=None, us=top["us_per_launch"], share_of_step=top["us"] / total,
                         us_warm=warm["us"] if warm else None, frac_warm=warm["frac"] if warm else None)
-            # the family's single largest launch, in-step, with the PMC traffic of exactly that launch when profiles/ holds it
             big = max((r for r in rows if r["entry"] == top["entry"]), key=lambda r: r["us"])
             roof["largest_launch"] = dict(MxNxK=[big.get("M"), big.get("N"), big.get("K")], us=big["us"],
                                           achieved=big.get("flops", 0.0) / big["us"] * 1e-6, frac=big.get("flops", 0.0) / big["us"] * 1e-6 / MFMA_F32_PEAK_TF,
                                           traffic=(warm or {}).get("traffic"), us_warm=(warm or {}).get("us"))
+            # the whole step against the fp32 MFMA peak: every GEMM-class FLOP of the step over the step's wall time
+            roof["whole_step"] = dict(flops=in_step["gemm_class"]["flops"], achieved=in_step["gemm_class"]["flops"] / (dt / args.steps) * 1e-12,
+                                      frac=in_step["gemm_class"]["flops"] / (dt / args.steps) * 1e-12 / MFMA_F32_PEAK_TF)
         if roof is None:
             roof = dict(ks[0])
         line = {
@@ -587,18 +579,20 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Amazon-Beauty-shaped synthetic 768-d, {args.levels}x{args.codes} codebooks, batch {args.batch}/GPU, "
-                                   f"ROTATION_TRICK, {'tagged (projector+InfoNCE+predictor+focal/mixup)' if args.tagged else 'untagged core'}"
+                                   f"ROTATION_TRICK, {'tagged (projector+InfoNCE+predictor+focal/mixup: the step both h-configs run)' if args.tagged else 'untagged core'}"
                                    f" train step = fwd+bwd+{'RCCL all-reduce+' if world > 1 else ''}AdamW(cosine)",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(use_graph)},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                       "graph_queues": os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES"),
+                       "collectives_in_graph": bool(getattr(info["stepper"], "in_graph", False))},
             "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"], "us_per_launch": roof["us"]}
-                        | {k: roof[k] for k in ("share_of_step", "us_warm", "frac_warm", "largest_launch") if k in roof},
+                        | {k: roof[k] for k in ("share_of_step", "us_warm", "frac_warm", "largest_launch", "whole_step") if k in roof},
             "windows_ms_per_step": info["windows_ms_per_step"],
             "kernels": ks, "final_loss": final_loss,
         }
         if in_step is not None:
             line["in_step"] = in_step
-        if tagged_extra is not None:
-            line["tagged_step"] = tagged_extra
+        if other_extra is not None:
+            line["untagged_core_step" if args.tagged else "tagged_step"] = other_extra
         if large_extra is not None:
             line["large_batch_step"] = large_extra
         if world == 1 and args.cpu_seconds > 0:

@@ -81,7 +81,6 @@ _SIGNATURES = {
     "hidvae_gumbel_noise": [_vp, _i64, _f, _vp, _vp],
     "hidvae_gumbel_softmax_rows": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
     "hidvae_timestamp": [_vp, _vp],
-    "hidvae_gemm_bf16": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _vp, _i64, _i, _vp],
     "hidvae_linear_bwd_group": [_vp, _i, _vp],
 }
 WS_GEMM, WS_LINEAR_BWD, WS_COLSUM, WS_CODEBOOK_GRAD, WS_LAYERNORM_PARAM_GRAD, WS_LAYERNORM_BWD_ALL = 1, 2, 3, 4, 5, 6
@@ -353,51 +352,6 @@ def _host_ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-# ------------------------------------------------------------------------------------------------
-# OPT-IN bf16 throughput mode (include/hidvae.h, hidvae_gemm_bf16): large-batch Linear layers on bf16 MFMA with fp32 accumulation.
-# "f32" (default) is the parity path; "bf16" reroutes the GEMMs of the LDS-tiled regime (>= 2048 output tiles of 32x32, i.e. batches
-# from 4096 items on) and the Linear backward of batches >= 4096.  HIDVAE_GEMM_PRECISION=bf16 or set_gemm_precision("bf16").
-_GEMM_PRECISION = os.environ.get("HIDVAE_GEMM_PRECISION", "f32")
-
-
-def set_gemm_precision(p):
-    global _GEMM_PRECISION
-    if p not in ("f32", "bf16"):
-        raise ValueError("gemm precision is 'f32' or 'bf16'")
-    _GEMM_PRECISION = p
-
-
-def gemm_precision():
-    return _GEMM_PRECISION
-
-
-def gemm_bf16(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, accumulate=False, mask=None, mask_scale=1.0):
-    """hidvae_gemm_bf16: as gemm(), operands rounded to bf16 on the way into LDS, fp32 accumulate / epilogue"""
-    _f32(A, "A"), _f32(B, "B")
-    lda, ldb = _row_stride(A, "A"), _row_stride(B, "B")
-    if layout == GEMM_NT:
-        (M, K), (N, K2) = A.shape, B.shape
-    elif layout == GEMM_NN:
-        (M, K), (K2, N) = A.shape, B.shape
-    else:
-        (K, M), (K2, N) = A.shape, B.shape
-    if K != K2:
-        raise RuntimeError(f"gemm_bf16: inner dimensions differ ({K} vs {K2})")
-    if out is None:
-        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
-    ws, ws_floats = None, 0
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles < 256 and K >= 1024:  # deep K, few tiles (weight gradients): K slabs
-        ws_floats = min(32, max(2, K // 256), max(2, (512 + tiles - 1) // tiles)) * M * N
-        ws = torch.empty((ws_floats,), device=A.device, dtype=torch.float32)
-    ldaux = _row_stride(aux, "aux") if aux is not None else 0
-    ldmask = _row_stride(mask, "mask") if mask is not None else 0
-    _check(lib().hidvae_gemm_bf16(layout, M, N, K, _p(A), lda, _p(B), ldb, _p(bias), _p(out), _row_stride(out, "C"), int(epilogue), _p(aux),
-                                  ldaux, _p(mask), ldmask, float(mask_scale), _p(ws), ws_floats, int(bool(accumulate)), _stream()),
-           "hidvae_gemm_bf16")
-    return out
-
-
 class DropSpec:
     """Dropout evaluated INSIDE the launch that produces the activation (include/hidvae.h, hidvae_rng_advance): stands where a keep-mask
     tensor would.  state: device int64[2] {seed, step}; site: the dropout layer's number within the forward pass; p: drop probability."""
@@ -432,13 +386,6 @@ def dropout_mask(spec, shape):
 def gemm(layout, A, B, out=None, bias=None, epilogue=EPI_NONE, aux=None, split_k=1, accumulate=False, mask=None,
          mask_scale=1.0):
     """C = epilogue(op(A) op(B) + bias).  NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
-    if _GEMM_PRECISION == "bf16" and A.dim() == 2 and B.dim() == 2:
-        Mq, Nq = (A.shape[1] if layout == GEMM_TN else A.shape[0]), (B.shape[0] if layout == GEMM_NT else B.shape[1])
-        Kq = A.shape[0] if layout == GEMM_TN else A.shape[1]
-        if ((Mq + 31) // 32) * ((Nq + 31) // 32) >= 2048 and Kq >= 64:
-            if isinstance(mask, DropSpec):
-                mask = dropout_mask(mask, (Mq, Nq))
-            return gemm_bf16(layout, A, B, out=out, bias=bias, epilogue=epilogue, aux=aux, accumulate=accumulate, mask=mask, mask_scale=mask_scale)
     _f32(A, "A"), _f32(B, "B")
     lda, ldb = _row_stride(A, "A"), _row_stride(B, "B")
     if layout == GEMM_NT:
@@ -478,13 +425,6 @@ def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accu
         accumulate = False
     elif tuple(dW.shape) != (n_out, n_in) or not dW.is_contiguous():
         raise RuntimeError(f"linear_bwd: dW slot has shape {tuple(dW.shape)}, expected {(n_out, n_in)} contiguous")
-    if _GEMM_PRECISION == "bf16" and B >= 4096 and min(n_out, n_in) >= 32:  # opt-in throughput mode: dW, dX on bf16 MFMA, db in fp32
-        gemm_bf16(GEMM_TN, g, x, out=dW, accumulate=accumulate)
-        dXb = gemm_bf16(GEMM_NN, g, w, epilogue=epilogue, aux=aux) if need_dx else None
-        if bias:
-            db = colsum(g, out=db, accumulate=accumulate_db and db is not None)
-            return dW, dXb, db
-        return dW, dXb
     dX = torch.empty((B, n_in), device=g.device, dtype=torch.float32) if need_dx else None
     if bias and db is None:
         db = torch.empty((n_out,), device=g.device, dtype=torch.float32)

@@ -1652,45 +1652,6 @@ __global__ __launch_bounds__(64 * GROUP_WAVES) void gemm_group_kernel(GroupArgs 
     }
 }
 
-// The same group on the LDS-tiled kernel (64x64 workgroup tiles, one unsplit ORDER-G chain per output): chosen when the group as a
-// whole has enough 64x64 tiles to occupy the chip -- a single problem of a tag head does not (1024 x 768 outputs are 192 tiles for
-// 256 CUs, which is why hidvae_gemm_f32 keeps such problems on the direct kernels), three levels together do.  Sub-problem fields
-// reused: nbx = column tiles, nt = tiles, nb = workgroups (= tiles); kind 2 = column sums as above.
-__global__ __launch_bounds__(256) void gemm_group_tiled_kernel(GroupArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[2 * BK * 68];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * 68];
-    int bid = blockIdx.x, p = 0;
-    while (p + 1 < a.n && bid >= a.s[p].nb) {
-        bid -= a.s[p].nb;
-        p++;
-    }
-    const GroupSub &s = a.s[p];
-    if (s.kind == 2) {
-        colsum_group_body(s.g, (int64_t)bid * 32, As);
-        return;
-    }
-    const int nby = (int)(s.nt / s.nbx);
-    const int bx = bid % s.nbx, by = bid / s.nbx;
-    if (s.layout == HIDVAE_GEMM_NT) tile_body<2, 2, HIDVAE_GEMM_NT>(s.g, bx, by, s.nbx, nby, 0, As, Bs);
-    else if (s.layout == HIDVAE_GEMM_NN) tile_body<2, 2, HIDVAE_GEMM_NN>(s.g, bx, by, s.nbx, nby, 0, As, Bs);
-    else tile_body<2, 2, HIDVAE_GEMM_TN>(s.g, bx, by, s.nbx, nby, 0, As, Bs);
-}
-
-inline void group_tiled_sub(GroupSub &s, int layout, const GemmArgs &g) {
-    s.g = g;
-    s.g.k_per_split = hv_cdiv(g.K, BK) * BK;
-    s.g.partial = nullptr;
-    s.g.vecA = (g.lda % 4 == 0) && aligned16(g.A);
-    s.g.vecB = (g.ldb % 4 == 0) && aligned16(g.B);
-    s.layout = layout;
-    s.kind = 3;
-    s.split = 1;
-    s.deep = 0;
-    s.nbx = (int)hv_cdiv(g.N, 64);
-    s.nt = (int64_t)s.nbx * hv_cdiv(g.M, 64);
-    s.nb = (int)s.nt;
-}
-
 // fill one GEMM sub-problem with the group's dispatch rule; false: the problem is outside the direct kernels' regime
 inline bool group_gemm_sub(GroupSub &s, int layout, const GemmArgs &g) {
     if (!fits32bit(layout, g.M, g.N, g.K, g.lda, g.ldb) || hv_cdiv(g.M, 32) * hv_cdiv(g.N, 32) >= 2048) return false;
@@ -1699,7 +1660,7 @@ inline bool group_gemm_sub(GroupSub &s, int layout, const GemmArgs &g) {
     const bool f16 = use_direct16(g.M, g.N, g.K);
     s.kind = f16 ? 0 : 1;
     int sp = f16 ? pick_split16(g.M, g.N, g.K, 0) : pick_split32(g.M, g.N, g.K, 0);
-    static const int cap = getenv("HIDVAE_GROUP_SPLIT_CAP") ? atoi(getenv("HIDVAE_GROUP_SPLIT_CAP")) : 4;
+    constexpr int cap = 4;  // in-workgroup K split of a grouped sub-problem (measured: 1 -> 63 us, 2 -> 58 us, 4 -> 52 us for the three levels' widest layer)
     if (sp > GROUP_WAVES) sp = GROUP_WAVES;
     while (sp > cap && sp > 1) sp /= 2;
     s.split = sp;
@@ -1712,23 +1673,10 @@ inline bool group_gemm_sub(GroupSub &s, int layout, const GemmArgs &g) {
 }
 
 inline int launch_group(GroupArgs &a, hipStream_t s) {
-    // 64x64 tiles of the whole group: at >= GROUP_TILED_MIN of them the LDS-tiled form keeps every CU busy with long unsplit chains
-    int64_t t64 = 0;
-    for (int i = 0; i < a.n; i++)
-        if (a.s[i].kind != 2) t64 += hv_cdiv(a.s[i].g.M, 64) * hv_cdiv(a.s[i].g.N, 64);
-    static const int64_t tiled_min = getenv("HIDVAE_GROUP_TILED_MIN") ? atoll(getenv("HIDVAE_GROUP_TILED_MIN")) : 1000000;
-    const bool tiled = t64 >= tiled_min;
-    if (tiled)
-        for (int i = 0; i < a.n; i++)
-            if (a.s[i].kind != 2) {
-                const GemmArgs g = a.s[i].g;
-                group_tiled_sub(a.s[i], a.s[i].layout, g);
-            }
     int64_t blocks = 0;
     for (int i = 0; i < a.n; i++) blocks += a.s[i].nb;
     if (blocks == 0) return HIDVAE_OK;
-    if (tiled) hipLaunchKernelGGL(gemm_group_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(gemm_group_kernel, dim3((unsigned)blocks), dim3(64 * GROUP_WAVES), 0, s, a);
+    hipLaunchKernelGGL(gemm_group_kernel, dim3((unsigned)blocks), dim3(64 * GROUP_WAVES), 0, s, a);
     HV_LAUNCH_CHECK("gemm_group");
     return HIDVAE_OK;
 }
@@ -1770,8 +1718,7 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
         const int64_t wgs = hv_cdiv(M, 64) * hv_cdiv(N, 64);
         while (deep_splits > 2 && wgs * deep_splits > 2048) deep_splits /= 2;
     }
-    static const int force_tiled = getenv("HIDVAE_GEMM_FORCE_TILED") ? atoi(getenv("HIDVAE_GEMM_FORCE_TILED")) : 0;  // (experiments)
-    const bool big = (tiles32 >= 2048 && K >= 64) || !fits32 || deep_splits > 1 || (force_tiled && split_k > 1 && workspace != nullptr);
+    const bool big = (tiles32 >= 2048 && K >= 64) || !fits32 || deep_splits > 1;
     if (!big || split_k == 1) {
         if (!big) {
             // direct path.  split_k == 1: one wave per tile, sequential (ORDER-G) chain; otherwise spread K over up to 16
@@ -1780,23 +1727,20 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
             // NT with ONE exact chain per output (the id-determining forward layers), and the small NT problems the 16x16 form serves
             // anyway: 16x16 tiles with coalesced operand loads through per-wave LDS strips (gemm_directL16_kernel).  Bit-identical to
             // the register-path kernels (same ORDER-G16 chain); measured at B = 1024: 1024x512x768 19.5 -> 15.5 us, 1024x768x512
-            // 19.5 -> 13.2, 1024x256x512 10.8 -> 7.9, 1024x512x256 11.3 -> 7.4, 1000x300x333 12.7 -> 8.6 (HIDVAE_GEMM_L16=0: off)
-            static const int use_l16 = getenv("HIDVAE_GEMM_L16") ? atoi(getenv("HIDVAE_GEMM_L16")) : 1;
+            // 19.5 -> 13.2, 1024x256x512 10.8 -> 7.9, 1024x512x256 11.3 -> 7.4, 1000x300x333 12.7 -> 8.6
             const int64_t nt16 = hv_cdiv(M, 16) * hv_cdiv(N, 16);
             // the widest of them on LDS-shared 32x64 tiles (gemm_tile16_kernel): same chain, same bits, a third of the operand traffic
-            static const int use_t16 = getenv("HIDVAE_GEMM_T16") ? atoi(getenv("HIDVAE_GEMM_T16")) : 1;
             // -- where the tiles fill the chip in ONE round (192 .. 256 of them): 1024x512x768 16.1 -> 13.5 us (32x64), 2048x512x768
             // 24.9 -> 20.7 (64x64); with 1.5 rounds (1024x768x512 on 32x64 tiles) the finer-grained kernel below wins, 14.8 vs 16.3
             const int64_t t_small = hv_cdiv(M, 32) * hv_cdiv(N, 64), t_big = hv_cdiv(M, 64) * hv_cdiv(N, 64);
             const bool fit_small = t_small >= 192 && t_small <= 256, fit_big = t_big >= 224 && t_big <= 256;  // (192 64x64 tiles: no gain)
-            if (use_t16 && layout == HIDVAE_GEMM_NT && split_k == 1 && K >= 256 && (fit_small || fit_big || use_t16 >= 2)) {
-                const int rc = (use_t16 == 3 || (use_t16 == 1 && !fit_small)) ? launch_tile16<4, 4>(g, s) : launch_tile16<2, 4>(g, s);
+            if (layout == HIDVAE_GEMM_NT && split_k == 1 && K >= 256 && (fit_small || fit_big)) {
+                const int rc = !fit_small ? launch_tile16<4, 4>(g, s) : launch_tile16<2, 4>(g, s);
                 HV_REQUIRE(rc == 0, "gemm_f32: could not size the LDS of gemm_tile16_kernel");
                 HV_LAUNCH_CHECK("gemm_f32 tile16");
                 return HIDVAE_OK;
             }
-            if (use_l16 && layout == HIDVAE_GEMM_NT && nt16 >= 512 && nt16 <= 8192 && K >= 64 &&
-                (split_k == 1 || use_l16 == 2 || (use_direct16(M, N, K) && K >= 128))) {
+            if (layout == HIDVAE_GEMM_NT && nt16 >= 512 && nt16 <= 8192 && K >= 64 && (split_k == 1 || (use_direct16(M, N, K) && K >= 128))) {
                 constexpr int W16 = 4;
                 hipLaunchKernelGGL(gemm_directL16_kernel<W16>, dim3((unsigned)hv_cdiv(nt16, W16)), dim3(64 * W16), 0, s, g);
                 HV_LAUNCH_CHECK("gemm_f32 directL16");
@@ -1816,11 +1760,9 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
                 return HIDVAE_OK;
             }
             const int sp = pick_split32(M, N, K, split_k);
-            // HIDVAE_GEMM_LDS: 0 = register path only, 1 = the LDS-transposed loader wherever it applies, default (2) = where it
-            // measured faster: K shared out over >= 2 waves per tile, or >= 1024 tiles (one exact chain per tile at 512 tiles --
-            // the encoder's first layer at B = 1024 -- is bound by the chain itself: 21.5 us against 18.4 us)
-            static const int use_lds = getenv("HIDVAE_GEMM_LDS") ? atoi(getenv("HIDVAE_GEMM_LDS")) : 2;
-            if (layout != HIDVAE_GEMM_TN && sp <= 8 && (use_lds == 1 || (use_lds == 2 && (sp >= 2 || tiles32 >= 1024)))) {
+            // the LDS-transposed loader where it measured faster: K shared out over >= 2 waves per tile, or >= 1024 tiles (one exact chain
+            // per tile at 512 tiles -- the encoder's first layer at B = 1024 -- is bound by the chain itself: 21.5 us against 18.4 us)
+            if (layout != HIDVAE_GEMM_TN && sp <= 8 && (sp >= 2 || tiles32 >= 1024)) {
                 switch (sp) {
                     case 1: launch_directL<1>(layout, g, s); break;
                     case 2: launch_directL<2>(layout, g, s); break;
@@ -1879,14 +1821,12 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
     const int s32_0 = pick_split32(n_out, n_in, B, 0), s32_1 = pick_split32(B, n_in, n_out, 0);
     const bool pair32 = small && !use_direct16(n_out, n_in, B) && !use_direct16(B, n_in, n_out) && s32_0 <= 8 && s32_1 <= 8;
     const bool pair = pair16 || pair32;
-    // LDS-shared 64x64 tiles, evenly dealt (gemm_mid_sk_kernel): HIDVAE_GEMM_MID = 0 off, else KG (waves per workgroup / 4)
-    static const int mid_mode = getenv("HIDVAE_GEMM_MID") ? atoi(getenv("HIDVAE_GEMM_MID")) : 4;
-    static const int mid_pf = getenv("HIDVAE_GEMM_MID_PF") ? atoi(getenv("HIDVAE_GEMM_MID_PF")) : 2;
-    static const int mid_minq = getenv("HIDVAE_GEMM_MID_MINQ") ? atoi(getenv("HIDVAE_GEMM_MID_MINQ")) : 6;
-    static const int mid_slots = getenv("HIDVAE_GEMM_MID_SLOTS") ? atoi(getenv("HIDVAE_GEMM_MID_SLOTS")) : 0;
-    if (mid_mode > 0 && balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, dX != nullptr) &&
+    // LDS-shared 64x64 tiles, evenly dealt (gemm_mid_sk_kernel<4, 2>: 16 waves = 2x2 quarters x 4 k-groups, register prefetch two steps
+    // ahead; measured and not kept: 8-wave workgroups two per CU, four prefetch stages -- DESIGN.md)
+    constexpr int mid_minq = 6;  // shortest range worth a workgroup (steps)
+    if (balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, dX != nullptr) &&
         fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && (dX == nullptr || fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw))) {
-        const int KG = mid_mode >= 4 ? 4 : (mid_mode >= 2 ? 2 : 1), BKS = 16 * KG;
+        constexpr int KG = 4, BKS = 16 * KG;
         SkArgs a{};
         PairArgs &p = a.p;
         p.g0.M = n_out; p.g0.N = n_in; p.g0.K = B; p.g0.A = g; p.g0.lda = ldg; p.g0.B = x; p.g0.ldb = ldx; p.g0.C = dW; p.g0.ldc = lddw;
@@ -1905,7 +1845,7 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         a.nbc = db != nullptr ? (int)hv_cdiv(n_out, 32) : 0;
         a.cu = (int)hv_cdiv(B, 512);  // a 32-column strip of B rows, priced against a step's MFMAs (~1 us either way)
         a.S = p.nb0 * a.n0 + p.nb1 * a.n1 + a.nbc * a.cu;
-        const int slots = mid_slots > 0 ? mid_slots : (KG == 4 ? 256 : 512);
+        constexpr int slots = 256;  // one 16-wave workgroup per CU
         int G = a.S / mid_minq;
         if (G > slots) G = slots;
         if (G < 1) G = 1;
@@ -1914,9 +1854,8 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         // one tile per workgroup when the tiles fit the chip in one round and are short (B = 1024: 24.8 us against 29.1 for the 768 x 512
         // layer -- a range that ends inside a tile costs ~3.5 us of pipeline refill and hand-over); even ranges otherwise (B = 2048:
         // 45.6 against 80.3 us)
-        static const int mid_sched = getenv("HIDVAE_GEMM_MID_SCHED") ? atoi(getenv("HIDVAE_GEMM_MID_SCHED")) : 0;  // 1: tile per workgroup, 2: even ranges
         const int longest = a.n0 > (p.nb1 ? a.n1 : 0) ? a.n0 : a.n1;
-        const bool tiles = mid_sched == 1 || (mid_sched == 0 && p.nb0 + p.nb1 + a.nbc <= slots && longest * KG <= 96);
+        const bool tiles = p.nb0 + p.nb1 + a.nbc <= slots && longest * KG <= 96;
         if (tiles) {
             a.q = 0;
             a.G = p.nb0 + p.nb1 + a.nbc;
@@ -1924,10 +1863,7 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         if (p.nb0 + p.nb1 <= HV_SK_COUNTERS && (tiles || a.G <= HV_SK_MAX_G)) {
             a.counters = reinterpret_cast<int *>(workspace);
             a.slabs = workspace + HV_SK_COUNTERS;
-            int rc;
-            if (KG == 4) rc = mid_pf >= 4 ? launch_mid_sk<4, 4>(a, (hipStream_t)stream) : launch_mid_sk<4, 2>(a, (hipStream_t)stream);
-            else if (KG == 2) rc = mid_pf >= 4 ? launch_mid_sk<2, 4>(a, (hipStream_t)stream) : launch_mid_sk<2, 2>(a, (hipStream_t)stream);
-            else rc = mid_pf >= 4 ? launch_mid_sk<1, 4>(a, (hipStream_t)stream) : launch_mid_sk<1, 2>(a, (hipStream_t)stream);
+            const int rc = launch_mid_sk<4, 2>(a, (hipStream_t)stream);
             HV_REQUIRE(rc == 0, "linear_bwd: could not size the LDS of gemm_mid_sk_kernel");
             HV_LAUNCH_CHECK("linear_bwd mid");
             return HIDVAE_OK;
@@ -1965,11 +1901,10 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
     p.nb1 = (int)hv_cdiv(p.nt1, waves / p.split1);
     p.cs_x = g; p.cs_ld = ldg; p.cs_rows = B; p.cs_cols = n_out; p.cs_out = db; p.cs_accumulate = accumulate_db;
     const int nbc = db != nullptr ? (int)hv_cdiv(n_out, 32) : 0;
-    // (measured: staging the NN half's A operand through LDS makes the paired launch SLOWER -- tagged step 1.913 -> 1.959 ms, B = 2048
-    //  3.02 -> 3.09 ms: its row-contiguous B operand still takes 8 scalar loads per block and the 2-block stage is shallower than
-    //  the 6-deep register ring; only HIDVAE_GEMM_LDS=1 turns it on)
-    static const int pair_lds = getenv("HIDVAE_GEMM_LDS") ? atoi(getenv("HIDVAE_GEMM_LDS")) : 2;
-    p.lds_a = pair_lds == 1 && (size_t)(p.split0 > p.split1 ? p.split0 : p.split1) * (4096 + 32 * LSTR * 4) <= 65536;
+    // (measured in round 2 and removed: staging the NN half's A operand through LDS made the paired launch SLOWER, tagged step 1.913 ->
+    //  1.959 ms -- its row-contiguous B operand still takes 8 scalar loads per block and the 2-block stage is shallower than the 6-deep
+    //  register ring)
+    p.lds_a = 0;
     const dim3 grid((unsigned)(p.nb0 + p.nb1 + nbc)), block(64 * waves);
     const size_t lds32 = (size_t)waves * (4096 + (p.lds_a ? 32 * LSTR * 4 : 0));
     if (pair16) hipLaunchKernelGGL(gemm_pair16_kernel, grid, block, 0, (hipStream_t)stream, p);

@@ -1387,8 +1387,7 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     // small batches: split the codes over the 4 waves of a workgroup (16 items per workgroup) to cut the serial search
     // (codebooks that do not fit LDS -- 4 x 1024: the streamed code-split kernel up to 16384 items, 16 per workgroup; above that the
     //  staged kernel amortises a level's codes over 128 items per workgroup)
-    static const int stream_env = getenv("HIDVAE_RQ_STREAM") ? atoi(getenv("HIDVAE_RQ_STREAM")) : 1;
-    const bool csplit = (resident && a.KC % 128 == 0 && B <= 4096) || (!resident && stream_env && B <= 16384);
+    const bool csplit = (resident && a.KC % 128 == 0 && B <= 4096) || (!resident && B <= 16384);
     // large batches: 8 or 16 waves per workgroup (two / four per SIMD) share one LDS copy of the codebooks, so one wave's per-level VALU
     // work (rotation, loss, argmin merge) overlaps the other's MFMAs; LDS allows only one workgroup per CU either way
     // (measured at 1,048,576 items, 3x256: 4 waves 1050 us, 8 waves 787 us, 16 waves 704 us; 85 VGPRs, so 4 waves per SIMD fit)
@@ -1399,11 +1398,10 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
     const int grid = (int)(ntiles < gcap ? ntiles : gcap);  // grid-stride over tiles
     hipStream_t s = (hipStream_t)stream;
     // large batches whose codebooks fit as bf16 hi/lo images: split-bf16 prefilter, then the exact kernel over the items it could not
-    // decide (bit-identical results; needs the caller's workspace for that list).  HIDVAE_RQ_PREFILTER=0: exact kernels only.
-    static const int pf_env = getenv("HIDVAE_RQ_PREFILTER") ? atoi(getenv("HIDVAE_RQ_PREFILTER")) : 1;
+    // decide (bit-identical results; needs the caller's workspace for that list: without one the exact kernels run alone)
     const int KCp = (int)(hv_cdiv(K, 32) * 32);
     const size_t pf32_bytes = pf32_level_bytes(KCp) * (size_t)L;
-    if (pf_env != 0 && workspace != nullptr && B >= 256 * 256 && B < (1ll << 31) && pf32_bytes <= 152 * 1024) {
+    if (workspace != nullptr && B >= 256 * 256 && B < (1ll << 31) && pf32_bytes <= 152 * 1024) {
         const bool ids_only = !training && !z && !emb_cat && !emb_sum && !res_cat && !qloss;  // eval, every output but ids NULL
         FwdArgs p = a;
         p.KC = KCp;

@@ -15,7 +15,7 @@ static inline bool hv_lbwd_balanced(int64_t B, int64_t n_out, int64_t n_in, bool
     // measured crossover ~0.9 GFLOP (B = 1024: 460 x 512 wins, 512 x 256 loses; B = 2048: 512 x 256 wins, 256 x 128 loses)
     const int64_t t64 = ((n_out + 63) / 64) * ((n_in + 63) / 64), u64 = ((B + 63) / 64) * ((n_in + 63) / 64);
     const double mflop = 2.0e-6 * (double)B * (double)n_out * (double)n_in * (has_dx ? 2.0 : 1.0);
-    static const double min_mflop = getenv("HIDVAE_GEMM_MID_MIN_MFLOP") ? atof(getenv("HIDVAE_GEMM_MID_MIN_MFLOP")) : 900.0;  // (experiments, tests)
-    static const int64_t max_b = getenv("HIDVAE_GEMM_MID_MAX_B") ? atoll(getenv("HIDVAE_GEMM_MID_MAX_B")) : 16384;
+    constexpr double min_mflop = 900.0;
+    constexpr int64_t max_b = 16384;
     return n_out >= 64 && n_in >= 64 && B >= 256 && B <= max_b && t64 + u64 <= HV_SK_COUNTERS && mflop >= min_mflop;
 }

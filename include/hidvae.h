@@ -92,16 +92,6 @@ int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K,
                     const unsigned long long *rng_state, unsigned rng_site, unsigned drop_threshold,
                     int split_k, float *workspace, int accumulate, void *stream);
 
-/* OPT-IN bf16 throughput mode for large batches (BASELINE config 2 "bf16"; reference train_hidvae.py:77,80,186-189 plumbs mixed
- * precision, every shipped config runs amp=False).  Same contract as hidvae_gemm_f32 with operands and results still fp32 in memory:
- * operands are rounded to bf16 (RNE) on their way into LDS, products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the
- * epilogue is computed in fp32.  128x128 workgroup tiles; deep-K problems with few tiles (weight gradients) are cut into K slabs
- * through `workspace` (workspace_floats >= 2*M*N enables it; slabs summed in ascending order).  Results differ from the fp32 path
- * at the 1e-3 level: never selected by default, parity is claimed on fp32 (bench.py reports id agreement and loss deviation). */
-int hidvae_gemm_bf16(int layout, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
-                     const float *bias, float *C, int64_t ldc, int epilogue, float *aux, int64_t ldaux, const float *mask,
-                     int64_t ldmask, float mask_scale, float *workspace, int64_t workspace_floats, int accumulate, void *stream);
-
 /* Backward of y = x W^T (nn.Linear without bias; encoder.py:27-31 as autograd differentiates it) in ONE launch:
  *   dW [n_out, n_in] = g^T x          (g [B, n_out], x [B, n_in])
  *   dX [B, n_in]     = epi(g W)       (W [n_out, n_in]; dx_epilogue = HIDVAE_EPI_NONE or a backward code D* whose `aux`

@@ -20,7 +20,7 @@ QUOTED = [
     ("gemm_mid_sk_kernel decoder layer 3 backward", "gemm_mid_sk_kernel<4, 2>", 229376),   # 96 + 128 tiles (no bias here), 1024 threads each
     ("gemm_mid_sk_kernel even ranges (B=8192, 256x512 layer)", "gemm_mid_sk_kernel<4, 2>", 262144),
     ("rq_forward_kernel streamed code-split (4x1024, B=4096)", "rq_forward_kernel<3, true, false, true, 4, true>", None),
-    ("gemm_bf16_kernel<NT> encoder layer 0 at 8192 rows", "gemm_bf16_kernel<0>", None),
+    ("rq_forward ids-only at 1,048,576 items", "rq_forward_pf32_kernel<2, false, 16, 8, true, true>", None),
 ]
 
 

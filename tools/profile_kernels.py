@@ -34,7 +34,7 @@ for _ in range(10):
     _C.linear_bwd(g1, o0, w1, True, _C.EPI_DSILU, pre)  # the paired dW + dX launch of encoder layer 1
     _C.rq_forward(y_small, cb, cc, True, 3, True, 0.4)
 # round 2: the launch family that leads the step (hidvae_linear_bwd, gemm_mid_sk on the decoder's last layer), the streamed
-# code-split RQ kernel of config 5 (4 x 1024 codes, B = 4096) and the opt-in bf16 GEMM
+# code-split RQ kernel of config 5 (4 x 1024 codes, B = 4096)
 wd3 = torch.randn(768, 512, device=dev) * 0.03
 gd, xd, pd = torch.randn(B, 768, device=dev), torch.randn(B, 512, device=dev), torch.randn(B, 512, device=dev)
 tabs5 = [(torch.rand(1024, 32, device=dev) * 2 - 1) * (1.0 if i == 0 else 0.35 * 0.5 ** i) for i in range(4)]
@@ -47,12 +47,24 @@ for _ in range(10):
     _C.linear_bwd(gd, xd, wd3, True, _C.EPI_DSILU, pd)
     _C.rq_forward(y5, cb5, cc5, True, 3, True, 0.4)
     _C.gemm(_C.GEMM_NT, x8, w0, out=o8, epilogue=_C.EPI_SILU, aux=a8)       # fp32 LDS-tiled at B = 8192
-    _C.gemm_bf16(_C.GEMM_NT, x8, w0, out=o8, epilogue=_C.EPI_SILU, aux=a8)  # the same layer in the opt-in bf16 mode
     _C.linear_bwd(g8, o8, w1, True, _C.EPI_DSILU, a8)                       # gemm_mid_sk_kernel with even k-step ranges (B = 8192)
 xb = torch.randn(1 << 16, 768, device=dev)
 ob, ab = torch.empty(1 << 16, 512, device=dev), torch.empty(1 << 16, 512, device=dev)
+# round 3: the tag heads' level-2 shapes (the widest Linear backward, LayerNorm both ways, the gate) and the ids-only corpus search
+gt, xt, wt, yt = torch.randn(B, 691, device=dev), torch.randn(B, 768, device=dev), torch.randn(691, 768, device=dev) * 0.03, torch.rand(B, 768, device=dev)
+gam, bet = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+xc = torch.randn(B, 96, device=dev)
+gW = [torch.randn(24, 96, device=dev) * 0.1, torch.randn(24, device=dev), torch.randn(48, 24, device=dev) * 0.1, torch.randn(48, device=dev),
+      torch.randn(96, 48, device=dev) * 0.1, torch.randn(96, device=dev)]
+for _ in range(10):
+    _C.linear_bwd(gt, xt, wt, True, _C.EPI_DRELU, yt, bias=True, dx_scale=1.6)   # 1024 x 691 x 768: the heads' widest backward launch
+    yl, ml, rl = _C.layernorm_fwd(xt, gam, bet, 1e-5, True, None, 1.0, None)
+    _C.layernorm_bwd_partial(xt, xt, gam, bet, ml, rl, True, yl, 1.0, 0.0)
+    hh, sv = _C.gate_fwd(xc, *gW, True)
+    _C.gate_bwd(hh, xc, gW[0], gW[2], gW[4], True, sv)
 for _ in range(5):
     _C.rq_forward(y_big, cb, cc, True, 3, True, 0.4)
+    _C.rq_ids(y_big, cb, cc, True)                                     # the tokenizer's corpus pass: only the ids leave the launch
     _C.gemm(_C.GEMM_NT, xb, w0, out=ob, epilogue=_C.EPI_SILU, aux=ab)  # the LDS-tiled kernel (throughput regime)
 torch.cuda.synchronize()
 print("done")
