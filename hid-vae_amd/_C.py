@@ -29,20 +29,20 @@ _SIGNATURES = {
     "hidvae_gate_fwd": [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_gate_bwd": [_vp, _i64, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
-    "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
-    "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _i, _vp],
+    "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_bottleneck_fwd": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp,
                               _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _vp],
-    "hidvae_uniq_loss": [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
-    "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
-    "hidvae_total_loss_bwd": [_vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp],
-    "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _i, _vp],
+    "hidvae_uniq_loss": [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _i, _vp],
+    "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "hidvae_total_loss_bwd": [_vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _i, _vp],
+    "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _i64, _vp, _vp, _vp, _vp],
     "hidvae_l2norm_fwd": [_vp, _i64, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm32_fwd": [_vp, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _f, _vp, _i64, _i, _vp],
-    "hidvae_id_stats": [_vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _vp],
+    "hidvae_id_stats": [_vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _i, _vp],
     "hidvae_act_bwd": [_vp, _vp, _i64, _i, _vp, _f, _vp, _vp],
     "hidvae_binary": [_i, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "hidvae_sum_prefix_slices": [_vp, _vp, _i, _i64, _i64, _vp, _vp],
@@ -62,17 +62,17 @@ _SIGNATURES = {
     "hidvae_mixup_plan": [_vp, _i64, _i, _i64, _vp, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_fwd": [_vp, _i64, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
-    "hidvae_kmeans_iter": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_kmeans_iter": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_gumbel_rows_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _f, _vp, _vp],
     "hidvae_gumbel_loss": [_vp, _vp, _i64, _f, _vp, _vp],
     "hidvae_gumbel_gemb": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp],
     "hidvae_gumbel_rows_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
     "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _vp],
-    "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_padded_to_jagged": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp],
     "hidvae_jagged_to_padded": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
-    "hidvae_codebook_prepare_adamw": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
+    "hidvae_codebook_prepare_adamw": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _i, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
     "hidvae_query_workspace": [_i, _vp, _i, _vp],
@@ -315,21 +315,20 @@ def _ws(op, device, *dims):
 
 # hidvae_linear_bwd's balanced kernel keeps arrival counters at the head of its workspace: zero on entry, zero again on return, and
 # never shared by launches that may run at the same time.  Launches on one stream are serialised, so ONE persistent zero-filled
-# buffer per (device, lane) serves them all; lane 0 is "whatever stream the caller is on", and every side stream that runs Linear
-# backwards concurrently with it (the per-level tag-head streams) registers a lane of its own.
-_WS_LANES = {}
+# buffer per (device, stream) serves them all -- keyed by the ACTUAL stream every launch goes to (round 2 mapped every unregistered
+# stream to one shared lane: two Linear backwards on different user streams would have shared counters, silently).  Buffers are
+# allocated lazily and never freed (a captured graph may hold their address).
 _WS_LANE_BUFFERS = {}
 _WS_RETIRED = []  # outgrown buffers stay alive: a captured graph may still hold their address
 
 
 def register_ws_lane(stream):
-    """Give `stream` its own hidvae_linear_bwd workspace (call once per side stream that runs backward GEMMs concurrently)."""
-    return _WS_LANES.setdefault(int(stream.cuda_stream), len(_WS_LANES) + 1)
+    """kept for callers that announce their side streams; every stream gets a workspace of its own on first use anyway"""
+    return int(stream.cuda_stream)
 
 
 def _lane_ws(device, nbytes):
-    lane = _WS_LANES.get(int(torch.cuda.current_stream(device).cuda_stream), 0)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), lane)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(device).cuda_stream))
     buf = _WS_LANE_BUFFERS.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         if torch.cuda.is_current_stream_capturing():
@@ -340,6 +339,19 @@ def _lane_ws(device, nbytes):
         buf = torch.zeros((nbytes // 4,), device=device, dtype=torch.float32)
         _WS_LANE_BUFFERS[key] = buf
     return buf
+
+
+def reset_lane_workspaces():
+    """zero every persistent hidvae_linear_bwd workspace again (called when a launch reported an error: a launch that did not run to
+    its end may have left arrival counters behind, and every later launch on that stream would silently add wrong partial tiles)"""
+    for buf in list(_WS_LANE_BUFFERS.values()) + _WS_RETIRED:
+        buf.zero_()
+
+
+def lane_counters_clean():
+    """True when every persistent workspace's arrival counters are zero (debug / tests; synchronises)"""
+    n = workspace_bytes(WS_LINEAR_BWD_ZEROED, 1024, 768, 512, 0) // 4
+    return all(not bool(buf[:n].any()) for buf in _WS_LANE_BUFFERS.values())
 
 
 def census_scratch(B, device):
@@ -433,10 +445,14 @@ def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accu
         ws = _lane_ws(g.device, workspace_bytes(WS_LINEAR_BWD, B, n_out, n_in, int(bool(bias))))
     else:
         ws = _ws(WS_LINEAR_BWD, g.device, B, n_out, n_in, int(bool(bias)))
-    _check(lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
-                                   _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, int(bool(accumulate)), _p(dX), n_in,
-                                   int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, float(dx_scale),
-                                   _p(db if bias else None), int(bool(accumulate_db)), _p(ws), _stream()), "hidvae_linear_bwd")
+    rc = lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
+                                 _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, int(bool(accumulate)), _p(dX), n_in,
+                                 int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, float(dx_scale),
+                                 _p(db if bias else None), int(bool(accumulate_db)), _p(ws), _stream())
+    if rc != 0:
+        msg = lib().hidvae_last_error().decode()
+        reset_lane_workspaces()  # the zero-on-entry contract of the arrival counters may no longer hold
+        raise RuntimeError(f"hidvae_linear_bwd failed ({rc}): {msg}")
     if bias:
         return dW, dX, db
     return dW, dX
@@ -452,12 +468,17 @@ def colsum(X, out=None, accumulate=False):
     return out
 
 
+def check_embed_dim(D):
+    if not (D == EMBED_DIM or (4 <= D <= 64 and D % 4 == 0)):
+        raise NotImplementedError(f"embed_dim={D}: the quantiser kernels take 32 (fused) or another multiple of 4 up to 64 (width-independent form)")
+
+
 def codebook_prepare(tables, normalize_flags):
-    """tables: list of L raw [K,32] tensors -> (cb_eff [L,K,32], cc [L,K])."""
+    """tables: list of L raw [K,D] tensors -> (cb_eff [L,K,D], cc [L,K]).  D = 32: the fused kernels; other multiples of 4 up to 64: the
+    width-independent kernels (csrc/rq_generic.hip)."""
     L = len(tables)
     K, D = tables[0].shape
-    if D != EMBED_DIM:
-        raise RuntimeError(f"the fused RQ kernels are specialised for embed_dim=32 (got {D})")
+    check_embed_dim(D)
     for t in tables:
         _f32(t, "codebook")
         if tuple(t.shape) != (K, D) or not t.is_contiguous():
@@ -470,10 +491,10 @@ def codebook_prepare(tables, normalize_flags):
         desc, step_dev, b1, b2, eta_min, T_max, step_size, gamma = carried
         _check(lib().hidvae_codebook_prepare_adamw(_host_ptr_array(tables), flags, L, K, _p(cb), _p(cc), _p(step_dev), _p(desc["lr"]),
                                                    _p(desc["wd"]), int(desc["n"]), float(b1), float(b2), float(eta_min), int(T_max),
-                                                   int(step_size), float(gamma), _p(desc["hyper"]), _stream()),
+                                                   int(step_size), float(gamma), _p(desc["hyper"]), int(D), _stream()),
                "hidvae_codebook_prepare_adamw")
         return cb, cc
-    _check(lib().hidvae_codebook_prepare(_host_ptr_array(tables), flags, L, K, _p(cb), _p(cc), _stream()), "hidvae_codebook_prepare")
+    _check(lib().hidvae_codebook_prepare(_host_ptr_array(tables), flags, L, K, _p(cb), _p(cc), int(D), _stream()), "hidvae_codebook_prepare")
     return cb, cc
 
 
@@ -498,21 +519,21 @@ def take_pending_adamw(device, owner=None):
 
 def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=False, want_z=True):
     _f32(y, "y")
-    if y.dim() != 2 or y.shape[1] != EMBED_DIM or not y.is_contiguous():
-        raise RuntimeError(f"rq_forward: expected contiguous [B,32] input, got {tuple(y.shape)}")  # quantize.py:101
+    L, K, D = cb_eff.shape
+    if y.dim() != 2 or y.shape[1] != D or not y.is_contiguous():
+        raise RuntimeError(f"rq_forward: expected contiguous [B,{D}] input, got {tuple(y.shape)}")  # quantize.py:101
     B = y.shape[0]
-    L, K, _ = cb_eff.shape
     dev = y.device
-    z = torch.empty((B, EMBED_DIM), device=dev, dtype=torch.float32) if (want_z or normalize_input) else None
+    z = torch.empty((B, D), device=dev, dtype=torch.float32) if (want_z or normalize_input) else None
     ids = torch.empty((B, L), device=dev, dtype=torch.int64)
-    emb_cat = torch.empty((B, L * EMBED_DIM), device=dev, dtype=torch.float32)
-    emb_sum = torch.empty((B, EMBED_DIM), device=dev, dtype=torch.float32)
-    res = torch.empty((B, L * EMBED_DIM), device=dev, dtype=torch.float32) if want_res else None
+    emb_cat = torch.empty((B, L * D), device=dev, dtype=torch.float32)
+    emb_sum = torch.empty((B, D), device=dev, dtype=torch.float32)
+    res = torch.empty((B, L * D), device=dev, dtype=torch.float32) if want_res else None
     qloss = torch.empty((B,), device=dev, dtype=torch.float32)
-    ws = _ws(WS_RQ_FORWARD, dev, B, L, K)
+    ws = _ws(WS_RQ_FORWARD, dev, B, L, K) if D == EMBED_DIM else None
     _check(lib().hidvae_rq_forward(_p(y), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, int(mode), int(bool(training)),
-                                   float(beta), _p(z), _p(ids), _p(emb_cat), L * EMBED_DIM, _p(emb_sum), _p(res), _p(qloss),
-                                   _p(ws), _stream()), "hidvae_rq_forward")
+                                   float(beta), _p(z), _p(ids), _p(emb_cat), L * D, _p(emb_sum), _p(res), _p(qloss),
+                                   _p(ws), int(D), _stream()), "hidvae_rq_forward")
     return z if z is not None else y, ids, emb_cat, emb_sum, res, qloss
 
 
@@ -521,14 +542,14 @@ def rq_ids(y, cb_eff, cc, normalize_input=False):
     HSemanticIdTokenizer.precompute_corpus_ids (reference h_semids.py:109-195).  At corpus sizes the launch takes the ids-only form of
     the prefilter kernel (no output rows, no winner fetch after the last level); the ids are those of rq_forward bit for bit."""
     _f32(y, "y")
-    if y.dim() != 2 or y.shape[1] != EMBED_DIM or not y.is_contiguous():
-        raise RuntimeError(f"rq_ids: expected contiguous [B,32] input, got {tuple(y.shape)}")
+    L, K, D = cb_eff.shape
+    if y.dim() != 2 or y.shape[1] != D or not y.is_contiguous():
+        raise RuntimeError(f"rq_ids: expected contiguous [B,{D}] input, got {tuple(y.shape)}")
     B = y.shape[0]
-    L, K, _ = cb_eff.shape
     ids = torch.empty((B, L), device=y.device, dtype=torch.int64)
-    ws = _ws(WS_RQ_FORWARD, y.device, B, L, K)
+    ws = _ws(WS_RQ_FORWARD, y.device, B, L, K) if D == EMBED_DIM else None
     _check(lib().hidvae_rq_forward(_p(y), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, MODE_STE, 0, 0.0, None, _p(ids),
-                                   None, L * EMBED_DIM, None, None, None, _p(ws), _stream()), "hidvae_rq_forward")
+                                   None, L * D, None, None, None, _p(ws), int(D), _stream()), "hidvae_rq_forward")
     return ids
 
 
@@ -577,26 +598,26 @@ def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1
 
 def rq_backward(y, z, cb_eff, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z_in, gq, gq_items):
     B = z.shape[0]
-    L, K, _ = cb_eff.shape
+    L, K, D = cb_eff.shape
     g_y = torch.empty_like(z)
-    dE = torch.empty((B, L * EMBED_DIM), device=z.device, dtype=torch.float32)
+    dE = torch.empty((B, L * D), device=z.device, dtype=torch.float32)
     ldg = _row_stride(g_cat, "g_cat") if g_cat is not None else 0
     _check(lib().hidvae_rq_backward(_p(y), _p(z), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, int(mode), float(beta),
                                     _p(ids), _p(g_cat), ldg, _p(g_sum), _p(g_z_in),
                                     int(g_z_in.shape[0]) if g_z_in is not None else 0, float(gq), _p(gq_items), _vec_stride(gq_items), _p(g_y), _p(dE),
-                                    _stream()), "hidvae_rq_backward")
+                                    int(D), _stream()), "hidvae_rq_backward")
     return g_y, dE
 
 
 def codebook_grad(ids, dE_rows, tables, cb_eff, normalize_flags, grads=None, accumulate=False):
     B, L = ids.shape
-    K = tables[0].shape[0]
+    K, D = tables[0].shape
     if grads is None:
         grads = [torch.empty_like(t) for t in tables]
     flags = (ctypes.c_int32 * L)(*[int(bool(f)) for f in normalize_flags])
-    ws = _ws(WS_CODEBOOK_GRAD, ids.device, B, L, K)
+    ws = _ws(WS_CODEBOOK_GRAD, ids.device, B, L, K) if D == EMBED_DIM else None
     _check(lib().hidvae_codebook_grad(_p(ids), _p(dE_rows), B, L, K, _host_ptr_array(tables), _p(cb_eff), flags,
-                                      _host_ptr_array(grads), int(accumulate), _p(ws), _stream()), "hidvae_codebook_grad")
+                                      _host_ptr_array(grads), int(accumulate), _p(ws), int(D), _stream()), "hidvae_codebook_grad")
     return grads
 
 
@@ -647,7 +668,8 @@ def id_stats(emb_cat, ids, want_norms=True, scratch=None):
     norms = torch.empty((B, L), device=dev, dtype=torch.float32) if want_norms else None
     pu = torch.empty((), device=dev, dtype=torch.float32)
     ld = _row_stride(emb_cat, "emb_cat") if emb_cat is not None else 0
-    _check(lib().hidvae_id_stats(_p(emb_cat if want_norms else None), ld, _p(ids), B, L, _p(norms), _p(pu), _p(scratch), _stream()),
+    D = emb_cat.shape[1] // L if emb_cat is not None else EMBED_DIM
+    _check(lib().hidvae_id_stats(_p(emb_cat if want_norms else None), ld, _p(ids), B, L, _p(norms), _p(pu), _p(scratch), int(D), _stream()),
            "hidvae_id_stats")
     return norms, pu
 
@@ -668,8 +690,9 @@ def adamw_step(desc, beta1, beta2, eps, grad_scale):
 def uniq_loss(ids, z, weight, margin, want_grad=False):
     B, L = ids.shape
     loss = torch.empty((), device=ids.device, dtype=torch.float32)
-    g_rows = torch.empty((L, EMBED_DIM), device=ids.device, dtype=torch.float32) if want_grad else None
-    _check(lib().hidvae_uniq_loss(_p(ids), _p(z), B, L, float(weight), float(margin), _p(loss), _p(g_rows), _stream()), "hidvae_uniq_loss")
+    D = z.shape[1]
+    g_rows = torch.empty((L, D), device=ids.device, dtype=torch.float32) if want_grad else None
+    _check(lib().hidvae_uniq_loss(_p(ids), _p(z), B, L, float(weight), float(margin), _p(loss), _p(g_rows), int(D), _stream()), "hidvae_uniq_loss")
     return loss, g_rows
 
 
@@ -680,19 +703,21 @@ def total_loss(recon, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, 
     uniq = torch.empty((), device=dev, dtype=torch.float32)
     L = ids.shape[1] if ids is not None else 0
     n_tag = len(aligns)
-    g_rows = torch.empty((L, EMBED_DIM), device=dev, dtype=torch.float32) if (want_grad and ids is not None) else None
+    D = z.shape[1] if z is not None else EMBED_DIM
+    g_rows = torch.empty((L, D), device=dev, dtype=torch.float32) if (want_grad and ids is not None) else None
     tagstats = torch.empty((3 + 3 * n_tag,), device=dev, dtype=torch.float32) if n_tag else None
     arr = lambda ts: _host_ptr_array(ts) if ts else None
     _check(lib().hidvae_total_loss(_p(recon), _p(qloss), recon.shape[0], arr(aligns), arr(preds), arr(accs), n_tag, float(tag_div),
                                    _p(ids), _p(z), L, float(uniq_weight), float(uniq_margin), float(w_a), float(w_p), float(w_u),
-                                   _p(loss), _p(uniq), _p(g_rows), _p(tagstats), None, _stream()), "hidvae_total_loss")
+                                   _p(loss), _p(uniq), _p(g_rows), _p(tagstats), None, int(D), _stream()), "hidvae_total_loss")
     return loss, uniq, g_rows, tagstats
 
 
-def total_loss_bwd(g_loss, B, L, w_a, w_p, w_u, g_rows, want_gz):
+def total_loss_bwd(g_loss, B, L, w_a, w_p, w_u, g_rows, want_gz, embed_dim=EMBED_DIM):
     scal = torch.empty((3,), device=g_loss.device, dtype=torch.float32)
-    g_z = torch.empty((B, EMBED_DIM), device=g_loss.device, dtype=torch.float32) if want_gz else None
-    _check(lib().hidvae_total_loss_bwd(_p(g_loss), B, L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(scal), _p(g_z), _stream()),
+    D = g_rows.shape[1] if g_rows is not None else int(embed_dim)
+    g_z = torch.empty((B, D), device=g_loss.device, dtype=torch.float32) if want_gz else None
+    _check(lib().hidvae_total_loss_bwd(_p(g_loss), B, L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(scal), _p(g_z), int(D), _stream()),
            "hidvae_total_loss_bwd")
     return scal, g_z
 
@@ -709,23 +734,25 @@ def loss_fwd(y, x, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, uni
     uniq = torch.empty((), device=dev, dtype=torch.float32)
     L = ids.shape[1] if ids is not None else 0
     n_tag = len(aligns)
-    g_rows = torch.empty((L, EMBED_DIM), device=dev, dtype=torch.float32) if (want_grad and ids is not None) else None
+    D = z.shape[1] if z is not None else EMBED_DIM
+    g_rows = torch.empty((L, D), device=dev, dtype=torch.float32) if (want_grad and ids is not None) else None
     tagstats = torch.empty((3 + 3 * n_tag,), device=dev, dtype=torch.float32) if n_tag else None
     summary = torch.empty((6,), device=dev, dtype=torch.float32)
     arr = lambda ts: _host_ptr_array(ts) if ts else None
     _check(lib().hidvae_loss_fwd(_p(y), _p(x), B, N, _p(qloss), arr(aligns), arr(preds), arr(accs), n_tag, float(tag_div), _p(ids), _p(z), L,
                                  float(uniq_weight), float(uniq_margin), float(w_a), float(w_p), float(w_u), _p(recon), _p(loss), _p(uniq),
-                                 _p(g_rows), _p(tagstats), _p(summary), _stream()), "hidvae_loss_fwd")
+                                 _p(g_rows), _p(tagstats), _p(summary), int(D), _stream()), "hidvae_loss_fwd")
     return loss, recon, uniq, g_rows, tagstats, summary
 
 
-def loss_bwd(g_loss, y, x, L, w_a, w_p, w_u, g_rows, want_gz):
+def loss_bwd(g_loss, y, x, L, w_a, w_p, w_u, g_rows, want_gz, embed_dim=EMBED_DIM):
     B, N = y.shape
     scal = torch.empty((3,), device=y.device, dtype=torch.float32)
     g_y = torch.empty_like(y)
-    g_z = torch.empty((B, EMBED_DIM), device=y.device, dtype=torch.float32) if want_gz else None
+    D = g_rows.shape[1] if g_rows is not None else int(embed_dim)
+    g_z = torch.empty((B, D), device=y.device, dtype=torch.float32) if want_gz else None
     _check(lib().hidvae_loss_bwd(_p(g_loss), _p(y), _p(x), B, N, L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(g_y), _p(scal), _p(g_z),
-                                 _stream()), "hidvae_loss_bwd")
+                                 int(D), _stream()), "hidvae_loss_bwd")
     return g_y, scal, g_z
 
 
@@ -967,7 +994,7 @@ def tag_loss_bwd(dmix, dkl, target, inverse, lam, g, n_valid):
 
 def kmeans_iter(x, centroids, assign, reseed_idx, new_centroids, shift_scratch, shift):
     _check(lib().hidvae_kmeans_iter(_p(x), x.shape[0], _p(centroids), centroids.shape[0], _p(assign), _p(reseed_idx), _p(new_centroids),
-                                    _p(shift_scratch), _p(shift), _stream()), "hidvae_kmeans_iter")
+                                    _p(shift_scratch), _p(shift), int(x.shape[1]), _stream()), "hidvae_kmeans_iter")
 
 
 # ------------------------------------------------------------------------------------------------ gumbel branch

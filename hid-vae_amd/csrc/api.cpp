@@ -47,7 +47,7 @@ extern "C" int hidvae_query_workspace(int op, const int64_t *d, int n, int64_t *
         if (need(3)) fl = hv_lbwd_balanced(d[0], d[1], d[2]) ? HV_SK_COUNTERS : 0;
         break;
     case HIDVAE_WS_COLSUM: if (need(2)) fl = cdiv(d[0], 64) * d[1]; break;                             // M, N
-    case HIDVAE_WS_CODEBOOK_GRAD: if (need(3)) fl = d[0] > 2048 ? d[1] * d[2] * cdiv(d[0], 2048) * HIDVAE_EMBED_DIM : 0; break;  // B, L, K
+    case HIDVAE_WS_CODEBOOK_GRAD: if (need(3)) fl = d[0] > 2048 ? d[1] * d[2] * cdiv(d[0], 2048) * 32 : 0; break;  // B, L, K  (the slabbed form belongs to the 32-wide kernels)
     case HIDVAE_WS_LAYERNORM_PARAM_GRAD: if (need(2)) fl = 2 * cdiv(d[0], 128) * d[1]; break;          // M, N
     case HIDVAE_WS_LAYERNORM_BWD_ALL: if (need(2)) fl = 2 * cdiv(d[0], 4) * d[1]; break;               // M, N
     case HIDVAE_WS_BATCHNORM_FWD: if (need(2)) fl = 3 * cdiv(d[0], 64) * d[1]; break;                  // M, N

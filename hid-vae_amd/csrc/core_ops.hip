@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 // the table when the 24-bit generation wraps).
 constexpr unsigned long long GEN_MOD = 0xFFFFFEull;
 __global__ __launch_bounds__(256) void id_stats_kernel(const float *emb_cat, int64_t ld_cat, const int64_t *ids, int64_t B, int L,
-                                                       float *embs_norm, unsigned long long *table, int64_t tsize, float *p_unique) {
+                                                       float *embs_norm, unsigned long long *table, int64_t tsize, float *p_unique, int D) {
     __shared__ int s_new;
     __shared__ int s_last;
     unsigned long long *ctrl = table + tsize;
@@ -204,10 +204,9 @@ __global__ __launch_bounds__(256) void id_stats_kernel(const float *emb_cat, int
     if (embs_norm != nullptr && idx < B * L) {
         const int64_t b = idx / L;
         const int i = (int)(idx - b * L);
-        const float4 *p = reinterpret_cast<const float4 *>(emb_cat + b * ld_cat + i * 32);
+        const float4 *p = reinterpret_cast<const float4 *>(emb_cat + b * ld_cat + i * D);
         float s = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < D / 4; j++) {  // (D = 32: eight float4, the order the fused middle launch reproduces)
             const float4 v = p[j];
             s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
@@ -312,13 +311,14 @@ extern "C" int hidvae_adamw_step(float *const *p_dev, const float *const *g_host
 }
 
 extern "C" int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, int64_t B, int L, float *embs_norm,
-                               float *p_unique, int64_t *scratch, void *stream) {
+                               float *p_unique, int64_t *scratch, int embed_dim, void *stream) {
     HV_REQUIRE(ids && p_unique && scratch && B >= 1 && L >= 1 && L <= HIDVAE_MAX_LEVELS, "id_stats: bad arguments");
-    HV_REQUIRE(embs_norm == nullptr || (emb_cat != nullptr && ld_cat >= (int64_t)L * 32 && ld_cat % 4 == 0), "id_stats: emb_cat/ld_cat");
+    HV_REQUIRE(embed_dim >= 4 && embed_dim <= 64 && embed_dim % 4 == 0, "id_stats: embed_dim=%d (a multiple of 4, at most 64)", embed_dim);
+    HV_REQUIRE(embs_norm == nullptr || (emb_cat != nullptr && ld_cat >= (int64_t)L * embed_dim && ld_cat % 4 == 0), "id_stats: emb_cat/ld_cat");
     const int64_t tsize = 4 * B;  // + 3 control words
     const int64_t n0 = B * (embs_norm != nullptr && L > 1 ? L : 1);
     hipLaunchKernelGGL(id_stats_kernel, dim3((unsigned)hv_cdiv(n0, 256)), dim3(256), 0, (hipStream_t)stream, emb_cat, ld_cat, ids, B, L,
-                       embs_norm, reinterpret_cast<unsigned long long *>(scratch), tsize, p_unique);
+                       embs_norm, reinterpret_cast<unsigned long long *>(scratch), tsize, p_unique, embed_dim);
     HV_LAUNCH_CHECK("id_stats");
     return HIDVAE_OK;
 }
@@ -348,13 +348,16 @@ extern "C" int hidvae_l2norm_bwd(const float *g, int64_t ldg, const float *out, 
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-// executed by ONE full wave; returns the loss on every lane; g_rows [L,32] (optional) = d loss / d z[0:L]
+// executed by ONE full wave; returns the loss on every lane; g_rows [L,D] (optional) = d loss / d z[0:L].  A lane per component
+// (lane < D <= 64; the lanes past D hold zeros, which the wave sums leave exact: at D = 32 the results are bit for bit those of
+// the 32-lane form this replaces)
 __device__ float uniq_loss_wave(const int64_t *ids, const float *z, int64_t B, int L, float weight, float margin,
-                                float *g_rows) {
+                                float *g_rows, int D) {
     const int lane = threadIdx.x & 63;
-    const int d = lane & 31;
+    const int d = lane;
+    const bool on = lane < D;
     if (g_rows != nullptr)
-        for (int i = lane; i < L * 32; i += 64) g_rows[i] = 0.0f;
+        for (int i = lane; i < L * D; i += 64) g_rows[i] = 0.0f;
     float total = 0.0f;
     int count = 0;
     unsigned long long flagged = 0ull;  // bit (a*8+b): levels a<b carry identical id vectors over the whole batch
@@ -380,22 +383,18 @@ __device__ float uniq_loss_wave(const int64_t *ids, const float *z, int64_t B, i
         for (int a = 0; a < L; a++)
             for (int b = a + 1; b < L; b++) {
                 if (!((flagged >> (a * 8 + b)) & 1ull) || b >= B) continue;  // (b >= B: the reference would raise IndexError)
-                const float za = z[(int64_t)a * 32 + d], zb = z[(int64_t)b * 32 + d];
-                float na = za * za, nb = zb * zb;
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { na += __shfl_xor(na, o); nb += __shfl_xor(nb, o); }
+                const float za = on ? z[(int64_t)a * D + d] : 0.0f, zb = on ? z[(int64_t)b * D + d] : 0.0f;
+                const float na = hv_wave_sum(za * za), nb = hv_wave_sum(zb * zb);
                 const float da = fmaxf(sqrtf(na), 1e-12f), db = fmaxf(sqrtf(nb), 1e-12f);
                 const float ha = za / da, hb = zb / db;
-                float ab = ha * hb;
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) ab += __shfl_xor(ab, o);
+                const float ab = hv_wave_sum(ha * hb);
                 const float v = ab - margin;
                 if (v > 0.0f) {
                     total += v;
-                    if (g_rows != nullptr && lane < 32) {  // d cos / d za = (hb - ha cos) / |za|
+                    if (g_rows != nullptr && on) {  // d cos / d za = (hb - ha cos) / |za|
                         const float c = weight / (float)count;
-                        g_rows[a * 32 + d] += c * (hb - ha * ab) / da;
-                        g_rows[b * 32 + d] += c * (ha - hb * ab) / db;
+                        g_rows[a * D + d] += c * (hb - ha * ab) / da;
+                        g_rows[b * D + d] += c * (ha - hb * ab) / db;
                     }
                 }
             }
@@ -404,8 +403,8 @@ __device__ float uniq_loss_wave(const int64_t *ids, const float *z, int64_t B, i
 }
 
 __global__ __launch_bounds__(64) void uniq_loss_kernel(const int64_t *ids, const float *z, int64_t B, int L, float weight,
-                                                       float margin, float *loss, float *g_rows) {
-    const float v = uniq_loss_wave(ids, z, B, L, weight, margin, g_rows);
+                                                       float margin, float *loss, float *g_rows, int D) {
+    const float v = uniq_loss_wave(ids, z, B, L, weight, margin, g_rows, D);
     if (threadIdx.x == 0) *loss = v;
 }
 
@@ -422,6 +421,7 @@ struct TotalArgs {
     float uniq_weight, uniq_margin;
     float w_a, w_p, w_u;
     float *loss, *uniq, *g_rows;
+    int D;            // embedding width (rows of z / g_rows)
     float *summary;   // optional [6]: loss, mean recon, mean qloss, tag align, tag pred, tag accuracy (the training log's row)
 };
 
@@ -446,7 +446,7 @@ __device__ __forceinline__ void total_loss_body(const TotalArgs &a) {
     q = hv_wave_sum(q);
     if (lane == 0) { red[0][wave] = r; red[1][wave] = q; }
     if (wave == 3) {  // the last wave evaluates the uniqueness term meanwhile
-        const float v = a.ids != nullptr ? uniq_loss_wave(a.ids, a.z, a.B, a.L, a.uniq_weight, a.uniq_margin, a.g_rows) : 0.0f;
+        const float v = a.ids != nullptr ? uniq_loss_wave(a.ids, a.z, a.B, a.L, a.uniq_weight, a.uniq_margin, a.g_rows, a.D) : 0.0f;
         if (lane == 0) uq = v;
     }
     __syncthreads();
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void total_loss_kernel(TotalArgs a) { total_lo
 template <bool VEC>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L,
                                                        float w_a, float w_p, float w_u, const float *g_rows, float *g_y, float *scal,
-                                                       float *g_z) {
+                                                       float *g_z, int D) {
     const float g = *g_loss;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -491,16 +491,16 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float *g_loss, cons
         scal[1] = g * w_a;
         scal[2] = g * w_p;
     }
-    if (g_z != nullptr && threadIdx.x < 128) {  // this workgroup's 4 rows of g_z
-        const int64_t idx = (int64_t)blockIdx.x * 128 + threadIdx.x;
-        if (idx < B * 32) g_z[idx] = (g_rows != nullptr && idx < (int64_t)L * 32) ? (g * w_u) * g_rows[idx] : 0.0f;
+    if (g_z != nullptr && threadIdx.x < 4 * D) {  // this workgroup's 4 rows of g_z
+        const int64_t idx = (int64_t)blockIdx.x * (4 * D) + threadIdx.x;
+        if (idx < B * D) g_z[idx] = (g_rows != nullptr && idx < (int64_t)L * D) ? (g * w_u) * g_rows[idx] : 0.0f;
     }
     if (row < B) recon_row<VEC>(y, x, row, N, 1.0f * (g / (float)B), nullptr, nullptr, g_y);
 }
 
-// scal[0] = g/B, scal[1] = g*w_a, scal[2] = g*w_p ; g_z [B,32] = g*w_u*g_rows on the first L rows, 0 elsewhere
+// scal[0] = g/B, scal[1] = g*w_a, scal[2] = g*w_p ; g_z [B,D] = g*w_u*g_rows on the first L rows, 0 elsewhere
 __global__ __launch_bounds__(256) void total_loss_bwd_kernel(const float *g_loss, int64_t B, int L, float w_a, float w_p, float w_u,
-                                                             const float *g_rows, float *scal, float *g_z) {
+                                                             const float *g_rows, float *scal, float *g_z, int D) {
     const float g = *g_loss;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx == 0) {
@@ -508,15 +508,16 @@ __global__ __launch_bounds__(256) void total_loss_bwd_kernel(const float *g_loss
         scal[1] = g * w_a;
         scal[2] = g * w_p;
     }
-    if (g_z != nullptr && idx < B * 32) g_z[idx] = (g_rows != nullptr && idx < (int64_t)L * 32) ? (g * w_u) * g_rows[idx] : 0.0f;
+    if (g_z != nullptr && idx < B * D) g_z[idx] = (g_rows != nullptr && idx < (int64_t)L * D) ? (g * w_u) * g_rows[idx] : 0.0f;
 }
 
 }  // namespace
 
 extern "C" int hidvae_uniq_loss(const int64_t *ids, const float *z, int64_t B, int L, float weight, float margin, float *loss,
-                                float *g_rows, void *stream) {
+                                float *g_rows, int embed_dim, void *stream) {
     HV_REQUIRE(ids && z && loss && B >= 1 && L >= 1 && L <= HIDVAE_MAX_LEVELS, "uniq_loss: bad arguments");
-    hipLaunchKernelGGL(uniq_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ids, z, B, L, weight, margin, loss, g_rows);
+    HV_REQUIRE(embed_dim >= 1 && embed_dim <= 64, "uniq_loss: embed_dim=%d (at most 64)", embed_dim);
+    hipLaunchKernelGGL(uniq_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ids, z, B, L, weight, margin, loss, g_rows, embed_dim);
     HV_LAUNCH_CHECK("uniq_loss");
     return HIDVAE_OK;
 }
@@ -525,7 +526,7 @@ extern "C" int hidvae_total_loss(const float *recon, const float *qloss, int64_t
                                  const float *const *pred_host, const float *const *acc_host, int n_tag, float tag_div,
                                  const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
                                  float w_p, float w_u, float *loss, float *uniq, float *g_rows, float *tagstats, float *summary,
-                                 void *stream) {
+                                 int embed_dim, void *stream) {
     HV_REQUIRE(recon && qloss && loss && B >= 1, "total_loss: bad arguments");
     HV_REQUIRE(ids == nullptr || (z != nullptr && L >= 1 && L <= HIDVAE_MAX_LEVELS),
                "total_loss: uniqueness term needs z and 1 <= n_layers <= %d (L=%d)", HIDVAE_MAX_LEVELS, L);
@@ -539,6 +540,8 @@ extern "C" int hidvae_total_loss(const float *recon, const float *qloss, int64_t
     }
     a.ids = ids; a.z = z; a.L = L; a.uniq_weight = uniq_weight; a.uniq_margin = uniq_margin;
     a.w_a = w_a; a.w_p = w_p; a.w_u = w_u; a.loss = loss; a.uniq = uniq; a.g_rows = g_rows; a.summary = summary;
+    a.D = embed_dim;
+    HV_REQUIRE(ids == nullptr || (embed_dim >= 1 && embed_dim <= 64), "loss: embed_dim=%d (at most 64)", embed_dim);
     hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     HV_LAUNCH_CHECK("total_loss");
     return HIDVAE_OK;
@@ -553,7 +556,7 @@ extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_
                                const float *const *align_host, const float *const *pred_host, const float *const *acc_host, int n_tag,
                                float tag_div, const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
                                float w_p, float w_u, float *recon, float *loss, float *uniq, float *g_rows, float *tagstats,
-                               float *summary, void *stream) {
+                               float *summary, int embed_dim, void *stream) {
     HV_REQUIRE(y && x && qloss && recon && loss && B >= 1 && N >= 1, "loss_fwd: bad arguments");
     HV_REQUIRE(ids == nullptr || (z != nullptr && L >= 1 && L <= HIDVAE_MAX_LEVELS),
                "loss_fwd: uniqueness term needs z and 1 <= n_layers <= %d (L=%d)", HIDVAE_MAX_LEVELS, L);
@@ -567,6 +570,8 @@ extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_
     }
     a.ids = ids; a.z = z; a.L = L; a.uniq_weight = uniq_weight; a.uniq_margin = uniq_margin;
     a.w_a = w_a; a.w_p = w_p; a.w_u = w_u; a.loss = loss; a.uniq = uniq; a.g_rows = g_rows; a.summary = summary;
+    a.D = embed_dim;
+    HV_REQUIRE(ids == nullptr || (embed_dim >= 1 && embed_dim <= 64), "loss: embed_dim=%d (at most 64)", embed_dim);
     // two launches: a grid-wide hand-off inside one launch needs an agent-scope release per workgroup, and on 8 XCDs that
     // L2 write-back costs several times the second launch (measured 25 us fused vs 5 + 6.6 us)
     const unsigned grid = (unsigned)hv_cdiv(B, 4);
@@ -583,25 +588,27 @@ extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_
 }
 
 extern "C" int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L, float w_a, float w_p,
-                               float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, void *stream) {
+                               float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, int embed_dim, void *stream) {
     HV_REQUIRE(g_loss && y && x && g_y && scal && B >= 1 && N >= 1, "loss_bwd: bad arguments");
+    HV_REQUIRE(g_z == nullptr || (embed_dim >= 1 && embed_dim <= 64), "loss_bwd: embed_dim=%d (at most 64)", embed_dim);
     const unsigned grid = (unsigned)hv_cdiv(B, 4);
     if (recon_vec_ok(N, y, x, g_y, nullptr))
         hipLaunchKernelGGL(loss_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_loss, y, x, B, N, L, w_a, w_p, w_u, g_rows,
-                           g_y, scal, g_z);
+                           g_y, scal, g_z, embed_dim);
     else
         hipLaunchKernelGGL(loss_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_loss, y, x, B, N, L, w_a, w_p, w_u, g_rows,
-                           g_y, scal, g_z);
+                           g_y, scal, g_z, embed_dim);
     HV_LAUNCH_CHECK("loss_bwd");
     return HIDVAE_OK;
 }
 
 extern "C" int hidvae_total_loss_bwd(const float *g_loss, int64_t B, int L, float w_a, float w_p, float w_u, const float *g_rows,
-                                     float *scal, float *g_z, void *stream) {
+                                     float *scal, float *g_z, int embed_dim, void *stream) {
     HV_REQUIRE(g_loss && scal && B >= 1, "total_loss_bwd: bad arguments");
-    const int64_t n = g_z != nullptr ? B * 32 : 1;
+    HV_REQUIRE(g_z == nullptr || (embed_dim >= 1 && embed_dim <= 64), "total_loss_bwd: embed_dim=%d (at most 64)", embed_dim);
+    const int64_t n = g_z != nullptr ? B * embed_dim : 1;
     hipLaunchKernelGGL(total_loss_bwd_kernel, dim3((unsigned)hv_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g_loss, B, L, w_a,
-                       w_p, w_u, g_rows, scal, g_z);
+                       w_p, w_u, g_rows, scal, g_z, embed_dim);
     HV_LAUNCH_CHECK("total_loss_bwd");
     return HIDVAE_OK;
 }

@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int D = HIDVAE_EMBED_DIM;
+constexpr int D = 32;  // (the GUMBEL_SOFTMAX row kernels exist for embed_dim = 32 only: no shipped config trains in that mode)
 
 // S [B,K] = x cb^T on entry -> P = softmax((-(|x|^2 + |c|^2 - 2 S) + G)/T) on exit; ids = first argmin of the distance
 __global__ __launch_bounds__(256) void gumbel_rows_fwd_kernel(float *S, const float *x, const float *cc, const float *U, int64_t B,

@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int D = HIDVAE_EMBED_DIM;
+constexpr int D = 32;  // the width these kernels are built around (4 quarter-lanes x 8 components); other widths: rq_generic.hip
 constexpr int WG_THREADS = 256;
 constexpr int ITEMS_PER_WAVE = 16;
 constexpr int ITEMS_PER_WG = 64;
@@ -1328,9 +1328,13 @@ int launch_bwd(const BwdArgs &a, int L, int grid, hipStream_t s) {
 }  // namespace
 
 extern "C" int hidvae_codebook_prepare(const float *const *E_host, const int32_t *normalize_host, int L, int64_t K,
-                                       float *cb_eff, float *cc, void *stream) {
+                                       float *cb_eff, float *cc, int embed_dim, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "codebook_prepare: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
     HV_REQUIRE(K >= 1 && E_host && cb_eff && cc, "codebook_prepare: bad arguments");
+    if (embed_dim != D) {
+        HV_REQUIRE(hv_rqg_dim_ok(embed_dim), "codebook_prepare: embed_dim=%d (a multiple of 4, at most 64)", embed_dim);
+        return hv_rqg_prepare(E_host, normalize_host, L, K, embed_dim, cb_eff, cc, (hipStream_t)stream);
+    }
     PrepArgs a{};
     for (int i = 0; i < L; i++) {
         a.E[i] = E_host[i];
@@ -1346,10 +1350,16 @@ extern "C" int hidvae_codebook_prepare(const float *const *E_host, const int32_t
 extern "C" int hidvae_codebook_prepare_adamw(const float *const *E_host, const int32_t *normalize_host, int L, int64_t K, float *cb_eff,
                                              float *cc, int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
                                              float beta1, float beta2, float eta_min, int64_t T_max, int64_t step_size, float gamma,
-                                             float *hyper_dev, void *stream) {
+                                             float *hyper_dev, int embed_dim, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "codebook_prepare_adamw: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
     HV_REQUIRE(K >= 1 && E_host && cb_eff && cc, "codebook_prepare_adamw: bad arguments");
     HV_REQUIRE(step_dev && base_lr_dev && wd_dev && hyper_dev && n_tensors >= 1, "codebook_prepare_adamw: bad optimizer arguments");
+    if (embed_dim != D) {  // other widths: the two launches one after the other
+        HV_REQUIRE(hv_rqg_dim_ok(embed_dim), "codebook_prepare_adamw: embed_dim=%d (a multiple of 4, at most 64)", embed_dim);
+        const int rc = hv_rqg_prepare(E_host, normalize_host, L, K, embed_dim, cb_eff, cc, (hipStream_t)stream);
+        if (rc != HIDVAE_OK) return rc;
+        return hidvae_adamw_prepare(step_dev, base_lr_dev, wd_dev, n_tensors, beta1, beta2, eta_min, T_max, step_size, gamma, hyper_dev, stream);
+    }
     PrepArgs a{};
     for (int i = 0; i < L; i++) {
         a.E[i] = E_host[i];
@@ -1367,12 +1377,18 @@ extern "C" int hidvae_codebook_prepare_adamw(const float *const *E_host, const i
 extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input, const float *cb_eff, const float *cc,
                                  int L, int64_t K, int mode, int training, float beta, float *z, int64_t *ids,
                                  float *emb_cat, int64_t ld_cat, float *emb_sum, float *res_cat, float *qloss,
-                                 void *workspace, void *stream) {
+                                 void *workspace, int embed_dim, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "rq_forward: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
     HV_REQUIRE(B >= 1 && K >= 1, "rq_forward: empty batch or codebook (B=%lld K=%lld)", (long long)B, (long long)K);
     HV_REQUIRE(y && cb_eff && cc && ids, "rq_forward: null pointer");
     HV_REQUIRE(mode == HIDVAE_MODE_STE || mode == HIDVAE_MODE_ROTATION || !training,
                "rq_forward: mode %d is not fused (GUMBEL_SOFTMAX is composed from GEMM + softmax)", mode);
+    if (embed_dim != D) {
+        HV_REQUIRE(hv_rqg_dim_ok(embed_dim), "rq_forward: embed_dim=%d (a multiple of 4, at most 64)", embed_dim);
+        HV_REQUIRE(emb_cat == nullptr || ld_cat >= (int64_t)L * embed_dim, "rq_forward: ld_cat=%lld", (long long)ld_cat);
+        return hv_rqg_forward(y, B, normalize_input, cb_eff, cc, L, K, embed_dim, mode, training, beta, z, ids, emb_cat, ld_cat, emb_sum, res_cat,
+                              qloss, (hipStream_t)stream);
+    }
     HV_REQUIRE(emb_cat == nullptr || (ld_cat >= (int64_t)L * D && ld_cat % 4 == 0), "rq_forward: ld_cat=%lld", (long long)ld_cat);
     FwdArgs a{};
     a.y = y; a.B = B; a.normalize_input = normalize_input; a.cb_eff = cb_eff; a.cc = cc; a.L = L; a.K = K;
@@ -1504,11 +1520,17 @@ extern "C" int hidvae_bottleneck_fwd(const float *h1, int64_t B, int K2, int N2,
 extern "C" int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_input, const float *cb_eff,
                                   const float *cc, int L, int64_t K, int mode, float beta, const int64_t *ids,
                                   const float *g_cat, int64_t ld_gcat, const float *g_sum, const float *g_z_in,
-                                  int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows, void *stream) {
+                                  int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows, int embed_dim, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "rq_backward: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
     HV_REQUIRE(B >= 1 && K >= 1 && z && cb_eff && cc && ids && g_y, "rq_backward: bad arguments");
     HV_REQUIRE(!normalize_input || y, "rq_backward: normalize_input needs y");
     HV_REQUIRE(mode == HIDVAE_MODE_STE || mode == HIDVAE_MODE_ROTATION, "rq_backward: mode %d is not fused", mode);
+    if (embed_dim != D) {
+        HV_REQUIRE(hv_rqg_dim_ok(embed_dim), "rq_backward: embed_dim=%d (a multiple of 4, at most 64)", embed_dim);
+        HV_REQUIRE(g_cat == nullptr || ld_gcat >= (int64_t)L * embed_dim, "rq_backward: ld_gcat=%lld", (long long)ld_gcat);
+        return hv_rqg_backward(y, z, B, normalize_input, cb_eff, cc, L, K, embed_dim, mode, beta, ids, g_cat, ld_gcat, g_sum, g_z_in, g_z_rows, gq,
+                               gq_items, gq_stride, g_y, dE_rows, (hipStream_t)stream);
+    }
     HV_REQUIRE(g_cat == nullptr || (ld_gcat >= (int64_t)L * D && ld_gcat % 4 == 0), "rq_backward: ld_gcat=%lld", (long long)ld_gcat);
     BwdArgs a{y, z, B, normalize_input, cb_eff, cc, K, beta, ids, g_cat, ld_gcat, g_sum, g_z_in, g_z_rows, gq, gq_items, gq_stride, g_y, dE_rows};
     const int grid = (int)hv_cdiv(B, ITEMS_PER_WG);
@@ -1518,9 +1540,13 @@ extern "C" int hidvae_rq_backward(const float *y, const float *z, int64_t B, int
 
 extern "C" int hidvae_codebook_grad(const int64_t *ids, const float *dE_rows, int64_t B, int L, int64_t K,
                                     const float *const *E_host, const float *cb_eff, const int32_t *normalize_host,
-                                    float *const *gE_host, int accumulate, float *workspace, void *stream) {
+                                    float *const *gE_host, int accumulate, float *workspace, int embed_dim, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS && B >= 1 && K >= 1, "codebook_grad: bad sizes");
     HV_REQUIRE(ids && dE_rows && E_host && cb_eff && gE_host, "codebook_grad: null pointer");
+    if (embed_dim != D) {
+        HV_REQUIRE(hv_rqg_dim_ok(embed_dim), "codebook_grad: embed_dim=%d (a multiple of 4, at most 64)", embed_dim);
+        return hv_rqg_codebook_grad(ids, dE_rows, B, L, K, embed_dim, E_host, cb_eff, normalize_host, gE_host, accumulate, (hipStream_t)stream);
+    }
     CbGradArgs a{};
     a.ids = ids; a.dE_rows = dE_rows; a.B = B; a.L = L; a.K = K; a.cb_eff = cb_eff; a.accumulate = accumulate;
     for (int i = 0; i < L; i++) {

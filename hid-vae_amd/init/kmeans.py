@@ -25,8 +25,7 @@ class Kmeans:
 
     def run(self, x: torch.Tensor) -> KmeansOutput:
         assert x.dim() == 2
-        if x.shape[1] != _C.EMBED_DIM:
-            raise NotImplementedError(f"k-means kernels are specialised for embed_dim={_C.EMBED_DIM}")
+        _C.check_embed_dim(x.shape[1])  # (kernels instantiated for 32 and 64; narrower multiples of 4 run zero-padded)
         x = x.detach().float().contiguous()
         N = x.shape[0]
         idx = self.init_indices if self.init_indices is not None else np.random.choice(N, self.k, replace=False)

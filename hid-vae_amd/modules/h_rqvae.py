@@ -89,8 +89,7 @@ class HRqVae(nn.Module, _HubMixin):
         if n_cat_features != 0:
             raise NotImplementedError("n_cat_features != 0 (categorical BCE tail) is unreachable in the reference as shipped "
                                       "(SURVEY Q1) and unused by both configs; not built on the HIP path")
-        if embed_dim != _C.EMBED_DIM:
-            raise NotImplementedError(f"the fused RQ kernels are specialised for embed_dim={_C.EMBED_DIM} (got {embed_dim})")
+        _C.check_embed_dim(embed_dim)  # 32: the fused kernels; other multiples of 4 up to 64 (rqvae_ml32m.gin: 64): csrc/rq_generic.hip
         if not 1 <= n_layers <= _C.MAX_LEVELS:
             raise ValueError(f"n_layers must be in [1, {_C.MAX_LEVELS}]")
         self.input_dim, self.embed_dim, self.hidden_dims = input_dim, embed_dim, hidden_dims
@@ -182,7 +181,7 @@ class HRqVae(nn.Module, _HubMixin):
         Wd = self.decoder.weights()
         We = self.encoder.weights()
         fused = (len(We) >= 3 and len(Wd) >= 3 and self.codebook_mode.value in (QuantizeForwardMode.STE.value, QuantizeForwardMode.ROTATION_TRICK.value)
-                 and getattr(self, "fuse_bottleneck", True)
+                 and getattr(self, "fuse_bottleneck", True) and self.embed_dim == _C.EMBED_DIM
                  and _C.bottleneck_eligible(batch_size, We[-2].shape[1], We[-2].shape[0], Wd[0].shape[0], Wd[1].shape[0], self.n_layers, self.codebook_size))
         return list(Wd[2:]) if fused else list(Wd)
 
@@ -290,7 +289,7 @@ class HRqVae(nn.Module, _HubMixin):
         if any(getattr(layer, "do_kmeans_init", False) and not getattr(layer, "kmeans_initted", True) for layer in self.layers):
             return False  # the k-means start-up pass wants y on its own first
         We, Wd = self.encoder.weights(), self.decoder.weights()
-        if len(We) < 3 or len(Wd) < 3 or x.dim() != 2:
+        if len(We) < 3 or len(Wd) < 3 or x.dim() != 2 or self.embed_dim != _C.EMBED_DIM:
             return False
         return _C.bottleneck_eligible(x.shape[0], We[-2].shape[1], We[-2].shape[0], Wd[0].shape[0], Wd[1].shape[0], self.n_layers,
                                       self.codebook_size)
@@ -303,6 +302,8 @@ class HRqVae(nn.Module, _HubMixin):
         """-> z, ids [B,L], emb_cat [B,L*D], emb_sum [B,D], qloss [B], res_cat"""
         self._maybe_kmeans(y, normalize_input)
         if self.training and self.codebook_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
+            if self.embed_dim != _C.EMBED_DIM:
+                raise NotImplementedError("GUMBEL_SOFTMAX training is built for embed_dim = 32 only (no shipped config trains in that mode)")
             from ..gumbel_path import gumbel_all_levels
             return gumbel_all_levels(self, y, normalize_input)
         return RQFn.apply(y.contiguous(), normalize_input, self._fused_mode(), self.training, self.commitment_weight,

@@ -28,8 +28,7 @@ class RqVae(HRqVae):
         if n_cat_features != 0:
             raise NotImplementedError("n_cat_features != 0 (categorical BCE tail, reference rqvae.py:89-92) is not built on the HIP "
                                       "path; the HiD-VAE configs use 768-d text embeddings with n_cat_features = 0")
-        if embed_dim != _C.EMBED_DIM:
-            raise NotImplementedError(f"the fused RQ kernels are specialised for embed_dim={_C.EMBED_DIM} (got {embed_dim})")
+        _C.check_embed_dim(embed_dim)  # 32: the fused kernels; other multiples of 4 up to 64 (rqvae_ml32m.gin: 64): csrc/rq_generic.hip
         if not 1 <= n_layers <= _C.MAX_LEVELS:
             raise ValueError(f"n_layers must be in [1, {_C.MAX_LEVELS}]")
         self.input_dim, self.embed_dim, self.hidden_dims = input_dim, embed_dim, hidden_dims

@@ -29,7 +29,10 @@ extern "C" {
 #define HIDVAE_ELAUNCH (-3)  /* hip runtime error at launch                                       */
 
 #define HIDVAE_MAX_LEVELS 8
-#define HIDVAE_EMBED_DIM 32  /* the fused RQ kernels are specialised for embed_dim = 32 (both gin configs) */
+/* embed_dim is an ARGUMENT of every entry point that sees code vectors (rounds 1-2 fixed it at 32 as a constant of the ABI).  The fused
+ * kernels are built for 32 (both h-configs); other widths -- a multiple of 4, at most 64: configs/rqvae_ml32m.gin uses 64 -- run the
+ * same algorithm in a width-independent geometry (csrc/rq_generic.hip), exact fp32, not tuned.  hidvae_bottleneck_fwd and the
+ * GUMBEL row kernels are 32 only. */
 
 /* quantize.py:17-20 QuantizeForwardMode */
 #define HIDVAE_MODE_GUMBEL 1
@@ -148,7 +151,7 @@ int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out,
  * E_host / normalize_host are HOST arrays of L entries (device pointers / flags).
  * cb_eff: [L][K][32], cc: [L][K] device workspaces. */
 int hidvae_codebook_prepare(const float *const *E_host, const int32_t *normalize_host, int L, int64_t K,
-                            float *cb_eff, float *cc, void *stream);
+                            float *cb_eff, float *cc, int embed_dim, void *stream);
 
 /* ---- a4-a7: fused L-level residual quantisation, forward ------------------------------------------
  * Replaces the level loop of HRqVae.get_semantic_ids (h_rqvae.py:515-552) and Quantize.forward
@@ -172,7 +175,7 @@ int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
                       const float *cb_eff, const float *cc, int L, int64_t K,
                       int mode, int training, float beta,
                       float *z, int64_t *ids, float *emb_cat, int64_t ld_cat,
-                      float *emb_sum, float *res_cat, float *qloss, void *workspace, void *stream);
+                      float *emb_sum, float *res_cat, float *qloss, void *workspace, int embed_dim, void *stream);
 
 /* ---- a2 (last two layers) + a5-a7 + a3 (first two layers) in ONE launch, for small batches (B <= 4096; codebooks + 34 KB of
  * activations must fit in LDS: L*(33*Kp+64)*4 bytes with Kp = K rounded up to 128, e.g. 3x256 or 2x512).  Training only.
@@ -202,7 +205,7 @@ int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_
                        const float *cb_eff, const float *cc, int L, int64_t K,
                        int mode, float beta, const int64_t *ids,
                        const float *g_cat, int64_t ld_gcat, const float *g_sum, const float *g_z_in,
-                       int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows, void *stream);
+                       int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows, int embed_dim, void *stream);
 
 /* gE[i][k][:] (+)= sum_{b: ids[b,i]==k} dE_rows[b, i*32:(i+1)*32], pushed through the row-normalise
  * Jacobian for levels with normalize[i] (E_host: raw tables, needed for |E_k|).  gE_host: L device ptrs.
@@ -211,7 +214,7 @@ int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_
  * code's chain no longer sets the time; identical results for B <= 2048, a different fixed order above. */
 int hidvae_codebook_grad(const int64_t *ids, const float *dE_rows, int64_t B, int L, int64_t K,
                          const float *const *E_host, const float *cb_eff, const int32_t *normalize_host,
-                         float *const *gE_host, int accumulate, float *workspace, void *stream);
+                         float *const *gE_host, int accumulate, float *workspace, int embed_dim, void *stream);
 
 /* ---- a3/a14: decoder tail.  x_hat = y / max(|y|,1e-12) (encoder.py:32), recon[b] = sum (x_hat-x)^2
  * (loss.py:11-12) and, if g_y != NULL, g_y = d(sum_b gscale_b * recon[b]) / dy with gscale_b = gscale *
@@ -239,17 +242,17 @@ int hidvae_l2norm_bwd(const float *g, int64_t ldg, const float *out, int64_t ldo
  * tagstats [3+3*n_tag] (optional) receives the three means followed by the three by-layer vectors; summary [6] (optional)
  * receives {loss, mean recon, mean qloss, tag align, tag pred, tag accuracy}: the row train_hidvae.py:770-790 logs. */
 int hidvae_uniq_loss(const int64_t *ids, const float *z, int64_t B, int L, float weight, float margin, float *loss,
-                     float *g_rows, void *stream);
+                     float *g_rows, int embed_dim, void *stream);
 int hidvae_total_loss(const float *recon, const float *qloss, int64_t B,
                       const float *const *align_host, const float *const *pred_host, const float *const *acc_host,
                       int n_tag, float tag_div,
                       const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin,
                       float w_a, float w_p, float w_u, float *loss, float *uniq, float *g_rows, float *tagstats,
-                      float *summary, void *stream);
+                      float *summary, int embed_dim, void *stream);
 /* backward of the above for a device scalar g = d/d loss: scal[0] = g/B (per-item grad of recon and qloss),
  * scal[1] = g*w_a, scal[2] = g*w_p (pass w_a/tag_div, w_p/tag_div to get the per-level gradients); g_z [B,32] (optional) = g*w_u*g_rows on rows < L, 0 elsewhere. */
 int hidvae_total_loss_bwd(const float *g_loss, int64_t B, int L, float w_a, float w_p, float w_u, const float *g_rows,
-                          float *scal, float *g_z, void *stream);
+                          float *scal, float *g_z, int embed_dim, void *stream);
 
 /* The step's own pairing of the two above with the decoder tail (a3 + a14 + a1): one call forward, ONE launch backward.
  * loss_fwd: recon[b] = |normalize(y[b]) - x[b]|^2 (encoder.py:32, loss.py:11-12) for every row, then the total loss as
@@ -259,9 +262,9 @@ int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, const 
                     const float *const *align_host, const float *const *pred_host, const float *const *acc_host, int n_tag,
                     float tag_div, const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
                     float w_p, float w_u, float *recon, float *loss, float *uniq, float *g_rows, float *tagstats,
-                    float *summary, void *stream);
+                    float *summary, int embed_dim, void *stream);
 int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L, float w_a, float w_p,
-                    float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, void *stream);
+                    float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, int embed_dim, void *stream);
 
 /* ---- a14 as stand-alone modules: ReconstructionLoss.forward (loss.py:7-12) and the two halves of QuantizeLoss.forward
  * (loss.py:36-44) are sums s[m] = sum_j (a[m,j]-b[m,j])^2 over rows (lda/ldb row strides in elements):
@@ -279,7 +282,7 @@ int hidvae_sqdiff_rows_bwd(const float *g, int64_t g_stride, const float *a, int
  * scratch: 4*B + 3 int64 that the caller zero-fills ONCE when it allocates them and then leaves alone: the table is
  * generation-tagged and the kernel resets its own counters, so consecutive calls (same B, one at a time) share it. */
 int hidvae_id_stats(const float *emb_cat, int64_t ld_cat, const int64_t *ids, int64_t B, int L,
-                    float *embs_norm, float *p_unique, int64_t *scratch, void *stream);
+                    float *embs_norm, float *p_unique, int64_t *scratch, int embed_dim, void *stream);
 
 /* ---- a16: AdamW (torch.optim.AdamW defaults; train_hidvae.py:533-563,762-766) with the cosine schedule
  * evaluated ON DEVICE from a device step counter, so the whole step is graph-capturable.
@@ -301,7 +304,7 @@ int hidvae_adamw_prepare(int64_t *step_dev, const float *base_lr_dev, const floa
 int hidvae_codebook_prepare_adamw(const float *const *E_host, const int32_t *normalize_host, int L, int64_t K, float *cb_eff,
                                   float *cc, int64_t *step_dev, const float *base_lr_dev, const float *wd_dev, int n_tensors,
                                   float beta1, float beta2, float eta_min, int64_t T_max, int64_t step_size, float gamma,
-                                  float *hyper_dev, void *stream);
+                                  float *hyper_dev, int embed_dim, void *stream);
 int hidvae_adamw_step(float *const *p_dev, const float *const *g_host, float *const *m_dev, float *const *v_dev,
                       const int64_t *numel_dev, const float *hyper_dev, int n_tensors, int64_t max_numel,
                       float beta1, float beta2, float eps, float grad_scale, void *stream);
@@ -434,7 +437,7 @@ int hidvae_tag_loss_bwd(const float *dmix, const float *dkl, const int64_t *targ
  * an empty cluster takes x[reseed_idx[k]]), *shift = max_k |new_k - old_k|_2 (the reference stops below 1e-10).
  * shift_scratch: K floats. */
 int hidvae_kmeans_iter(const float *x, int64_t N, const float *centroids, int64_t K, int32_t *assign,
-                       const int64_t *reseed_idx, float *new_centroids, float *shift_scratch, float *shift, void *stream);
+                       const int64_t *reseed_idx, float *new_centroids, float *shift_scratch, float *shift, int embed_dim, void *stream);
 
 /* ---- a6: GUMBEL_SOFTMAX training branch of one level (quantize.py:125-130, distributions/gumbel.py:8-18); row kernels
  * around the GEMMs (S = x cb^T, emb = P cb and their gradients run on hidvae_gemm_f32).  D = 32.

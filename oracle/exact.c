@@ -20,6 +20,9 @@
  *            (p0+p1)+(p2+p3)
  *   ORDER-P  r.c dot: one fmaf chain visiting d = 0,8,16,24, 1,9,17,25, ... 7,15,23,31
  *            (MFMA 16x16x4 with lane-quarter q holding d = 8q+j, step j)
+ *   ORDER-GEN (embedding widths other than 32, csrc/rq_generic.hip): sums over the D <= 64 components are a 64-lane
+ *            xor butterfly (lane d holds term d, lanes >= D hold 0; steps 32, 16, 8, 4, 2, 1); the r.c dot is ONE fmaf
+ *            chain over d = 0, 1, ..., D-1
  *   expE     own exp: Cody-Waite reduction + degree-5 Cephes polynomial, all fmaf (no libm).
  * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -mfma -mavx2 -fPIC -shared
  */
@@ -189,5 +192,85 @@ void orc_mlp(const float *x, int64_t B, int n_layers, const int64_t *dims, const
         free(buf);
         buf = (j == n_layers - 1) ? NULL : nxt;
         cur = nxt;
+    }
+}
+
+/* ---- ORDER-GEN: the same level loop at any embedding width D <= 64 (a multiple of 4) -- modules/rqvae.py:37-88 with
+ * configs/rqvae_ml32m.gin:11 (embed_dim 64), modules/h_rqvae.py:231-256.  Mirrors csrc/rq_generic.hip operation for operation. */
+static inline float wave_sum64(const float *term, int Dg) { /* xor butterfly over 64 lanes, lanes >= Dg hold 0 */
+    float v[64];
+    for (int l = 0; l < 64; l++) v[l] = l < Dg ? term[l] : 0.0f;
+    for (int o = 32; o > 0; o >>= 1) {
+        float t[64];
+        for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ o];
+        memcpy(v, t, sizeof(v));
+    }
+    return v[0];
+}
+static inline float dotG(const float *a, const float *b, int Dg) {
+    float t[64];
+    for (int d = 0; d < Dg; d++) t[d] = a[d] * b[d];
+    return wave_sum64(t, Dg);
+}
+
+void orc_codebook_prepare_gen(const float *E, int64_t K, int Dg, int normalize, float *cb, float *cc) {
+    for (int64_t k = 0; k < K; k++) {
+        const float *e = E + k * Dg;
+        float *c = cb + k * Dg;
+        if (normalize) {
+            const float den = fmaxf(sqrtf(dotG(e, e, Dg)), 1e-12f);
+            for (int d = 0; d < Dg; d++) c[d] = e[d] / den;
+        } else memcpy(c, e, sizeof(float) * (size_t)Dg);
+        cc[k] = dotG(c, c, Dg);
+    }
+}
+
+void orc_rq_forward_gen(const float *y, int64_t B, int Dg, int normalize_input, int L, int64_t K, const float *const *cbs,
+                        const float *const *ccs, int mode, int training, float beta, float *z_out, int64_t *ids, float *emb_cat,
+                        float *emb_sum, float *res_cat, float *loss) {
+    for (int64_t b = 0; b < B; b++) {
+        float r[64], o[64], esum[64];
+        memcpy(r, y + b * Dg, sizeof(float) * (size_t)Dg);
+        if (normalize_input) {
+            const float den = fmaxf(sqrtf(dotG(r, r, Dg)), 1e-12f);
+            for (int d = 0; d < Dg; d++) r[d] = r[d] / den;
+        }
+        if (z_out) memcpy(z_out + b * Dg, r, sizeof(float) * (size_t)Dg);
+        float lsum = 0.0f;
+        for (int i = 0; i < L; i++) {
+            const float *cb = cbs[i], *cc = ccs[i];
+            if (res_cat) memcpy(res_cat + (b * L + i) * Dg, r, sizeof(float) * (size_t)Dg);
+            const float xx = dotG(r, r, Dg);
+            float best = INFINITY;
+            int64_t bi = 0;
+            for (int64_t k = 0; k < K; k++) { /* (lane order on the GPU: ascending k inside a lane, lowest index on ties across lanes) */
+                const float *c = cb + k * Dg;
+                float acc = 0.0f;
+                for (int d = 0; d < Dg; d++) acc = fmaf(r[d], c[d], acc);
+                const float dist = fmaf(-2.0f, acc, xx + cc[k]);
+                if (dist < best) { best = dist; bi = k; }
+            }
+            const float *e = cb + bi * Dg;
+            if (!training) memcpy(o, e, sizeof(float) * (size_t)Dg);
+            else if (mode == 2) { for (int d = 0; d < Dg; d++) o[d] = r[d] + (e[d] - r[d]); }
+            else {
+                float u[64], q[64], s[64], w[64];
+                const float inr = 1.0f / (sqrtf(xx) + 1e-8f), ine = 1.0f / (sqrtf(cc[bi]) + 1e-8f);
+                for (int d = 0; d < Dg; d++) { u[d] = r[d] * inr; q[d] = e[d] * ine; s[d] = u[d] + q[d]; }
+                const float inw = 1.0f / fmaxf(sqrtf(dotG(s, s, Dg)), 1e-6f);
+                for (int d = 0; d < Dg; d++) w[d] = s[d] * inw;
+                const float rw = dotG(r, w, Dg), ru = dotG(r, u, Dg);
+                for (int d = 0; d < Dg; d++) o[d] = (r[d] - 2.0f * (rw * w[d])) + 2.0f * (ru * q[d]);
+            }
+            float df[64];
+            for (int d = 0; d < Dg; d++) df[d] = r[d] - e[d];
+            const float l1 = dotG(df, df, Dg);
+            lsum = lsum + (l1 + beta * l1);
+            if (ids) ids[b * L + i] = bi;
+            if (emb_cat) memcpy(emb_cat + (b * L + i) * Dg, o, sizeof(float) * (size_t)Dg);
+            for (int d = 0; d < Dg; d++) { esum[d] = i == 0 ? o[d] : esum[d] + o[d]; r[d] = r[d] - o[d]; }
+        }
+        if (emb_sum) memcpy(emb_sum + b * Dg, esum, sizeof(float) * (size_t)Dg);
+        if (loss) loss[b] = lsum;
     }
 }

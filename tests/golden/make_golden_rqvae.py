@@ -89,3 +89,4 @@ if __name__ == "__main__":
     run("rqvae_rot_train_b96", O.Cfg(**base), 96, True)
     run("rqvae_ste_train_nonorm_b48", O.Cfg(**{**base, "codebook_mode": O.STE, "codebook_normalize": False}), 48, True)
     run("rqvae_rot_eval_b64", O.Cfg(**base), 64, False)
+    run("rqvae_rot_train_d64_b96", O.Cfg(**{**base, "embed_dim": 64}), 96, True)  # configs/rqvae_ml32m.gin:11

@@ -24,8 +24,8 @@ def test_exact_oracle_matches_reference(name):
     if "z" in fx:
         L = cfg.n_layers
         assert H.rel_err(r["z"], fx["z"]) <= 1e-5
-        emb = r["emb_cat"].reshape(-1, L, 32).transpose(0, 2, 1)
-        res = r["res_cat"].reshape(-1, L, 32).transpose(0, 2, 1)
+        emb = r["emb_cat"].reshape(-1, L, cfg.embed_dim).transpose(0, 2, 1)
+        res = r["res_cat"].reshape(-1, L, cfg.embed_dim).transpose(0, 2, 1)
         assert H.rel_err(emb, fx["embeddings"]) <= 1e-5
         assert H.rel_err(res, fx["residuals"]) <= 1e-5
         assert H.rel_err(np.linalg.norm(emb, axis=1), fx["embs_norm"]) <= 1e-5

@@ -77,9 +77,9 @@ def test_colsum(C):
     assert H.rel_err(C.colsum(x).cpu().numpy(), x.double().sum(0).cpu().numpy()) < 2e-6
 
 
-def _rq_inputs(B, L, K, seed, scale=1.0):
-    y = fill.gauss((B, 32), seed) * np.float32(scale)
-    tables = [fill.uniform((K, 32), seed + 1 + i, -1, 1) * np.float32(1.0 if i == 0 else 0.35 * 0.5 ** i) for i in range(L)]
+def _rq_inputs(B, L, K, seed, scale=1.0, D=32):
+    y = fill.gauss((B, D), seed) * np.float32(scale)
+    tables = [fill.uniform((K, D), seed + 1 + i, -1, 1) * np.float32(1.0 if i == 0 else 0.35 * 0.5 ** i) for i in range(L)]
     return y, tables
 
 
@@ -96,6 +96,32 @@ def test_rq_forward_bit_exact_vs_c_oracle(C, B, L, K, mode, training):
     assert np.array_equal(ids.cpu().numpy(), want["ids"]), "semantic ids differ"
     for got, key in ((z, "z"), (emb_cat, "emb_cat"), (emb_sum, "emb_sum"), (res, "res_cat"), (qloss, "loss")):
         assert np.array_equal(got.cpu().numpy(), want[key]), key
+
+
+@pytest.mark.parametrize("D", [64, 16, 48, 4])
+@pytest.mark.parametrize("B,L,K", [(1, 1, 1), (130, 3, 256), (77, 4, 1000), (1027, 2, 40)])
+@pytest.mark.parametrize("mode,training", [(3, True), (2, True), (3, False)])
+def test_rq_forward_other_widths_bit_exact_vs_c_oracle(C, D, B, L, K, mode, training):
+    """embed_dim other than 32 (configs/rqvae_ml32m.gin:11 uses 64): csrc/rq_generic.hip against ORDER-GEN of oracle/exact.c."""
+    y, tables = _rq_inputs(B, L, K, 60 + D, D=D)
+    want = exact.rq_forward(y, tables, True, True, mode, training, 0.4)
+    cb, cc = C.codebook_prepare([dev(t) for t in tables], [i == 0 for i in range(L)])
+    assert np.array_equal(cb.cpu().numpy(), np.stack(want["cbs"]))
+    assert np.array_equal(cc.cpu().numpy(), np.stack(want["ccs"]))
+    z, ids, emb_cat, emb_sum, res, qloss = C.rq_forward(dev(y), cb, cc, True, mode, training, 0.4, want_res=True)
+    assert np.array_equal(ids.cpu().numpy(), want["ids"]), "semantic ids differ"
+    for got, key in ((z, "z"), (emb_cat, "emb_cat"), (emb_sum, "emb_sum"), (res, "res_cat"), (qloss, "loss")):
+        assert np.array_equal(got.cpu().numpy(), want[key]), key
+    if not training:  # the ids-only launch is the eval-mode search
+        assert np.array_equal(C.rq_ids(dev(y), cb, cc, True).cpu().numpy(), want["ids"])
+
+
+def test_embed_dim_outside_the_supported_set_is_refused(C):
+    for D in (0, 6, 68, 128):
+        with pytest.raises((RuntimeError, ValueError)):
+            C.check_embed_dim(D)
+    for D in (4, 16, 32, 64):
+        C.check_embed_dim(D)
 
 
 def test_rq_exact_ties_pick_lowest_index(C):
@@ -127,18 +153,19 @@ def test_rq_forward_on_reference_goldens(C, name):
     assert (fx["margins"] > 1e-6).all()
     assert np.array_equal(ids.cpu().numpy(), fx["sem_ids"].astype(np.int64))
     L = cfg.n_layers
-    assert H.rel_err(emb_cat.cpu().numpy().reshape(-1, L, 32).transpose(0, 2, 1), fx["embeddings"]) <= 1e-5
-    assert H.rel_err(res.cpu().numpy().reshape(-1, L, 32).transpose(0, 2, 1), fx["residuals"]) <= 1e-5
+    assert H.rel_err(emb_cat.cpu().numpy().reshape(-1, L, cfg.embed_dim).transpose(0, 2, 1), fx["embeddings"]) <= 1e-5
+    assert H.rel_err(res.cpu().numpy().reshape(-1, L, cfg.embed_dim).transpose(0, 2, 1), fx["residuals"]) <= 1e-5
     assert H.rel_err(qloss.cpu().numpy(), fx["rqvae_loss"]) <= 1e-5
 
 
 @pytest.mark.parametrize("mode", [3, 2])
-@pytest.mark.parametrize("B,L,K,norm", [(50, 3, 256, True), (200, 4, 64, False), (17, 1, 16, True), (5000, 3, 256, True), (4100, 2, 6, False)])
-def test_rq_backward_vs_autograd(C, mode, B, L, K, norm):
-    y, tables = _rq_inputs(B, L, K, 31)
-    g_cat = fill.uniform((B, L * 32), 32, -1, 1)
-    g_sum = fill.uniform((B, 32), 33, -1, 1)
-    g_z = fill.uniform((B, 32), 34, -1, 1)
+@pytest.mark.parametrize("B,L,K,norm,D", [(50, 3, 256, True, 32), (200, 4, 64, False, 32), (17, 1, 16, True, 32), (5000, 3, 256, True, 32),
+                                          (4100, 2, 6, False, 32), (300, 3, 256, True, 64), (129, 2, 40, False, 64), (70, 3, 33, True, 16)])
+def test_rq_backward_vs_autograd(C, mode, B, L, K, norm, D):
+    y, tables = _rq_inputs(B, L, K, 31, D=D)
+    g_cat = fill.uniform((B, L * D), 32, -1, 1)
+    g_sum = fill.uniform((B, D), 33, -1, 1)
+    g_z = fill.uniform((B, D), 34, -1, 1)
     gq = fill.uniform((B,), 35, 0.1, 1)
     # autograd reference (oracle) for sum(g_cat*emb) + sum(g_sum*emb.sum) + sum(g_z*z) + sum(gq*loss)
     yt = torch.from_numpy(y).requires_grad_(True)
@@ -285,6 +312,16 @@ def test_linear_bwd_balanced_kernel_against_float64_and_itself(C, B, n_out, n_in
     # the arrival counters at the head of the lane's workspace are zero again
     lane = C._lane_ws(g.device, 4)
     assert int(lane[:4096].view(torch.int32).abs().sum()) == 0
+    # every stream owns its counters (two Linear backwards on different streams must never share them), and an error path re-zeroes them
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        other = C._lane_ws(g.device, 4)
+    assert other.data_ptr() != lane.data_ptr() and C.lane_counters_clean()
+    lane[3] = 1.0  # what a launch that died mid-way would leave behind
+    assert not C.lane_counters_clean()
+    with pytest.raises(RuntimeError):
+        C.linear_bwd(g, x, w, True, C.EPI_DSILU, None)  # refused by the library (a D* epilogue without aux): reported, workspaces reset
+    assert C.lane_counters_clean()
 
 
 @pytest.mark.parametrize("B,mode,norm", [(1024, 3, True), (50, 3, True), (16, 2, False), (333, 3, False)])
