@@ -38,7 +38,7 @@ _SIGNATURES = {
     "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_total_loss_bwd": [_vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _i, _vp],
     "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
-    "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _i64, _vp, _vp, _vp, _vp],
+    "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _i, _f, _vp, _i64, _vp, _vp, _vp, _vp],
     "hidvae_l2norm_fwd": [_vp, _i64, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm32_fwd": [_vp, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _f, _vp, _i64, _i, _vp],
@@ -68,8 +68,9 @@ _SIGNATURES = {
     "hidvae_gumbel_gemb": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp],
     "hidvae_gumbel_rows_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
     "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _vp],
-    "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
+    "hidvae_cat_recon_rows": [_vp, _i64, _vp, _i64, _i64, _i64, _i, _vp, _i64, _vp, _vp, _vp],
+    "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_padded_to_jagged": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp],
     "hidvae_jagged_to_padded": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
     "hidvae_codebook_prepare_adamw": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _i, _vp],
@@ -621,7 +622,15 @@ def codebook_grad(ids, dE_rows, tables, cb_eff, normalize_flags, grads=None, acc
     return grads
 
 
-def recon_fwd_bwd(y, x, gscale=1.0, gscale_items=None, want_xhat=False, want_grad=False):
+def _n_cat(n_cat, N):
+    n_cat = int(n_cat)
+    if not 0 <= n_cat < N:
+        raise RuntimeError(f"n_cat_features={n_cat}: must leave at least one of the {N} columns non-categorical")
+    return n_cat
+
+
+def recon_fwd_bwd(y, x, gscale=1.0, gscale_items=None, want_xhat=False, want_grad=False, n_cat=0):
+    """decoder tail; n_cat > 0: the last n_cat columns enter as BCE-with-logits (reference loss.py:15-33, h_rqvae.py:610-613)"""
     _f32(y, "y"), _f32(x, "x")
     if y.shape != x.shape or not y.is_contiguous() or not x.is_contiguous():
         raise RuntimeError(f"recon: shapes differ or not contiguous ({tuple(y.shape)} vs {tuple(x.shape)})")
@@ -629,10 +638,25 @@ def recon_fwd_bwd(y, x, gscale=1.0, gscale_items=None, want_xhat=False, want_gra
     x_hat = torch.empty_like(y) if want_xhat else None
     recon = torch.empty((B,), device=y.device, dtype=torch.float32)
     g_y = torch.empty_like(y) if want_grad else None
-    _check(lib().hidvae_recon_fwd_bwd(_p(y), _p(x), B, N, float(gscale), _p(gscale_items), _vec_stride(gscale_items), _p(x_hat), _p(recon),
+    _check(lib().hidvae_recon_fwd_bwd(_p(y), _p(x), B, N, _n_cat(n_cat, N), float(gscale), _p(gscale_items), _vec_stride(gscale_items), _p(x_hat), _p(recon),
                                       _p(g_y), _stream()),
            "hidvae_recon_fwd_bwd")
     return recon, x_hat, g_y
+
+
+def cat_recon_rows(x_hat, x, n_cat, g=None):
+    """CategoricalReconstructionLoss.forward on given x_hat (reference loss.py:15-33): -> out [M], or with g [M] -> g_xhat [M,N]"""
+    _f32(x_hat, "x_hat"), _f32(x, "x")
+    if x_hat.shape != x.shape or x_hat.dim() != 2:
+        raise RuntimeError(f"cat_recon_rows: shapes differ ({tuple(x_hat.shape)} vs {tuple(x.shape)})")
+    M, N = x_hat.shape
+    if not 0 <= int(n_cat) <= N:
+        raise RuntimeError(f"cat_recon_rows: n_cat={n_cat} of {N} columns")
+    out = torch.empty((M,), device=x.device, dtype=torch.float32) if g is None else None
+    g_xhat = torch.empty((M, N), device=x.device, dtype=torch.float32) if g is not None else None
+    _check(lib().hidvae_cat_recon_rows(_p(x_hat), _row_stride(x_hat, "x_hat"), _p(x), _row_stride(x, "x"), M, N, int(n_cat), _p(g), _vec_stride(g),
+                                       _p(out), _p(g_xhat), _stream()), "hidvae_cat_recon_rows")
+    return out if g is None else g_xhat
 
 
 def l2norm_fwd(x, eps=1e-12):
@@ -722,7 +746,7 @@ def total_loss_bwd(g_loss, B, L, w_a, w_p, w_u, g_rows, want_gz, embed_dim=EMBED
     return scal, g_z
 
 
-def loss_fwd(y, x, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want_grad):
+def loss_fwd(y, x, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, uniq_margin, w_a, w_p, w_u, want_grad, n_cat=0):
     """decoder tail + total loss -> (loss, recon, uniq, g_rows, tagstats, summary [6] = the training log row)"""
     _f32(y, "y"), _f32(x, "x")
     if y.shape != x.shape or not y.is_contiguous() or not x.is_contiguous():
@@ -739,19 +763,19 @@ def loss_fwd(y, x, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, uni
     tagstats = torch.empty((3 + 3 * n_tag,), device=dev, dtype=torch.float32) if n_tag else None
     summary = torch.empty((6,), device=dev, dtype=torch.float32)
     arr = lambda ts: _host_ptr_array(ts) if ts else None
-    _check(lib().hidvae_loss_fwd(_p(y), _p(x), B, N, _p(qloss), arr(aligns), arr(preds), arr(accs), n_tag, float(tag_div), _p(ids), _p(z), L,
+    _check(lib().hidvae_loss_fwd(_p(y), _p(x), B, N, _n_cat(n_cat, N), _p(qloss), arr(aligns), arr(preds), arr(accs), n_tag, float(tag_div), _p(ids), _p(z), L,
                                  float(uniq_weight), float(uniq_margin), float(w_a), float(w_p), float(w_u), _p(recon), _p(loss), _p(uniq),
                                  _p(g_rows), _p(tagstats), _p(summary), int(D), _stream()), "hidvae_loss_fwd")
     return loss, recon, uniq, g_rows, tagstats, summary
 
 
-def loss_bwd(g_loss, y, x, L, w_a, w_p, w_u, g_rows, want_gz, embed_dim=EMBED_DIM):
+def loss_bwd(g_loss, y, x, L, w_a, w_p, w_u, g_rows, want_gz, embed_dim=EMBED_DIM, n_cat=0):
     B, N = y.shape
     scal = torch.empty((3,), device=y.device, dtype=torch.float32)
     g_y = torch.empty_like(y)
     D = g_rows.shape[1] if g_rows is not None else int(embed_dim)
     g_z = torch.empty((B, D), device=y.device, dtype=torch.float32) if want_gz else None
-    _check(lib().hidvae_loss_bwd(_p(g_loss), _p(y), _p(x), B, N, L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(g_y), _p(scal), _p(g_z),
+    _check(lib().hidvae_loss_bwd(_p(g_loss), _p(y), _p(x), B, N, _n_cat(n_cat, N), L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(g_y), _p(scal), _p(g_z),
                                  int(D), _stream()), "hidvae_loss_bwd")
     return g_y, scal, g_z
 

@@ -12,10 +12,63 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 constexpr int MAXV = 4;  // N <= 64 lanes * 4 floats * MAXV = 1024 on the vector path
 
+// the decoder tail with n_cat categorical columns at the end of the row (h_rqvae.py:610-613, rqvae.py:146-149, loss.py:15-33):
+//   u = y / max(|y|, eps)            the decoder's closing L2NormalizationLayer, over the WHOLE row (encoder.py:32)
+//   v = u[:H] / max(|u[:H]|, eps)    the forward's l2norm of the non-categorical head, H = N - n_cat
+//   recon = sum_{i<H} (v_i - x_i)^2 + sum_{i>=H} BCE-with-logits(u_i, x_i)
+// and its gradient through both normalisations.  Not on any shipped config's path (all bind n_cat = 0): one wave per row, scalar loads.
+__device__ __noinline__ void recon_cat_row(const float *y, const float *x, int64_t row, int64_t N, int n_cat, float gscale, float *x_hat,
+                                           float *recon, float *g_y) {
+    const int lane = threadIdx.x & 63;
+    const float *yr = y + row * N, *xr = x + row * N;
+    const int64_t H = N - n_cat;
+    float ss = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) ss += yr[i] * yr[i];
+    const float n1 = sqrtf(hv_wave_sum(ss)), den1 = fmaxf(n1, 1e-12f);
+    float sh = 0.0f;
+    for (int64_t i = lane; i < H; i += 64) { const float u = yr[i] / den1; sh += u * u; }
+    const float n2 = sqrtf(hv_wave_sum(sh)), den2 = fmaxf(n2, 1e-12f);
+    float rs = 0.0f, t2 = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) {
+        const float u = yr[i] / den1;
+        if (i < H) {
+            const float v = u / den2, d = v - xr[i];
+            rs += d * d;
+            t2 += v * d;
+            if (x_hat != nullptr) x_hat[row * N + i] = v;
+        } else {  // max(u, 0) - u x + log(1 + exp(-|u|))
+            rs += (fmaxf(u, 0.0f) - u * xr[i]) + log1pf(expf(-fabsf(u)));
+            if (x_hat != nullptr) x_hat[row * N + i] = u;
+        }
+    }
+    rs = hv_wave_sum(rs);
+    if (lane == 0 && recon != nullptr) recon[row] = rs;
+    if (g_y == nullptr) return;
+    t2 = n2 > 1e-12f ? hv_wave_sum(t2) : 0.0f;
+    // g_u: head 2 (d - v (v.d)) / den2, tail sigmoid(u) - x;  g_y = gscale (g_u - u (u.g_u)) / den1
+    float t1 = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) {
+        const float u = yr[i] / den1;
+        float gu;
+        if (i < H) { const float v = u / den2; gu = 2.0f * ((v - xr[i]) - v * t2) / den2; }
+        else gu = 1.0f / (1.0f + expf(-u)) - xr[i];
+        t1 += u * gu;
+    }
+    t1 = n1 > 1e-12f ? hv_wave_sum(t1) : 0.0f;
+    for (int64_t i = lane; i < N; i += 64) {
+        const float u = yr[i] / den1;
+        float gu;
+        if (i < H) { const float v = u / den2; gu = 2.0f * ((v - xr[i]) - v * t2) / den2; }
+        else gu = 1.0f / (1.0f + expf(-u)) - xr[i];
+        g_y[row * N + i] = gscale * (gu - u * t1) / den1;
+    }
+}
+
 // one wave, one row: x_hat = y/max(|y|,eps), recon = |x_hat - x|^2, g_y = gscale * d recon / d y   (each output optional)
 template <bool VEC>
-__device__ __forceinline__ void recon_row(const float *y, const float *x, int64_t row, int64_t N, float gscale, float *x_hat,
+__device__ __forceinline__ void recon_row(const float *y, const float *x, int64_t row, int64_t N, int n_cat, float gscale, float *x_hat,
                                           float *recon, float *g_y) {
+    if (n_cat > 0) return recon_cat_row(y, x, row, N, n_cat, gscale, x_hat, recon, g_y);
     const int lane = threadIdx.x & 63;
     const float *yr = y + row * N, *xr = x + row * N;
     if (VEC) {
@@ -89,12 +142,12 @@ __device__ __forceinline__ void recon_row(const float *y, const float *x, int64_
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void recon_kernel(const float *y, const float *x, int64_t B, int64_t N, float gscale_all,
+__global__ __launch_bounds__(256) void recon_kernel(const float *y, const float *x, int64_t B, int64_t N, int n_cat, float gscale_all,
                                                     const float *gscale_items, int64_t gs_stride, float *x_hat, float *recon, float *g_y) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
     const float gscale = gscale_items != nullptr ? gscale_all * gscale_items[row * gs_stride] : gscale_all;
-    recon_row<VEC>(y, x, row, N, gscale, x_hat, recon, g_y);
+    recon_row<VEC>(y, x, row, N, n_cat, gscale, x_hat, recon, g_y);
 }
 
 // generic row L2 normalise: out = x / max(|x|, eps); saves |x| for the backward.  One wave per row.
@@ -261,17 +314,54 @@ __global__ __launch_bounds__(256) void id_stats_kernel(const float *emb_cat, int
         for (int64_t i = threadIdx.x; i < tsize; i += 256) table[i] = 0ull;
 }
 
+// CategoricalReconstructionLoss.forward as a stand-alone module (loss.py:15-33): x_hat is taken as given.
+// out[m] = sum_{j<H} (x_hat - x)^2 + sum_{j>=H} BCE-with-logits(x_hat, x);  g_xhat = g[m] * (2 (x_hat - x) | sigmoid(x_hat) - x)
+__global__ __launch_bounds__(256) void cat_recon_rows_kernel(const float *xh, int64_t ldh, const float *x, int64_t ldx, int64_t M, int64_t N,
+                                                             int n_cat, const float *g, int64_t g_stride, float *out, float *g_xhat) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t H = N - n_cat;
+    const float gr = g != nullptr ? g[row * g_stride] : 0.0f;
+    float rs = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) {
+        const float u = xh[row * ldh + i], t = x[row * ldx + i];
+        if (i < H) {
+            const float d = u - t;
+            rs += d * d;
+            if (g_xhat != nullptr) g_xhat[row * N + i] = gr * (2.0f * d);
+        } else {
+            rs += (fmaxf(u, 0.0f) - u * t) + log1pf(expf(-fabsf(u)));
+            if (g_xhat != nullptr) g_xhat[row * N + i] = gr * (1.0f / (1.0f + expf(-u)) - t);
+        }
+    }
+    rs = hv_wave_sum(rs);
+    if (lane == 0 && out != nullptr) out[row] = rs;
+}
+
 }  // namespace
 
-extern "C" int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, int64_t N, float gscale,
+extern "C" int hidvae_cat_recon_rows(const float *x_hat, int64_t ldh, const float *x, int64_t ldx, int64_t M, int64_t N, int n_cat,
+                                     const float *g, int64_t g_stride, float *out, float *g_xhat, void *stream) {
+    HV_REQUIRE(x_hat && x && M >= 1 && N >= 1 && (out || g_xhat), "cat_recon_rows: bad arguments");
+    HV_REQUIRE(n_cat >= 0 && n_cat <= N, "cat_recon_rows: n_cat=%d of %lld columns", n_cat, (long long)N);
+    HV_REQUIRE(g_xhat == nullptr || g != nullptr, "cat_recon_rows: a gradient output needs the incoming per-row gradient");
+    hipLaunchKernelGGL(cat_recon_rows_kernel, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x_hat, ldh, x, ldx, M, N, n_cat, g,
+                       g_stride, out, g_xhat);
+    HV_LAUNCH_CHECK("cat_recon_rows");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, int64_t N, int n_cat, float gscale,
                                     const float *gscale_items, int64_t gs_stride, float *x_hat, float *recon, float *g_y,
                                     void *stream) {
     HV_REQUIRE(y && x && B >= 1 && N >= 1, "recon: bad arguments");
+    HV_REQUIRE(n_cat >= 0 && n_cat < N, "recon: n_cat=%d of %lld columns", n_cat, (long long)N);
     const unsigned grid = (unsigned)hv_cdiv(B, 4);
     const bool vec = (N % 4 == 0) && N <= 256 * MAXV && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x) |
                                                           reinterpret_cast<uintptr_t>(x_hat) | reinterpret_cast<uintptr_t>(g_y)) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(recon_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, gscale, gscale_items, gs_stride, x_hat, recon, g_y);
-    else hipLaunchKernelGGL(recon_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, gscale, gscale_items, gs_stride, x_hat, recon, g_y);
+    if (vec) hipLaunchKernelGGL(recon_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, n_cat, gscale, gscale_items, gs_stride, x_hat, recon, g_y);
+    else hipLaunchKernelGGL(recon_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, n_cat, gscale, gscale_items, gs_stride, x_hat, recon, g_y);
     HV_LAUNCH_CHECK("recon_fwd_bwd");
     return HIDVAE_OK;
 }
@@ -481,7 +571,7 @@ __global__ __launch_bounds__(256) void total_loss_kernel(TotalArgs a) { total_lo
 
 // backward of the same pair in ONE launch: g_y = (g/B) d recon/d y per row; scal / g_z as total_loss_bwd_kernel
 template <bool VEC>
-__global__ __launch_bounds__(256) void loss_bwd_kernel(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L,
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int n_cat, int L,
                                                        float w_a, float w_p, float w_u, const float *g_rows, float *g_y, float *scal,
                                                        float *g_z, int D) {
     const float g = *g_loss;
@@ -495,7 +585,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float *g_loss, cons
         const int64_t idx = (int64_t)blockIdx.x * (4 * D) + threadIdx.x;
         if (idx < B * D) g_z[idx] = (g_rows != nullptr && idx < (int64_t)L * D) ? (g * w_u) * g_rows[idx] : 0.0f;
     }
-    if (row < B) recon_row<VEC>(y, x, row, N, 1.0f * (g / (float)B), nullptr, nullptr, g_y);
+    if (row < B) recon_row<VEC>(y, x, row, N, n_cat, 1.0f * (g / (float)B), nullptr, nullptr, g_y);
 }
 
 // scal[0] = g/B, scal[1] = g*w_a, scal[2] = g*w_p ; g_z [B,D] = g*w_u*g_rows on the first L rows, 0 elsewhere
@@ -552,12 +642,13 @@ static bool recon_vec_ok(int64_t N, const void *a, const void *b, const void *c,
            ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
 }
 
-extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, const float *qloss,
+extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, int n_cat, const float *qloss,
                                const float *const *align_host, const float *const *pred_host, const float *const *acc_host, int n_tag,
                                float tag_div, const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
                                float w_p, float w_u, float *recon, float *loss, float *uniq, float *g_rows, float *tagstats,
                                float *summary, int embed_dim, void *stream) {
     HV_REQUIRE(y && x && qloss && recon && loss && B >= 1 && N >= 1, "loss_fwd: bad arguments");
+    HV_REQUIRE(n_cat >= 0 && n_cat < N, "loss_fwd: n_cat=%d of %lld columns", n_cat, (long long)N);
     HV_REQUIRE(ids == nullptr || (z != nullptr && L >= 1 && L <= HIDVAE_MAX_LEVELS),
                "loss_fwd: uniqueness term needs z and 1 <= n_layers <= %d (L=%d)", HIDVAE_MAX_LEVELS, L);
     HV_REQUIRE(n_tag >= 0 && n_tag <= HIDVAE_MAX_LEVELS && (n_tag == 0 || (align_host && pred_host && acc_host && tag_div > 0.0f)),
@@ -576,10 +667,10 @@ extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_
     // L2 write-back costs several times the second launch (measured 25 us fused vs 5 + 6.6 us)
     const unsigned grid = (unsigned)hv_cdiv(B, 4);
     if (recon_vec_ok(N, y, x, nullptr, nullptr))
-        hipLaunchKernelGGL(recon_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, 0.0f, (const float *)nullptr,
+        hipLaunchKernelGGL(recon_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, n_cat, 0.0f, (const float *)nullptr,
                            (int64_t)0, (float *)nullptr, recon, (float *)nullptr);
     else
-        hipLaunchKernelGGL(recon_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, 0.0f, (const float *)nullptr,
+        hipLaunchKernelGGL(recon_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, B, N, n_cat, 0.0f, (const float *)nullptr,
                            (int64_t)0, (float *)nullptr, recon, (float *)nullptr);
     HV_LAUNCH_CHECK("loss_fwd recon");
     hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
@@ -587,16 +678,17 @@ extern "C" int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_
     return HIDVAE_OK;
 }
 
-extern "C" int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L, float w_a, float w_p,
+extern "C" int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int n_cat, int L, float w_a, float w_p,
                                float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, int embed_dim, void *stream) {
     HV_REQUIRE(g_loss && y && x && g_y && scal && B >= 1 && N >= 1, "loss_bwd: bad arguments");
+    HV_REQUIRE(n_cat >= 0 && n_cat < N, "loss_bwd: n_cat=%d of %lld columns", n_cat, (long long)N);
     HV_REQUIRE(g_z == nullptr || (embed_dim >= 1 && embed_dim <= 64), "loss_bwd: embed_dim=%d (at most 64)", embed_dim);
     const unsigned grid = (unsigned)hv_cdiv(B, 4);
     if (recon_vec_ok(N, y, x, g_y, nullptr))
-        hipLaunchKernelGGL(loss_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_loss, y, x, B, N, L, w_a, w_p, w_u, g_rows,
+        hipLaunchKernelGGL(loss_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_loss, y, x, B, N, n_cat, L, w_a, w_p, w_u, g_rows,
                            g_y, scal, g_z, embed_dim);
     else
-        hipLaunchKernelGGL(loss_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_loss, y, x, B, N, L, w_a, w_p, w_u, g_rows,
+        hipLaunchKernelGGL(loss_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_loss, y, x, B, N, n_cat, L, w_a, w_p, w_u, g_rows,
                            g_y, scal, g_z, embed_dim);
     HV_LAUNCH_CHECK("loss_bwd");
     return HIDVAE_OK;

@@ -16,7 +16,7 @@ from .. import _C
 from ..data.schemas import HRqVaeComputedLosses, HRqVaeOutput
 from ..ops import RQFn, StepLossFn, TotalLossFn  # noqa: F401
 from .encoder import MLP
-from .loss import QuantizeLoss, ReconstructionLoss, TagAlignmentLoss, TagPredictionLoss  # noqa: F401
+from .loss import CategoricalReconstructionLoss, QuantizeLoss, ReconstructionLoss, TagAlignmentLoss, TagPredictionLoss  # noqa: F401
 from .quantize import Quantize, QuantizeForwardMode
 
 try:  # the reference mixes in PyTorchModelHubMixin (h_rqvae.py:230); keep it when the hub package is importable
@@ -86,9 +86,8 @@ class HRqVae(nn.Module, _HubMixin):
         # the reference stores locals() here, `self` included; the module itself is left out on purpose
         self._config = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
         super().__init__()
-        if n_cat_features != 0:
-            raise NotImplementedError("n_cat_features != 0 (categorical BCE tail) is unreachable in the reference as shipped "
-                                      "(SURVEY Q1) and unused by both configs; not built on the HIP path")
+        if not 0 <= n_cat_features < input_dim:
+            raise ValueError(f"n_cat_features={n_cat_features} must leave at least one of the {input_dim} input columns non-categorical")
         _C.check_embed_dim(embed_dim)  # 32: the fused kernels; other multiples of 4 up to 64 (rqvae_ml32m.gin: 64): csrc/rq_generic.hip
         if not 1 <= n_layers <= _C.MAX_LEVELS:
             raise ValueError(f"n_layers must be in [1, {_C.MAX_LEVELS}]")
@@ -119,7 +118,7 @@ class HRqVae(nn.Module, _HubMixin):
         self.tag_projectors = nn.ModuleList([self._make_projector(i, codebook_normalize) for i in range(n_layers)])
         self.encoder = MLP(input_dim=input_dim, hidden_dims=hidden_dims, out_dim=embed_dim, normalize=codebook_normalize)
         self.decoder = MLP(input_dim=embed_dim, hidden_dims=hidden_dims[-1::-1], out_dim=input_dim, normalize=True)
-        self.reconstruction_loss = ReconstructionLoss()
+        self.reconstruction_loss = CategoricalReconstructionLoss(n_cat_features) if n_cat_features != 0 else ReconstructionLoss()  # h_rqvae.py:349-352
         self.tag_alignment_loss = TagAlignmentLoss(alignment_weight=tag_alignment_weight, temperature=alignment_temperature)
         self.tag_prediction_loss = TagPredictionLoss(use_focal_loss=use_focal_loss, focal_params=focal_loss_params, class_counts=None)
         self.sem_id_uniqueness_loss = SemanticIdUniquenessLoss(margin=sem_id_uniqueness_margin, weight=sem_id_uniqueness_weight)
@@ -419,13 +418,14 @@ class HRqVae(nn.Module, _HubMixin):
                 t.record_stream(main)
             for t in (emb_cat, ids):
                 t.record_stream(side)
-        # decoder l2norm + sum (x_hat-x)^2 (Q7: n_cat = 0) and the total loss in one launch
+        # decoder l2norm + sum (x_hat-x)^2 (Q7; with n_cat > 0 the head is normalised once more and the last n_cat columns enter as
+        # BCE-with-logits, h_rqvae.py:610-613 + loss.py:15-33) and the total loss in one launch
         # the alignment / uniqueness weights enter once inside their loss modules and once more here
         n_tag = len(tag_scalars) // 3
         loss, recon, uniq, stats, summary = StepLossFn.apply(y_dec, x, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
                                                     self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight,
                                                     self.tag_prediction_weight, self.sem_id_uniqueness_weight, n_tag,
-                                                    float(self.n_layers), *tag_scalars)
+                                                    float(self.n_layers), int(self.n_cat_feats), *tag_scalars)
         main.wait_stream(side)  # the statistics above were computed beside the decoder
         _C.phase_mark("fwd:loss done")
         self.last_summary = summary  # device [6]: loss, mean recon, mean rqvae, tag align, tag pred, tag accuracy (training log row)

@@ -2,7 +2,7 @@
 the reference's constructor arguments and the attributes train_hidvae.py pokes (loss.py:96-102 knobs)."""
 from torch import nn
 
-from ..ops import ReconFn, SqDiffRowsFn
+from ..ops import CatReconRowsFn, ReconFn, SqDiffRowsFn
 
 
 def _rows(t):
@@ -24,6 +24,27 @@ class ReconstructionLoss(nn.Module):
     @staticmethod
     def fused(decoder_body_out, x):
         return ReconFn.apply(decoder_body_out.contiguous(), x.contiguous())
+
+
+class CategoricalReconstructionLoss(nn.Module):
+    """Squared error on all but the last n_cat_feats columns + binary cross-entropy with logits on those (reference loss.py:15-33):
+    one launch each way (hidvae_cat_recon_rows).  `fused` takes the decoder output before its trailing L2 normalisation and folds
+    both normalisations of the forward (encoder.py:32, h_rqvae.py:610) into the same kernel."""
+
+    def __init__(self, n_cat_feats: int) -> None:
+        super().__init__()
+        self.reconstruction_loss = ReconstructionLoss()
+        self.n_cat_feats = n_cat_feats
+
+    def forward(self, x_hat, x):
+        out = CatReconRowsFn.apply(_rows(x_hat), _rows(x), int(self.n_cat_feats))
+        return out.reshape(x_hat.shape[:-1])
+
+    def fused(self, decoder_body_out, x):
+        return ReconFn.apply(decoder_body_out.contiguous(), x.contiguous(), int(self.n_cat_feats))
+
+
+CategoricalReconstuctionLoss = CategoricalReconstructionLoss  # the name h_rqvae.py:14 / rqvae.py import (SURVEY Q1: a typo in the reference)
 
 
 class QuantizeLoss(nn.Module):

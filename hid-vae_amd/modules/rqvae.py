@@ -11,7 +11,7 @@ from torch import Tensor, nn
 from .. import _C
 from .encoder import MLP
 from .h_rqvae import HRqVae, SemanticIdUniquenessLoss
-from .loss import ReconstructionLoss
+from .loss import CategoricalReconstructionLoss, ReconstructionLoss
 from .quantize import Quantize, QuantizeForwardMode
 
 RqVaeOutput = namedtuple("RqVaeOutput", ("embeddings", "residuals", "sem_ids", "quantize_loss"))
@@ -25,9 +25,8 @@ class RqVae(HRqVae):
                  commitment_weight: float = 0.25, n_cat_features: int = 18) -> None:
         self._config = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
         nn.Module.__init__(self)
-        if n_cat_features != 0:
-            raise NotImplementedError("n_cat_features != 0 (categorical BCE tail, reference rqvae.py:89-92) is not built on the HIP "
-                                      "path; the HiD-VAE configs use 768-d text embeddings with n_cat_features = 0")
+        if not 0 <= n_cat_features < input_dim:
+            raise ValueError(f"n_cat_features={n_cat_features} must leave at least one of the {input_dim} input columns non-categorical")
         _C.check_embed_dim(embed_dim)  # 32: the fused kernels; other multiples of 4 up to 64 (rqvae_ml32m.gin: 64): csrc/rq_generic.hip
         if not 1 <= n_layers <= _C.MAX_LEVELS:
             raise ValueError(f"n_layers must be in [1, {_C.MAX_LEVELS}]")
@@ -41,7 +40,7 @@ class RqVae(HRqVae):
                      commitment_weight=commitment_weight) for i in range(n_layers)])
         self.encoder = MLP(input_dim=input_dim, hidden_dims=hidden_dims, out_dim=embed_dim, normalize=codebook_normalize)
         self.decoder = MLP(input_dim=embed_dim, hidden_dims=hidden_dims[-1::-1], out_dim=input_dim, normalize=True)
-        self.reconstruction_loss = ReconstructionLoss()
+        self.reconstruction_loss = CategoricalReconstructionLoss(n_cat_features) if n_cat_features != 0 else ReconstructionLoss()  # rqvae.py:89-92
         # what HRqVae.forward consults; all inert here
         self.tag_alignment_weight = self.tag_prediction_weight = self.sem_id_uniqueness_weight = 0.0
         self.sem_id_uniqueness_loss = SemanticIdUniquenessLoss(margin=0.5, weight=0.0)

@@ -312,22 +312,42 @@ class RQFn(Function):
 
 
 class ReconFn(Function):
-    """decoder tail: recon[b] = sum_j (normalize(y)[b,j] - x[b,j])^2  (encoder.py:32 + loss.py:11-12)."""
+    """decoder tail: recon[b] = sum_j (normalize(y)[b,j] - x[b,j])^2  (encoder.py:32 + loss.py:11-12); with n_cat > 0 the last
+    n_cat columns of the row-normalised y enter as BCE-with-logits and the head is normalised once more (h_rqvae.py:610-613)."""
 
     @staticmethod
-    def forward(ctx, y, x):
+    def forward(ctx, y, x, n_cat=0):
         ctx.set_materialize_grads(False)
-        recon, _, _ = _C.recon_fwd_bwd(y, x)
+        recon, _, _ = _C.recon_fwd_bwd(y, x, n_cat=n_cat)
         ctx.save_for_backward(y, x)
+        ctx.n_cat = n_cat
         return recon
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return None, None
+            return None, None, None
         y, x = ctx.saved_tensors
-        _, _, g_y = _C.recon_fwd_bwd(y, x, gscale=1.0, gscale_items=g, want_grad=True)
-        return g_y, None
+        _, _, g_y = _C.recon_fwd_bwd(y, x, gscale=1.0, gscale_items=g, want_grad=True, n_cat=ctx.n_cat)
+        return g_y, None, None
+
+
+class CatReconRowsFn(Function):
+    """CategoricalReconstructionLoss.forward on a given x_hat (reference loss.py:15-33): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x_hat, x, n_cat):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x_hat, x)
+        ctx.n_cat = n_cat
+        return _C.cat_recon_rows(x_hat, x, n_cat)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        x_hat, x = ctx.saved_tensors
+        return _C.cat_recon_rows(x_hat, x, ctx.n_cat, g=g.contiguous()), None, None
 
 
 class TotalLossFn(Function):
@@ -370,13 +390,14 @@ class StepLossFn(Function):
     is differentiable (the reconstruction term's gradient travels inside it)."""
 
     @staticmethod
-    def forward(ctx, y, x, qloss, z, ids, uniq_weight, uniq_margin, w_a, w_p, w_u, n_tag, tag_div, *tag_scalars):
+    def forward(ctx, y, x, qloss, z, ids, uniq_weight, uniq_margin, w_a, w_p, w_u, n_tag, tag_div, n_cat, *tag_scalars):
         ctx.set_materialize_grads(False)
+        ctx.n_cat = n_cat
         want = z is not None and ctx.needs_input_grad[3]
         aligns, preds, accs = list(tag_scalars[:n_tag]), list(tag_scalars[n_tag:2 * n_tag]), list(tag_scalars[2 * n_tag:3 * n_tag])
         loss, recon, uniq, g_rows, tagstats, summary = _C.loss_fwd(y, x, qloss.detach(), [t.detach() for t in aligns], [t.detach() for t in preds],
                                                           [t.detach() for t in accs], tag_div, ids, z, uniq_weight, uniq_margin, w_a,
-                                                          w_p, w_u, want)
+                                                          w_p, w_u, want, n_cat=n_cat)
         ctx.meta = (y.shape[0], ids.shape[1] if ids is not None else 0, w_a, w_p, w_u, n_tag, tag_div, z is not None)
         ctx.g_rows = g_rows
         ctx.save_for_backward(y, x)
@@ -389,13 +410,13 @@ class StepLossFn(Function):
     def backward(ctx, g, _g_recon, _g_uniq, _g_stats, _g_summary):
         B, L, w_a, w_p, w_u, n_tag, tag_div, has_z = ctx.meta
         if g is None:
-            return (None,) * (12 + 3 * n_tag)
+            return (None,) * (13 + 3 * n_tag)
         y, x = ctx.saved_tensors
         g_y, scal, g_z = _C.loss_bwd(g.contiguous(), y, x, L, w_a / tag_div, w_p / tag_div, w_u, ctx.g_rows,
-                                     want_gz=has_z and ctx.g_rows is not None)
+                                     want_gz=has_z and ctx.g_rows is not None, n_cat=ctx.n_cat)
         per_item = scal[0].expand(B)  # stride-0 view: the kernels downstream read one device scalar
         tags = (scal[1],) * n_tag + (scal[2],) * n_tag + (None,) * n_tag
-        return (g_y, None, per_item, g_z, None, None, None, None, None, None, None, None) + tags
+        return (g_y, None, per_item, g_z, None, None, None, None, None, None, None, None, None) + tags
 
 
 class UniqLossFn(Function):

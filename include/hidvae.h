@@ -218,8 +218,11 @@ int hidvae_codebook_grad(const int64_t *ids, const float *dE_rows, int64_t B, in
 
 /* ---- a3/a14: decoder tail.  x_hat = y / max(|y|,1e-12) (encoder.py:32), recon[b] = sum (x_hat-x)^2
  * (loss.py:11-12) and, if g_y != NULL, g_y = d(sum_b gscale_b * recon[b]) / dy with gscale_b = gscale *
- * gscale_items[b*gs_stride] (just gscale when gscale_items == NULL; stride 0 broadcasts one device scalar). */
-int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, int64_t N, float gscale,
+ * gscale_items[b*gs_stride] (just gscale when gscale_items == NULL; stride 0 broadcasts one device scalar).
+ * n_cat > 0 (0 <= n_cat < N): the last n_cat columns are categorical (h_rqvae.py:610-613, rqvae.py:146-149, loss.py:15-33):
+ * u = y / max(|y|,1e-12) over the whole row, the first N - n_cat columns of u are L2-normalised once more and enter as squared
+ * error, the last n_cat enter as binary cross-entropy with logits against x; x_hat = cat(normalised head, tail of u). */
+int hidvae_recon_fwd_bwd(const float *y, const float *x, int64_t B, int64_t N, int n_cat, float gscale,
                          const float *gscale_items, int64_t gs_stride, float *x_hat, float *recon, float *g_y,
                          void *stream);
 
@@ -257,13 +260,14 @@ int hidvae_total_loss_bwd(const float *g_loss, int64_t B, int L, float w_a, floa
 /* The step's own pairing of the two above with the decoder tail (a3 + a14 + a1): one call forward, ONE launch backward.
  * loss_fwd: recon[b] = |normalize(y[b]) - x[b]|^2 (encoder.py:32, loss.py:11-12) for every row, then the total loss as
  *   hidvae_total_loss.
- * loss_bwd: g_y = (g_loss/B) d recon/d y;  scal / g_z exactly as hidvae_total_loss_bwd. */
-int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, const float *qloss,
+ * loss_bwd: g_y = (g_loss/B) d recon/d y;  scal / g_z exactly as hidvae_total_loss_bwd.
+ * n_cat: categorical columns at the end of the row, as in hidvae_recon_fwd_bwd (0 on every shipped config). */
+int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, int n_cat, const float *qloss,
                     const float *const *align_host, const float *const *pred_host, const float *const *acc_host, int n_tag,
                     float tag_div, const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
                     float w_p, float w_u, float *recon, float *loss, float *uniq, float *g_rows, float *tagstats,
                     float *summary, int embed_dim, void *stream);
-int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int L, float w_a, float w_p,
+int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int n_cat, int L, float w_a, float w_p,
                     float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, int embed_dim, void *stream);
 
 /* ---- a14 as stand-alone modules: ReconstructionLoss.forward (loss.py:7-12) and the two halves of QuantizeLoss.forward
@@ -275,6 +279,12 @@ int hidvae_sqdiff_rows(const float *a, int64_t lda, const float *b, int64_t ldb,
                        void *stream);
 int hidvae_sqdiff_rows_bwd(const float *g, int64_t g_stride, const float *a, int64_t lda, const float *b, int64_t ldb, int64_t M,
                            int64_t N, float scale_a, float scale_b, float *ga, float *gb, void *stream);
+
+/* CategoricalReconstructionLoss.forward as a stand-alone module (loss.py:15-33), x_hat taken as given (row strides ldh / ldx):
+ * out[m] = sum_{j < N-n_cat} (x_hat-x)^2 + sum_{j >= N-n_cat} BCE-with-logits(x_hat, x)   (out may be NULL);
+ * g_xhat [M,N] (optional, needs g) = g[m*g_stride] * d out[m] / d x_hat. */
+int hidvae_cat_recon_rows(const float *x_hat, int64_t ldh, const float *x, int64_t ldx, int64_t M, int64_t N, int n_cat, const float *g,
+                          int64_t g_stride, float *out, float *g_xhat, void *stream);
 
 /* ---- a13: debug statistics (h_rqvae.py:643-648) ----------------------------------------------------
  * embs_norm[b,i] = |emb_cat[b, i*32:(i+1)*32]|; *p_unique = (#distinct id tuples)/B computed by a

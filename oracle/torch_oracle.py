@@ -52,6 +52,7 @@ class Cfg:
     label_smoothing_alpha: float = 0.1
     use_mixup: bool = True
     mixup_alpha: float = 0.2
+    n_cat_features: int = 0  # the ctor default is 18 (h_rqvae.py:243); every shipped config binds 0
 
     def classes(self):
         c = self.tag_class_counts if self.tag_class_counts is not None else [10, 100, 1000]
@@ -365,8 +366,14 @@ def forward(P, cfg: Cfg, x, tags_emb=None, tags_indices=None, gumbel_t=0.2, trai
         res = res - out
     emb = torch.stack(embs, dim=-1)  # [B, D, L]
     sem_ids = torch.stack(ids_l, dim=-1)  # [B, L]
-    x_hat = mlp(emb.sum(-1), dec_weights(P, cfg), True)  # n_cat_features == 0
-    recon = ((x_hat - x) ** 2).sum(-1)
+    x_hat = mlp(emb.sum(-1), dec_weights(P, cfg), True)
+    c = cfg.n_cat_features
+    if c == 0:  # (the forward's second l2norm / cat is an identity then)
+        recon = ((x_hat - x) ** 2).sum(-1)
+    else:  # h_rqvae.py:610-613 + loss.py:15-33
+        x_hat = torch.cat([F.normalize(x_hat[..., :-c], p=2, dim=-1, eps=1e-12), x_hat[..., -c:]], dim=-1)
+        recon = ((x_hat[:, :-c] - x[:, :-c]) ** 2).sum(-1) \
+            + F.binary_cross_entropy_with_logits(x_hat[:, -c:], x[:, -c:], reduction="none").sum(-1)
     if tagged:
         align = torch.stack(align_l).sum() / L
         pred = torch.stack(pred_l).sum() / L
@@ -459,6 +466,9 @@ def formula_batch(cfg: Cfg, B, seed=7, tagged=True, invalid_frac=0.05):
     from . import fill
     import numpy as np
     x = torch.from_numpy(fill.unit_rows((B, cfg.input_dim), seed))
+    if cfg.n_cat_features:  # the categorical columns hold 0/1 indicators
+        c = cfg.n_cat_features
+        x[:, -c:] = (x[:, -c:] > 0).float()
     if not tagged:
         return x, None, None
     te = torch.from_numpy(fill.gauss((B, cfg.n_layers, cfg.tag_embed_dim), seed + 1))

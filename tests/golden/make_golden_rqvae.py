@@ -41,7 +41,7 @@ def run(name, cfg, B, training):
     x, _, _ = O.formula_batch(cfg, B, seed=7, tagged=False)
     m = RqVae(input_dim=cfg.input_dim, embed_dim=cfg.embed_dim, hidden_dims=list(cfg.hidden_dims), codebook_size=cfg.codebook_size,
               codebook_kmeans_init=False, codebook_normalize=cfg.codebook_normalize, codebook_sim_vq=False,
-              codebook_mode=MODES[cfg.codebook_mode], n_layers=cfg.n_layers, commitment_weight=cfg.commitment_weight, n_cat_features=0)
+              codebook_mode=MODES[cfg.codebook_mode], n_layers=cfg.n_layers, commitment_weight=cfg.commitment_weight, n_cat_features=cfg.n_cat_features)
     sd = m.state_dict()
     assert set(sd) == set(P), (sorted(sd), sorted(P))
     m.load_state_dict({k: v.clone() for k, v in P.items()})
@@ -90,3 +90,4 @@ if __name__ == "__main__":
     run("rqvae_ste_train_nonorm_b48", O.Cfg(**{**base, "codebook_mode": O.STE, "codebook_normalize": False}), 48, True)
     run("rqvae_rot_eval_b64", O.Cfg(**base), 64, False)
     run("rqvae_rot_train_d64_b96", O.Cfg(**{**base, "embed_dim": 64}), 96, True)  # configs/rqvae_ml32m.gin:11
+    run("rqvae_rot_train_ncat18_b48", O.Cfg(**{**base, "n_cat_features": 18}), 48, True)  # the ctor default (rqvae.py:50)

@@ -217,6 +217,39 @@ def test_recon_and_l2norm(C):
                           exact.rq_forward(z.cpu().numpy(), [np.ones((1, 32), np.float32)], True, False, 2, False, 0.0)["z"])
 
 
+@pytest.mark.parametrize("B,N,c", [(70, 768, 18), (33, 100, 1), (5, 40, 39), (300, 1030, 64)])
+def test_categorical_decoder_tail_against_autograd(C, B, N, c):
+    """n_cat_features > 0 (reference h_rqvae.py:610-613, loss.py:15-33): the row l2norm, the head's second l2norm, squared error on
+    the head and BCE-with-logits on the last c columns, forward and gradient, against torch autograd on the CPU."""
+    F = torch.nn.functional
+    y = fill.gauss((B, N), 46) * np.float32(3.0)
+    x = fill.unit_rows((B, N), 47)
+    x[:, -c:] = (x[:, -c:] > 0).astype(np.float32)
+    gs = fill.uniform((B,), 48, 0.1, 1.0)
+    yt = torch.from_numpy(y).requires_grad_(True)
+    u = F.normalize(yt, dim=-1, eps=1e-12)
+    xh = torch.cat([F.normalize(u[:, :-c], dim=-1, eps=1e-12), u[:, -c:]], -1)
+    xt = torch.from_numpy(x)
+    rec = ((xh[:, :-c] - xt[:, :-c]) ** 2).sum(-1) + F.binary_cross_entropy_with_logits(xh[:, -c:], xt[:, -c:], reduction="none").sum(-1)
+    (rec * torch.from_numpy(gs)).sum().backward()
+    recon, x_hat, g_y = C.recon_fwd_bwd(dev(y), dev(x), gscale_items=dev(gs), want_xhat=True, want_grad=True, n_cat=c)
+    assert H.rel_err(recon.cpu().numpy(), rec.detach().numpy()) < 1e-5
+    assert H.rel_err(x_hat.cpu().numpy(), xh.detach().numpy()) < 1e-5
+    assert H.close(g_y.cpu().numpy(), yt.grad.numpy(), 3e-5, 1e-8)
+    # the stand-alone module on a given x_hat (CategoricalReconstructionLoss.forward)
+    from hidvae_amd.modules.loss import CategoricalReconstructionLoss
+    ht = xh.detach().clone().requires_grad_(True)
+    ref = ((ht[:, :-c] - xt[:, :-c]) ** 2).sum(-1) + F.binary_cross_entropy_with_logits(ht[:, -c:], xt[:, -c:], reduction="none").sum(-1)
+    (ref * torch.from_numpy(gs)).sum().backward()
+    hd = xh.detach().cuda().requires_grad_(True)
+    out = CategoricalReconstructionLoss(c)(hd, dev(x))
+    (out * dev(gs)).sum().backward()
+    assert H.rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    assert H.close(hd.grad.cpu().numpy(), ht.grad.numpy(), 2e-5, 1e-8)
+    with pytest.raises(RuntimeError):
+        C.recon_fwd_bwd(dev(y), dev(x), n_cat=N)
+
+
 def test_id_stats(C):
     ids = torch.from_numpy(fill.ints((5000, 3), 50, 12)).cuda()
     emb = dev(fill.gauss((5000, 96), 51))

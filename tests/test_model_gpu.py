@@ -20,7 +20,7 @@ def build_model(cfg, P):
     m = HRqVae(input_dim=cfg.input_dim, embed_dim=cfg.embed_dim, hidden_dims=list(cfg.hidden_dims), codebook_size=cfg.codebook_size,
                codebook_kmeans_init=False, codebook_normalize=cfg.codebook_normalize, codebook_sim_vq=cfg.codebook_sim_vq,
                codebook_mode=QuantizeForwardMode(cfg.codebook_mode), n_layers=cfg.n_layers, commitment_weight=cfg.commitment_weight,
-               n_cat_features=0, tag_alignment_weight=cfg.tag_alignment_weight, tag_prediction_weight=cfg.tag_prediction_weight,
+               n_cat_features=cfg.n_cat_features, tag_alignment_weight=cfg.tag_alignment_weight, tag_prediction_weight=cfg.tag_prediction_weight,
                tag_class_counts=cfg.classes(), tag_embed_dim=cfg.tag_embed_dim, use_focal_loss=cfg.use_focal_loss,
                focal_loss_params=cfg.focal_loss_params, dropout_rate=cfg.dropout_rate, use_batch_norm=cfg.use_batch_norm,
                alignment_temperature=cfg.alignment_temperature, sem_id_uniqueness_weight=cfg.sem_id_uniqueness_weight,
@@ -274,7 +274,7 @@ def test_plain_rqvae_matches_reference_goldens(name):
     m = RqVae(input_dim=cfg.input_dim, embed_dim=cfg.embed_dim, hidden_dims=list(cfg.hidden_dims), codebook_size=cfg.codebook_size,
               codebook_kmeans_init=False, codebook_normalize=cfg.codebook_normalize, codebook_sim_vq=False,
               codebook_mode=QuantizeForwardMode(cfg.codebook_mode), n_layers=cfg.n_layers, commitment_weight=cfg.commitment_weight,
-              n_cat_features=0).cuda()
+              n_cat_features=cfg.n_cat_features).cuda()
     assert set(m.state_dict()) == set(P)
     m.load_state_dict({k: v.clone() for k, v in P.items()})
     m.train(desc["training"])
