@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libhidvae_hip.so")
 _lib = None
 
 MODE_GUMBEL, MODE_STE, MODE_ROTATION = 1, 2, 3
+DIST_L2, DIST_COSINE = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_SILU, EPI_RELU, EPI_GELU, EPI_SIGMOID = 0, 1, 2, 3, 4
 EPI_DSILU, EPI_DRELU, EPI_DGELU, EPI_DSIGMOID = 16, 17, 18, 19
@@ -30,7 +31,7 @@ _SIGNATURES = {
     "hidvae_gate_bwd": [_vp, _i64, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_codebook_prepare": [_vp, _vp, _i, _i64, _vp, _vp, _i, _vp],
-    "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _vp],
+    "hidvae_rq_forward": [_vp, _i64, _i, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "hidvae_bottleneck_fwd": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp,
                               _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _i, _vp],
@@ -518,7 +519,7 @@ def take_pending_adamw(device, owner=None):
     return ent[1]
 
 
-def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=False, want_z=True):
+def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=False, want_z=True, distance=DIST_L2):
     _f32(y, "y")
     L, K, D = cb_eff.shape
     if y.dim() != 2 or y.shape[1] != D or not y.is_contiguous():
@@ -531,10 +532,10 @@ def rq_forward(y, cb_eff, cc, normalize_input, mode, training, beta, want_res=Fa
     emb_sum = torch.empty((B, D), device=dev, dtype=torch.float32)
     res = torch.empty((B, L * D), device=dev, dtype=torch.float32) if want_res else None
     qloss = torch.empty((B,), device=dev, dtype=torch.float32)
-    ws = _ws(WS_RQ_FORWARD, dev, B, L, K) if D == EMBED_DIM else None
+    ws = _ws(WS_RQ_FORWARD, dev, B, L, K) if (D == EMBED_DIM and distance == DIST_L2) else None
     _check(lib().hidvae_rq_forward(_p(y), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, int(mode), int(bool(training)),
                                    float(beta), _p(z), _p(ids), _p(emb_cat), L * D, _p(emb_sum), _p(res), _p(qloss),
-                                   _p(ws), int(D), _stream()), "hidvae_rq_forward")
+                                   _p(ws), int(D), int(distance), _stream()), "hidvae_rq_forward")
     return z if z is not None else y, ids, emb_cat, emb_sum, res, qloss
 
 
@@ -550,7 +551,7 @@ def rq_ids(y, cb_eff, cc, normalize_input=False):
     ids = torch.empty((B, L), device=y.device, dtype=torch.int64)
     ws = _ws(WS_RQ_FORWARD, y.device, B, L, K) if D == EMBED_DIM else None
     _check(lib().hidvae_rq_forward(_p(y), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, MODE_STE, 0, 0.0, None, _p(ids),
-                                   None, L * D, None, None, None, _p(ws), int(D), _stream()), "hidvae_rq_forward")
+                                   None, L * D, None, None, None, _p(ws), int(D), DIST_L2, _stream()), "hidvae_rq_forward")
     return ids
 
 

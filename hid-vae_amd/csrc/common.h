@@ -130,7 +130,7 @@ bool hv_rqg_dim_ok(int D);
 int hv_rqg_prepare(const float *const *E_host, const int32_t *normalize_host, int L, int64_t K, int D, float *cb_eff, float *cc, hipStream_t s);
 int hv_rqg_forward(const float *y, int64_t B, int normalize_input, const float *cb_eff, const float *cc, int L, int64_t K, int D, int mode,
                    int training, float beta, float *z, int64_t *ids, float *emb_cat, int64_t ld_cat, float *emb_sum, float *res_cat,
-                   float *qloss, hipStream_t s);
+                   float *qloss, int cosine, hipStream_t s);
 int hv_rqg_backward(const float *y, const float *z, int64_t B, int normalize_input, const float *cb_eff, const float *cc, int L, int64_t K, int D,
                     int mode, float beta, const int64_t *ids, const float *g_cat, int64_t ld_gcat, const float *g_sum, const float *g_z_in,
                     int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows, hipStream_t s);

@@ -1377,17 +1377,18 @@ extern "C" int hidvae_codebook_prepare_adamw(const float *const *E_host, const i
 extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input, const float *cb_eff, const float *cc,
                                  int L, int64_t K, int mode, int training, float beta, float *z, int64_t *ids,
                                  float *emb_cat, int64_t ld_cat, float *emb_sum, float *res_cat, float *qloss,
-                                 void *workspace, int embed_dim, void *stream) {
+                                 void *workspace, int embed_dim, int distance, void *stream) {
     HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "rq_forward: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
+    HV_REQUIRE(distance == HIDVAE_DIST_L2 || distance == HIDVAE_DIST_COSINE, "rq_forward: distance %d", distance);
     HV_REQUIRE(B >= 1 && K >= 1, "rq_forward: empty batch or codebook (B=%lld K=%lld)", (long long)B, (long long)K);
     HV_REQUIRE(y && cb_eff && cc && ids, "rq_forward: null pointer");
     HV_REQUIRE(mode == HIDVAE_MODE_STE || mode == HIDVAE_MODE_ROTATION || !training,
                "rq_forward: mode %d is not fused (GUMBEL_SOFTMAX is composed from GEMM + softmax)", mode);
-    if (embed_dim != D) {
+    if (embed_dim != D || distance != HIDVAE_DIST_L2) {  // (the cosine ranking, which no shipped config selects, lives in the width-independent kernel only)
         HV_REQUIRE(hv_rqg_dim_ok(embed_dim), "rq_forward: embed_dim=%d (a multiple of 4, at most 64)", embed_dim);
         HV_REQUIRE(emb_cat == nullptr || ld_cat >= (int64_t)L * embed_dim, "rq_forward: ld_cat=%lld", (long long)ld_cat);
         return hv_rqg_forward(y, B, normalize_input, cb_eff, cc, L, K, embed_dim, mode, training, beta, z, ids, emb_cat, ld_cat, emb_sum, res_cat,
-                              qloss, (hipStream_t)stream);
+                              qloss, distance == HIDVAE_DIST_COSINE, (hipStream_t)stream);
     }
     HV_REQUIRE(emb_cat == nullptr || (ld_cat >= (int64_t)L * D && ld_cat % 4 == 0), "rq_forward: ld_cat=%lld", (long long)ld_cat);
     FwdArgs a{};

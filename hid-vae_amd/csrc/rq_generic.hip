@@ -22,6 +22,7 @@ struct GenFwd {
     int L; int64_t K; int D;
     float beta;
     float *z; int64_t *ids; float *emb_cat; int64_t ld_cat; float *emb_sum, *res_cat, *qloss;
+    int cosine;  // QuantizeDistance.COSINE (quantize.py:115-119): the search ranks by -(r/|r| . c) / |c|; outputs and loss as ever
 };
 
 template <int MODE, bool TRAIN>
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void rq_generic_fwd_kernel(GenFwd a) {
         for (int i = 0; i < GI; i++) {
             if (a.res_cat != nullptr && live[i] && lane < D) a.res_cat[(item0 + i) * ((int64_t)a.L * D) + lvl * D + lane] = r[i];
             xx[i] = hv_wave_sum(r[i] * r[i]);
-            rbuf[wave][i][lane] = r[i];
+            rbuf[wave][i][lane] = a.cosine ? r[i] / sqrtf(xx[i]) : r[i];  // (no epsilon: x / x.norm(), quantize.py:117)
             best[i] = INFINITY;
             bidx[i] = 0;
         }
@@ -91,9 +92,10 @@ __global__ __launch_bounds__(256) void rq_generic_fwd_kernel(GenFwd a) {
                 }
             }
             const float cck = kok ? cc[k] : INFINITY;
+            const float cn = sqrtf(cck);
 #pragma unroll
             for (int i = 0; i < GI; i++) {
-                const float dist = fmaf(-2.0f, dot[i], xx[i] + cck);
+                const float dist = !a.cosine ? fmaf(-2.0f, dot[i], xx[i] + cck) : (kok ? -(dot[i] / cn) : INFINITY);
                 if (dist < best[i]) { best[i] = dist; bidx[i] = (int)k; }  // ascending k inside the lane: strict < keeps the first minimum
             }
         }
@@ -266,8 +268,8 @@ int hv_rqg_prepare(const float *const *E_host, const int32_t *normalize_host, in
 
 int hv_rqg_forward(const float *y, int64_t B, int normalize_input, const float *cb_eff, const float *cc, int L, int64_t K, int D, int mode,
                    int training, float beta, float *z, int64_t *ids, float *emb_cat, int64_t ld_cat, float *emb_sum, float *res_cat,
-                   float *qloss, hipStream_t s) {
-    GenFwd a{y, B, normalize_input, cb_eff, cc, L, K, D, beta, z, ids, emb_cat, ld_cat, emb_sum, res_cat, qloss};
+                   float *qloss, int cosine, hipStream_t s) {
+    GenFwd a{y, B, normalize_input, cb_eff, cc, L, K, D, beta, z, ids, emb_cat, ld_cat, emb_sum, res_cat, qloss, cosine};
     const dim3 grid((unsigned)hv_cdiv(B, 4 * GI));
     if (!training) hipLaunchKernelGGL((rq_generic_fwd_kernel<HIDVAE_MODE_STE, false>), grid, dim3(256), 0, s, a);
     else if (mode == HIDVAE_MODE_STE) hipLaunchKernelGGL((rq_generic_fwd_kernel<HIDVAE_MODE_STE, true>), grid, dim3(256), 0, s, a);

@@ -259,12 +259,16 @@ class RQFn(Function):
     @staticmethod
     def forward(ctx, y, normalize_input, mode, training, beta, normalize_flags, want_res, prepared, *tables):
         ctx.set_materialize_grads(False)
+        distance = _C.DIST_L2
+        if isinstance(mode, tuple):  # (forward mode, distance): Quantize on its own with QuantizeDistance.COSINE (quantize.py:115-119)
+            mode, distance = mode
         if prepared is not None:  # effective codebooks were computed on the helper stream beside the encoder
             cb, cc = prepared
             join_side()
         else:
             cb, cc = _C.codebook_prepare([t.detach() for t in tables], normalize_flags)
-        z, ids, emb_cat, emb_sum, res, qloss = _C.rq_forward(y, cb, cc, normalize_input, mode, training, beta, want_res=want_res)
+        z, ids, emb_cat, emb_sum, res, qloss = _C.rq_forward(y, cb, cc, normalize_input, mode, training, beta, want_res=want_res,
+                                                             distance=distance)
         ctx.cfg = (normalize_input, mode, training, beta, tuple(normalize_flags))
         ctx.tables = tables
         # (save_for_backward, not attributes: z and ids are OUTPUTS of this node, and an output held by its own ctx is a reference

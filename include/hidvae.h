@@ -39,6 +39,12 @@ extern "C" {
 #define HIDVAE_MODE_STE 2
 #define HIDVAE_MODE_ROTATION 3
 
+/* quantize.py:22-24 QuantizeDistance: what the per-level search ranks the codes by.  L2 is |r - c|^2 (every shipped config; the fused
+ * kernels); COSINE is -(r/|r| . c)/|c| (quantize.py:115-119; HRqVae never selects it -- Quantize on its own can): the width-independent
+ * kernel at any embed_dim.  Outputs, losses and the backward are the same function of the chosen ids either way. */
+#define HIDVAE_DIST_L2 0
+#define HIDVAE_DIST_COSINE 1
+
 /* GEMM operand layouts: C[M,N] = opA(A) . opB(B) */
 #define HIDVAE_GEMM_NT 0 /* A[M,K] B[N,K]  : Linear forward   x W^T        (encoder.py:27) */
 #define HIDVAE_GEMM_NN 1 /* A[M,K] B[K,N]  : input gradient   dY W                          */
@@ -175,7 +181,7 @@ int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
                       const float *cb_eff, const float *cc, int L, int64_t K,
                       int mode, int training, float beta,
                       float *z, int64_t *ids, float *emb_cat, int64_t ld_cat,
-                      float *emb_sum, float *res_cat, float *qloss, void *workspace, int embed_dim, void *stream);
+                      float *emb_sum, float *res_cat, float *qloss, void *workspace, int embed_dim, int distance, void *stream);
 
 /* ---- a2 (last two layers) + a5-a7 + a3 (first two layers) in ONE launch, for small batches (B <= 4096; codebooks + 34 KB of
  * activations must fit in LDS: L*(33*Kp+64)*4 bytes with Kp = K rounded up to 128, e.g. 3x256 or 2x512).  Training only.

@@ -227,9 +227,10 @@ void orc_codebook_prepare_gen(const float *E, int64_t K, int Dg, int normalize, 
 
 void orc_rq_forward_gen(const float *y, int64_t B, int Dg, int normalize_input, int L, int64_t K, const float *const *cbs,
                         const float *const *ccs, int mode, int training, float beta, float *z_out, int64_t *ids, float *emb_cat,
-                        float *emb_sum, float *res_cat, float *loss) {
+                        float *emb_sum, float *res_cat, float *loss, int cosine) {
+    /* cosine != 0: QuantizeDistance.COSINE (modules/quantize.py:115-119): codes ranked by -((r/|r|) . c) / |c|, no epsilons */
     for (int64_t b = 0; b < B; b++) {
-        float r[64], o[64], esum[64];
+        float r[64], o[64], esum[64], rn[64];
         memcpy(r, y + b * Dg, sizeof(float) * (size_t)Dg);
         if (normalize_input) {
             const float den = fmaxf(sqrtf(dotG(r, r, Dg)), 1e-12f);
@@ -241,13 +242,14 @@ void orc_rq_forward_gen(const float *y, int64_t B, int Dg, int normalize_input, 
             const float *cb = cbs[i], *cc = ccs[i];
             if (res_cat) memcpy(res_cat + (b * L + i) * Dg, r, sizeof(float) * (size_t)Dg);
             const float xx = dotG(r, r, Dg);
+            for (int d = 0; d < Dg; d++) rn[d] = cosine ? r[d] / sqrtf(xx) : r[d];
             float best = INFINITY;
             int64_t bi = 0;
             for (int64_t k = 0; k < K; k++) { /* (lane order on the GPU: ascending k inside a lane, lowest index on ties across lanes) */
                 const float *c = cb + k * Dg;
                 float acc = 0.0f;
-                for (int d = 0; d < Dg; d++) acc = fmaf(r[d], c[d], acc);
-                const float dist = fmaf(-2.0f, acc, xx + cc[k]);
+                for (int d = 0; d < Dg; d++) acc = fmaf(rn[d], c[d], acc);
+                const float dist = cosine ? -(acc / sqrtf(cc[k])) : fmaf(-2.0f, acc, xx + cc[k]);
                 if (dist < best) { best = dist; bi = k; }
             }
             const float *e = cb + bi * Dg;

@@ -71,12 +71,12 @@ def codebook_prepare(E, normalize):
     return cb, cc
 
 
-def rq_forward(y, codebooks, normalize_input, normalize_l0, mode, training, beta):
+def rq_forward(y, codebooks, normalize_input, normalize_l0, mode, training, beta, cosine=False):
     """y [B,D] (pre-normalisation encoder output); codebooks: list of L raw [K,D] embedding tables (D = 32: ORDER-G/Q/P; else ORDER-GEN).
     Returns dict(z, ids[B,L] int64, emb_cat[B,L*32], emb_sum[B,32], res_cat[B,L*32], loss[B])."""
     y, yp = _f(y)
-    if y.shape[1] != 32:  # the width-independent kernels have their own operation order
-        return rq_forward_gen(y, codebooks, normalize_input, normalize_l0, mode, training, beta)
+    if y.shape[1] != 32 or cosine:  # the width-independent kernels have their own operation order
+        return rq_forward_gen(y, codebooks, normalize_input, normalize_l0, mode, training, beta, cosine)
     B, L = y.shape[0], len(codebooks)
     K = codebooks[0].shape[0]
     prepared = [codebook_prepare(E, normalize_l0 and i == 0) for i, E in enumerate(codebooks)]
@@ -95,7 +95,7 @@ def rq_forward(y, codebooks, normalize_input, normalize_l0, mode, training, beta
     return dict(z=z, ids=ids, emb_cat=emb_cat, emb_sum=emb_sum, res_cat=res_cat, loss=loss, cbs=cbs, ccs=ccs)
 
 
-def rq_forward_gen(y, codebooks, normalize_input, normalize_l0, mode, training, beta):
+def rq_forward_gen(y, codebooks, normalize_input, normalize_l0, mode, training, beta, cosine=False):
     """rq_forward at any embedding width D <= 64 (a multiple of 4): ORDER-GEN, the operation order of csrc/rq_generic.hip.
     y [B,D]; codebooks: list of L raw [K,D] tables.  Returns the same dict as rq_forward."""
     y, yp = _f(y)
@@ -105,6 +105,11 @@ def rq_forward_gen(y, codebooks, normalize_input, normalize_l0, mode, training, 
     cbs, ccs = [], []
     for i, E in enumerate(codebooks):
         E, Ep = _f(E)
+        if D == 32:  # (the cosine ranking at width 32: the tables still come from the width-32 prepare launch, in its order)
+            cb, cc = codebook_prepare(E, normalize_l0 and i == 0)
+            cbs.append(cb)
+            ccs.append(cc)
+            continue
         cb, cc = np.empty_like(E), np.empty((K,), np.float32)
         lib().orc_codebook_prepare_gen(Ep, ctypes.c_int64(K), ctypes.c_int(D), ctypes.c_int(int(normalize_l0 and i == 0)), vp(cb), vp(cc))
         cbs.append(cb)
@@ -116,5 +121,5 @@ def rq_forward_gen(y, codebooks, normalize_input, normalize_l0, mode, training, 
     loss = np.empty((B,), np.float32)
     lib().orc_rq_forward_gen(yp, ctypes.c_int64(B), ctypes.c_int(D), ctypes.c_int(int(normalize_input)), ctypes.c_int(L), ctypes.c_int64(K),
                              _ptr_array(cbs), _ptr_array(ccs), ctypes.c_int(mode), ctypes.c_int(int(training)), ctypes.c_float(beta),
-                             vp(z), vp(ids), vp(emb_cat), vp(emb_sum), vp(res_cat), vp(loss))
+                             vp(z), vp(ids), vp(emb_cat), vp(emb_sum), vp(res_cat), vp(loss), ctypes.c_int(int(cosine)))
     return dict(z=z, ids=ids, emb_cat=emb_cat, emb_sum=emb_sum, res_cat=res_cat, loss=loss, cbs=cbs, ccs=ccs)

@@ -166,8 +166,13 @@ def rotation_out(x, e):
     return x - 2 * xw * w + 2 * xu * q
 
 
-def quantize_level(x, cb, mode, beta, training, temperature, rand):
-    dist = distances(x, cb)
+def cosine_distances(x, cb):
+    # quantize.py:115-119: -(x / |x|) c^T / |c|, no epsilons
+    return -((x / x.norm(dim=1, keepdim=True)) @ cb.T / cb.T.norm(dim=0, keepdim=True))
+
+
+def quantize_level(x, cb, mode, beta, training, temperature, rand, cosine=False):
+    dist = cosine_distances(x, cb) if cosine else distances(x, cb)
     ids = dist.detach().min(dim=1).indices  # first minimum on CPU
     if training:
         if mode == GUMBEL:

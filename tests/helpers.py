@@ -17,7 +17,9 @@ def case_names(kind="case"):
         n = os.path.basename(p)[:-4]
         if kind == "rqvae" and n.startswith("rqvae"):
             out.append(n)
-        elif kind == "case" and not n.startswith(("kmeans", "train", "rqvae", "tokenizer")):
+        elif kind == "quantize" and n.startswith("quantize"):
+            out.append(n)
+        elif kind == "case" and not n.startswith(("kmeans", "train", "rqvae", "tokenizer", "quantize")):
             out.append(n)
         elif kind == "kmeans" and n.startswith("kmeans"):
             out.append(n)
@@ -30,6 +32,15 @@ def load(name):
     fx = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
     desc = json.loads(str(fx["desc"]))
     return fx, desc
+
+
+def quantize_inputs(desc):
+    """inputs of the stand-alone Quantize fixtures (the same formulas as tests/golden/make_golden_quantize.py inputs())"""
+    from oracle import fill
+    B, D, K, seed = desc["B"], desc["D"], desc["K"], desc["seed"]
+    x = fill.gauss((B, D), seed)
+    E = (fill.uniform((K, D), seed + 1, -1, 1) * fill.uniform((K, 1), seed + 2, 0.2, 1.5)).astype(np.float32)
+    return x, E, fill.uniform((B, D), seed + 3, -1, 1), fill.uniform((B,), seed + 4, 0.1, 1.0)
 
 
 def cfg_of(desc):

@@ -31,6 +31,30 @@ def test_exact_oracle_matches_reference(name):
         assert H.rel_err(np.linalg.norm(emb, axis=1), fx["embs_norm"]) <= 1e-5
 
 
+@pytest.mark.parametrize("name", H.case_names("quantize"))
+def test_cosine_ranking_matches_the_reference_quantize_level(name):
+    """QuantizeDistance.COSINE (reference modules/quantize.py:115-119) on ONE level: ORDER-GEN with the cosine ranking and the torch
+    restatement against the reference's own outputs."""
+    import torch
+    fx, d = H.load(name)
+    x, E, g_out, g_loss = H.quantize_inputs(d)
+    assert (fx["margins"] > 1e-6).all()
+    r = exact.rq_forward(x, [E], False, d["normalize"], d["mode"], d["training"], d["beta"], cosine=True)
+    assert np.array_equal(r["ids"][:, 0], fx["ids"].astype(np.int64))
+    assert H.rel_err(r["emb_cat"], fx["embeddings"]) <= 1e-5
+    assert H.rel_err(r["loss"], fx["loss"]) <= 1e-5
+    xt = torch.from_numpy(x).requires_grad_(d["training"])
+    Et = torch.from_numpy(E).requires_grad_(d["training"])
+    cb = torch.nn.functional.normalize(Et, dim=-1, eps=1e-12) if d["normalize"] else Et
+    out, ids, loss, _ = O.quantize_level(xt, cb, d["mode"], d["beta"], d["training"], 0.2, None, cosine=True)
+    assert np.array_equal(ids.numpy(), fx["ids"].astype(np.int64))
+    assert H.rel_err(out.detach().numpy(), fx["embeddings"]) <= 1e-5
+    if d["training"]:
+        ((out * torch.from_numpy(g_out)).sum() + (loss * torch.from_numpy(g_loss)).sum()).backward()
+        assert H.close(xt.grad.numpy(), fx["grad_x"], 2e-5, 1e-7)
+        assert H.close(Et.grad.numpy(), fx["grad_E"], 2e-5, 1e-7)
+
+
 def test_own_exp_is_accurate():
     xs = np.linspace(-80, 80, 4001).astype(np.float32)
     got = np.array([exact.lib().orc_exp(float(v)) for v in xs], dtype=np.float64)

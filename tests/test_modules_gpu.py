@@ -259,3 +259,37 @@ def test_layernorm_backward_split_at_its_seam(M, N, relu, in_gate):
     assert torch.equal(gg1, gg0 + 3.0) and torch.equal(gb1, gb0 - 2.0)
     _, wg, wb = _C.layernorm_bwd_all(ogy, other, torch.ones(40, device="cuda"), torch.zeros(40, device="cuda"), om, orr, False, None, 1.0)
     assert torch.equal(ogg, wg) and torch.equal(ogb, wb)
+
+
+@pytest.mark.parametrize("name", H.case_names("quantize"))
+def test_quantize_level_with_the_cosine_ranking_matches_the_reference(name):
+    """Quantize(distance_mode=COSINE) on its own (reference modules/quantize.py:115-119): ids bit-exact, embeddings / loss / both
+    gradients against the reference's own run; the launch itself bit for bit against ORDER-GEN of oracle/exact.c."""
+    from hidvae_amd import _C
+    from hidvae_amd.modules.quantize import Quantize, QuantizeDistance, QuantizeForwardMode
+    from oracle import exact
+    fx, d = H.load(name)
+    x, E, g_out, g_loss = H.quantize_inputs(d)
+    q = Quantize(embed_dim=d["D"], n_embed=d["K"], do_kmeans_init=False, codebook_normalize=d["normalize"], commitment_weight=d["beta"],
+                 forward_mode=QuantizeForwardMode(d["mode"]), distance_mode=QuantizeDistance.COSINE).cuda()
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(E))
+    q.train(d["training"])
+    xt = torch.from_numpy(x).cuda().requires_grad_(d["training"])
+    out = q(xt, temperature=0.2)
+    assert np.array_equal(out.ids.cpu().numpy(), fx["ids"].astype(np.int64))
+    assert H.rel_err(out.embeddings.detach().cpu().numpy(), fx["embeddings"]) <= 1e-5
+    assert H.rel_err(out.loss.detach().cpu().numpy(), fx["loss"]) <= 1e-5
+    if d["training"]:
+        ((out.embeddings * torch.from_numpy(g_out).cuda()).sum() + (out.loss * torch.from_numpy(g_loss).cuda()).sum()).backward()
+        assert H.close(xt.grad.cpu().numpy(), fx["grad_x"], 2e-5, 1e-7)
+        assert H.close(q.embedding.weight.grad.cpu().numpy(), fx["grad_E"], 2e-5, 1e-7)
+    want = exact.rq_forward(x, [E], False, d["normalize"], d["mode"], d["training"], d["beta"], cosine=True)
+    cb, cc = _C.codebook_prepare([torch.from_numpy(E).cuda()], [d["normalize"]])
+    _, ids, emb_cat, _, _, qloss = _C.rq_forward(torch.from_numpy(x).cuda(), cb, cc, False, d["mode"], d["training"], d["beta"],
+                                                 distance=_C.DIST_COSINE)
+    assert np.array_equal(ids.cpu().numpy(), want["ids"])
+    assert np.array_equal(emb_cat.cpu().numpy(), want["emb_cat"])
+    assert np.array_equal(qloss.cpu().numpy(), want["loss"])
+    with pytest.raises(NotImplementedError):
+        Quantize(embed_dim=32, n_embed=8, distance_mode=QuantizeDistance.COSINE)  # (GUMBEL_SOFTMAX is the ctor default)
