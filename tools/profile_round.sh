@@ -29,6 +29,11 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 note "pass sq done"
 rocprofv3 --kernel-trace --pmc TCC_REQ_sum TCC_READ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- python3 $R/tools/profile_kernels.py > $OUT/tcc.log 2>&1
 note "pass tcc done"
+# L1 / texture-addresser passes, at most 2 counters each (a wider TCP/TA pass aborted inside rocprofv3 with signal 6 in round 2): the logs are kept either way
+rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/tcp -- python3 $R/tools/profile_kernels.py > $OUT/${TAG}_tcp_pass.log 2>&1 && python3 $R/tools/pmc_table.py $OUT/tcp > $OUT/${TAG}_quoted_kernels_pmc_tcp.csv || note "tcp pass failed (see ${TAG}_tcp_pass.log)"
+note "pass tcp done"
+rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr --output-format csv -d $OUT/ta -- python3 $R/tools/profile_kernels.py > $OUT/${TAG}_ta_pass.log 2>&1 && python3 $R/tools/pmc_table.py $OUT/ta > $OUT/${TAG}_quoted_kernels_pmc_ta.csv || note "ta pass failed (see ${TAG}_ta_pass.log)"
+note "pass ta done"
 # fold into small CSVs (the raw traces are large)
 python3 $R/tools/pmc_summary.py $OUT/fetch $OUT/write > $OUT/${TAG}_quoted_kernels_pmc_hbm_traffic.csv
 python3 $R/tools/pmc_table.py $OUT/sq > $OUT/${TAG}_quoted_kernels_pmc_sq.csv
@@ -38,5 +43,5 @@ for d in step step_tagged step_config3 step_config4 step_config5 quoted; do
   cp "$f" $OUT/${TAG}_${d}_kernel_stats.csv
 done
 # keep only the folded files in the merge-back (<= 64 MiB)
-rm -rf $OUT/step $OUT/step_tagged $OUT/step_config3 $OUT/step_config4 $OUT/step_config5 $OUT/quoted $OUT/fetch $OUT/write $OUT/sq $OUT/tcc
+rm -rf $OUT/step $OUT/step_tagged $OUT/step_config3 $OUT/step_config4 $OUT/step_config5 $OUT/quoted $OUT/fetch $OUT/write $OUT/sq $OUT/tcc $OUT/tcp $OUT/ta
 ls -la $OUT
