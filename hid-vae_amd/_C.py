@@ -25,7 +25,7 @@ _vp, _i, _i64, _f, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.
 _SIGNATURES = {
     "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _vp, _u32, _u32, _i, _vp, _i, _vp],
     "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _f, _vp, _i, _vp, _vp],
-    "hidvae_layernorm_bwd_partial": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _f, _vp, _vp, _vp],
+    "hidvae_layernorm_bwd_partial": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_layernorm_param_final_many": [_vp, _i, _vp],
     "hidvae_gate_fwd": [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_gate_bwd": [_vp, _i64, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -71,7 +71,7 @@ _SIGNATURES = {
     "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _vp],
     "hidvae_cat_recon_rows": [_vp, _i64, _vp, _i64, _i64, _i64, _i, _vp, _i64, _vp, _vp, _vp],
     "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
+    "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _f, _vp],
     "hidvae_padded_to_jagged": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp],
     "hidvae_jagged_to_padded": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
     "hidvae_codebook_prepare_adamw": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _i, _vp],
@@ -770,14 +770,14 @@ def loss_fwd(y, x, qloss, aligns, preds, accs, tag_div, ids, z, uniq_weight, uni
     return loss, recon, uniq, g_rows, tagstats, summary
 
 
-def loss_bwd(g_loss, y, x, L, w_a, w_p, w_u, g_rows, want_gz, embed_dim=EMBED_DIM, n_cat=0):
+def loss_bwd(g_loss, y, x, L, w_a, w_p, w_u, g_rows, want_gz, embed_dim=EMBED_DIM, n_cat=0, expect_g=0.0):
     B, N = y.shape
     scal = torch.empty((3,), device=y.device, dtype=torch.float32)
     g_y = torch.empty_like(y)
     D = g_rows.shape[1] if g_rows is not None else int(embed_dim)
     g_z = torch.empty((B, D), device=y.device, dtype=torch.float32) if want_gz else None
     _check(lib().hidvae_loss_bwd(_p(g_loss), _p(y), _p(x), B, N, _n_cat(n_cat, N), L, float(w_a), float(w_p), float(w_u), _p(g_rows), _p(g_y), _p(scal), _p(g_z),
-                                 int(D), _stream()), "hidvae_loss_bwd")
+                                 int(D), float(expect_g), _stream()), "hidvae_loss_bwd")
     return g_y, scal, g_z
 
 
@@ -854,17 +854,21 @@ def layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, mask, mask_scale, ne
     return gx, gg, gb
 
 
-def layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y_out, keep_scale, in_relu_scale=0.0, need_gx=True):
+def layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y_out, keep_scale, in_relu_scale=0.0, need_gx=True, gy2=None, want_sum=False):
     """LayerNorm backward up to its seam: -> (gx or None, partials).  The affine gradients follow from `partials` in
     layernorm_param_final_many (one launch for many LayerNorms).  y_out: the forward output (ReLU -> Dropout gate, no mask needed);
-    in_relu_scale != 0: gx is returned already taken through the ReLU -> Dropout that produced the LayerNorm's input."""
+    in_relu_scale != 0: gx is returned already taken through the ReLU -> Dropout that produced the LayerNorm's input.
+    gy2: a second gradient of the same output, added on the way in; want_sum: -> (gx, partials, gy + gy2)."""
     M, N = x.shape
+    if gy2 is not None and (gy2.shape != gy.shape or not gy2.is_contiguous()):
+        raise RuntimeError(f"layernorm_bwd_partial: gy2 {tuple(gy2.shape)} vs gy {tuple(gy.shape)}")
     gx = torch.empty((M, N), device=x.device, dtype=torch.float32) if need_gx else None
+    gsum = torch.empty((M, N), device=x.device, dtype=torch.float32) if want_sum else None
     part = _ws(WS_LAYERNORM_BWD_ALL, x.device, M, N)
     _check(lib().hidvae_layernorm_bwd_partial(_p(gy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), M, N, int(relu), _p(y_out),
-                                              float(keep_scale), float(in_relu_scale), _p(gx), _p(part), _stream()),
+                                              float(keep_scale), float(in_relu_scale), _p(gy2), _p(gsum), _p(gx), _p(part), _stream()),
            "hidvae_layernorm_bwd_partial")
-    return gx, part
+    return (gx, part, gsum) if want_sum else (gx, part)
 
 
 class LnFinal(ctypes.Structure):  # hidvae_ln_final

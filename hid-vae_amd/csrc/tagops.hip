@@ -209,7 +209,11 @@ constexpr int LNF_ROWS = 4, LNF_NV = 16;  // one row per wave: rows in flight, n
 __device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*red)[3][64 * LNF_NV], const float *gy, const float *x,
                                                          const float *gamma, const float *beta, const float *mean, const float *rstd,
                                                          int64_t M, int64_t N, int relu, const float *mask, float scale, float *gx,
-                                                         float *part, const float *yout = nullptr, float in_relu_scale = 0.0f) {
+                                                         float *part, const float *yout = nullptr, float in_relu_scale = 0.0f,
+                                                         const float *gy2 = nullptr, float *gsum = nullptr) {
+    // gy2 (optional): a second gradient of the same output, added on the way in (the residual path of TagPredictor's blocks,
+    //   h_rqvae.py:165-186: f_{n+1} = LN(..) + f_n hands f_n's producer two gradients); gsum (optional): that sum, written out for the
+    //   next residual hop
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ga[LNF_NV], be[LNF_NV], sg[LNF_NV], sb[LNF_NV];
 #pragma unroll
@@ -237,6 +241,8 @@ __device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*re
                 if (xraw > 0.0f) xpos |= 1u << j;
                 xh[j] = (xraw - mu) * rs;
                 float gv = gy[row * N + c];
+                if (gy2 != nullptr) gv += gy2[row * N + c];
+                if (gsum != nullptr) gsum[row * N + c] = gv;
                 if (yout != nullptr) {
                     if (relu) gv = yout[row * N + c] > 0.0f ? gv * scale : 0.0f;
                 } else {
@@ -288,9 +294,10 @@ __device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*re
 __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *gy, const float *x, const float *gamma, const float *beta,
                                                                   const float *mean, const float *rstd, int64_t M, int64_t N, int relu,
                                                                   const float *mask, float scale, float *gx, float *part,
-                                                                  const float *yout, float in_relu_scale) {
+                                                                  const float *yout, float in_relu_scale, const float *gy2, float *gsum) {
     __shared__ float red[2][3][64 * LNF_NV];
-    layernorm_bwd_fused_body((int64_t)blockIdx.x, red, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, part, yout, in_relu_scale);
+    layernorm_bwd_fused_body((int64_t)blockIdx.x, red, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, part, yout, in_relu_scale,
+                             gy2, gsum);
 }
 // 32 columns x 32 chunk groups per workgroup: group q adds chunks q, q+32, ... in ascending order, then the groups are added
 // in ascending order (the fused backward leaves one partial per 4 rows, so depth matters more than work here)
@@ -1051,7 +1058,7 @@ extern "C" int hidvae_layernorm_bwd_all(const float *gy, const float *x, const f
     const int64_t chunks = hv_cdiv(M, LNF_ROWS);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(layernorm_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 0, s, gy, x, gamma, beta, mean, rstd, M, N, relu,
-                       keep_mask, keep_scale, gx, workspace, (const float *)nullptr, 0.0f);
+                       keep_mask, keep_scale, gx, workspace, (const float *)nullptr, 0.0f, (const float *)nullptr, (float *)nullptr);
     HV_LAUNCH_CHECK("layernorm_bwd_fused");
     hipLaunchKernelGGL(layernorm_param_final_kernel, dim3((unsigned)hv_cdiv(N, 32)), dim3(1024), 0, s, workspace, chunks, N, ggamma,
                        gbeta, accumulate);
@@ -1061,13 +1068,13 @@ extern "C" int hidvae_layernorm_bwd_all(const float *gy, const float *x, const f
 
 extern "C" int hidvae_layernorm_bwd_partial(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
                                             const float *rstd, int64_t M, int64_t N, int relu, const float *y_out, float keep_scale,
-                                            float in_relu_scale, float *gx, float *partials, void *stream) {
+                                            float in_relu_scale, const float *gy2, float *gsum, float *gx, float *partials, void *stream) {
     HV_REQUIRE(gy && x && gamma && beta && mean && rstd && partials && M >= 1 && N >= 1, "layernorm_bwd_partial: bad arguments");
     HV_REQUIRE(N <= 64 * LNF_NV, "layernorm_bwd_partial: N=%lld exceeds the register-resident form (%d)", (long long)N, 64 * LNF_NV);
     HV_REQUIRE(!relu || y_out != nullptr, "layernorm_bwd_partial: the ReLU gate is read off the forward output");
     const int64_t chunks = hv_cdiv(M, LNF_ROWS);
     hipLaunchKernelGGL(layernorm_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, gy, x, gamma, beta, mean, rstd,
-                       M, N, relu, (const float *)nullptr, keep_scale, gx, partials, y_out, in_relu_scale);
+                       M, N, relu, (const float *)nullptr, keep_scale, gx, partials, y_out, in_relu_scale, gy2, gsum);
     HV_LAUNCH_CHECK("layernorm_bwd_partial");
     return HIDVAE_OK;
 }

@@ -260,7 +260,7 @@ class HRqVae(nn.Module, _HubMixin):
             for i in pending:
                 tabs = [t.detach() for t in self._tables()[: i + 1]]
                 out = RQFn.apply(y.detach(), normalize_input, self._fused_mode(), self.training, self.commitment_weight,
-                                 self._normalize_flags()[: i + 1], True, None, *tabs)
+                                 self._normalize_flags()[: i + 1], True, None, None, *tabs)
                 res = out[5][:, i * self.embed_dim:(i + 1) * self.embed_dim].contiguous()
                 self.layers[i]._kmeans_init(res)
 
@@ -306,11 +306,12 @@ class HRqVae(nn.Module, _HubMixin):
             from ..gumbel_path import gumbel_all_levels
             return gumbel_all_levels(self, y, normalize_input)
         return RQFn.apply(y.contiguous(), normalize_input, self._fused_mode(), self.training, self.commitment_weight,
-                          self._normalize_flags(), want_res, getattr(self, "_prepared", None), *self._tables())
+                          self._normalize_flags(), want_res, getattr(self, "_prepared", None), getattr(self, "_heads_port", None),
+                          *self._tables())
 
-    def _tag_heads(self, emb_cat, tags_emb, tags_indices, defer_join=False):
+    def _tag_heads(self, emb_cat, tags_emb, tags_indices, defer_join=False, port=None, loss_grad=None):
         from ..tagpath import tag_heads_forward
-        return tag_heads_forward(self, emb_cat, tags_emb, tags_indices, defer_join=defer_join)
+        return tag_heads_forward(self, emb_cat, tags_emb, tags_indices, defer_join=defer_join, port=port, loss_grad=loss_grad)
 
     def get_semantic_ids(self, encoded_x: Tensor, tags_emb: Optional[Tensor] = None, tags_indices: Optional[Tensor] = None,
                          gumbel_t: float = 0.001) -> HRqVaeOutput:
@@ -368,6 +369,17 @@ class HRqVae(nn.Module, _HubMixin):
         # the backward still runs (see _cut_here / backward_rest)
         self._cutting = bool(getattr(self, "dp_cut", False)) and self.training and torch.is_grad_enabled()
         self._cut_pairs = [] if self._cutting else None
+        # loss_grad_hint (set by the training loop: the gradient it will hand loss.backward, 1 / gradient_accumulate_every): the tag heads
+        # then run their backward right after their forward, on their own streams (tagpath.HeadsGradPort); None = everything waits for
+        # loss.backward().  The hint is checked against the real gradient inside the loss backward launch (a mismatch poisons the step).
+        hint = getattr(self, "loss_grad_hint", None)
+        early_heads = (tagged and hint is not None and self.training and torch.is_grad_enabled() and x.dim() == 2
+                       and self.codebook_mode != QuantizeForwardMode.GUMBEL_SOFTMAX)  # (the Gumbel path differentiates emb_cat through autograd)
+        if early_heads:
+            from ..tagpath import HeadsGradPort
+            self._heads_port = HeadsGradPort((x.shape[0], self.n_layers * self.embed_dim))
+        else:
+            self._heads_port = None
         y_dec = None
         embs_norm = p_unique = None  # (the fused middle launch produces them itself when it can)
         fused = self._bottleneck_ok(x)
@@ -379,7 +391,8 @@ class HRqVae(nn.Module, _HubMixin):
             pre1, h1 = MLPFrontFn.apply(x, *We[:-2])
             z, ids, emb_cat, emb_sum, qloss, pre_d1, d1, embs_norm, p_unique = BottleneckFn.apply(
                 pre1, h1, We[-2], We[-1], Wd[0], Wd[1], self.codebook_normalize, self._fused_mode(), self.commitment_weight,
-                self._normalize_flags(), self._prepared, (lambda: self._census("fused", x.shape[0], x.device)), *self._tables())
+                self._normalize_flags(), self._prepared, (lambda: self._census("fused", x.shape[0], x.device)), self._heads_port,
+                *self._tables())
         else:
             y = self.encoder.body(x)  # the encoder's l2norm (codebook_normalize) happens in the RQ prologue
             z, ids, emb_cat, emb_sum, qloss, _ = self._quantize_all(y, self.codebook_normalize, False)
@@ -391,7 +404,9 @@ class HRqVae(nn.Module, _HubMixin):
         # deferred to just before the loss launch
         tag_scalars, tag_join = (), None
         if tagged:
-            tag_scalars, tag_join = self._tag_heads(emb_cat, tags_emb.float(), tags_indices, defer_join=True)  # (A_0.., P_0.., acc_0..)
+            tag_scalars, tag_join = self._tag_heads(emb_cat, tags_emb.float(), tags_indices, defer_join=True, port=self._heads_port,
+                                                    loss_grad=hint if early_heads else None)  # (A_0.., P_0.., acc_0..)
+        self._heads_port = None
         if fused:
             dec_in = self._cut_here(pre_d1)
             y_dec = MLPBackFn.apply(dec_in, d1, *Wd[2:])
@@ -425,7 +440,8 @@ class HRqVae(nn.Module, _HubMixin):
         loss, recon, uniq, stats, summary = StepLossFn.apply(y_dec, x, qloss, z, ids, self.sem_id_uniqueness_loss.weight,
                                                     self.sem_id_uniqueness_loss.margin, self.tag_alignment_weight,
                                                     self.tag_prediction_weight, self.sem_id_uniqueness_weight, n_tag,
-                                                    float(self.n_layers), int(self.n_cat_feats), *tag_scalars)
+                                                    float(self.n_layers),
+                                                    (int(self.n_cat_feats), float(hint)) if early_heads else int(self.n_cat_feats), *tag_scalars)
         main.wait_stream(side)  # the statistics above were computed beside the decoder
         _C.phase_mark("fwd:loss done")
         self.last_summary = summary  # device [6]: loss, mean recon, mean rqvae, tag align, tag pred, tag accuracy (training log row)

@@ -88,5 +88,5 @@ class Quantize(nn.Module):
         if self.distance_mode == QuantizeDistance.COSINE:  # -(x/|x| . c)/|c| ranks the codes (quantize.py:115-119); all else as L2
             mode = (mode, _C.DIST_COSINE)
         _, ids, emb_cat, _, qloss, _ = RQFn.apply(x.contiguous(), False, mode, self.training, self.quantize_loss.commitment_weight,
-                                                  (self.codebook_normalize,), False, None, self.table())
+                                                  (self.codebook_normalize,), False, None, None, self.table())
         return QuantizeOutput(embeddings=emb_cat, ids=ids[:, 0], loss=qloss)

@@ -174,8 +174,9 @@ class BottleneckFn(Function):
              embs_norm, p_unique (the debug statistics of h_rqvae.py:643-648 when the launch can carry the id census, else None)"""
 
     @staticmethod
-    def forward(ctx, pre1, h1, W2, W3, Wd0, Wd1, normalize_input, mode, beta, normalize_flags, prepared, scratch, *tables):
+    def forward(ctx, pre1, h1, W2, W3, Wd0, Wd1, normalize_input, mode, beta, normalize_flags, prepared, scratch, port, *tables):
         ctx.set_materialize_grads(False)
+        ctx.port = port  # tagpath.HeadsGradPort or None: where emb_cat's gradient waits when the heads ran their own backward early
         if prepared is not None:
             cb, cc = prepared
             join_side()
@@ -209,6 +210,8 @@ class BottleneckFn(Function):
             gWd0, g_sum = _C.linear_bwd(g_pre_d0, emb_sum, Wd0, True, dW=dst, accumulate=acc)
             if dst is not None:
                 gWd0 = None
+        if g_cat is None and ctx.port is not None:
+            g_cat = ctx.port.collect()
         g_cat = g_cat.contiguous() if g_cat is not None else None
         g_z = g_z.contiguous() if g_z is not None else None
         g_y, dE = _C.rq_backward(y, z, cb, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z, 1.0 if g_q is not None else 0.0, g_q)
@@ -228,7 +231,7 @@ class BottleneckFn(Function):
         gW2, g_pre1 = _C.linear_bwd(g_pre2, h1, W2, ctx.needs_input_grad[0], _C.EPI_DSILU, pre1, dW=dst, accumulate=acc)
         if dst is not None:
             gW2 = None
-        return (g_pre1, None, gW2, gW3, gWd0, gWd1, None, None, None, None, None, None) + tuple(gE)
+        return (g_pre1, None, gW2, gW3, gWd0, gWd1, None, None, None, None, None, None, None) + tuple(gE)
 
 
 class L2NormFn(Function):
@@ -257,8 +260,9 @@ class RQFn(Function):
     outputs: z, ids (int64, non-differentiable), emb_cat [B,L*32], emb_sum [B,32], qloss [B], res_cat"""
 
     @staticmethod
-    def forward(ctx, y, normalize_input, mode, training, beta, normalize_flags, want_res, prepared, *tables):
+    def forward(ctx, y, normalize_input, mode, training, beta, normalize_flags, want_res, prepared, port, *tables):
         ctx.set_materialize_grads(False)
+        ctx.port = port  # tagpath.HeadsGradPort or None (see BottleneckFn)
         distance = _C.DIST_L2
         if isinstance(mode, tuple):  # (forward mode, distance): Quantize on its own with QuantizeDistance.COSINE (quantize.py:115-119)
             mode, distance = mode
@@ -287,6 +291,8 @@ class RQFn(Function):
         if not training:
             raise RuntimeError("the eval branch of Quantize (o = codebook[ids]) is not differentiated on the fused path")
         y, z, ids, cb, cc = ctx.saved_tensors
+        if g_cat is None and ctx.port is not None:
+            g_cat = ctx.port.collect()
         if g_cat is not None:
             g_cat = g_cat.contiguous()
         if g_sum is not None:
@@ -312,7 +318,7 @@ class RQFn(Function):
             if t is not None:
                 t.record_stream(main)
         _join_after_backward()
-        return (g_y, None, None, None, None, None, None, None) + tuple(gE)
+        return (g_y, None, None, None, None, None, None, None, None) + tuple(gE)
 
 
 class ReconFn(Function):
@@ -396,6 +402,9 @@ class StepLossFn(Function):
     @staticmethod
     def forward(ctx, y, x, qloss, z, ids, uniq_weight, uniq_margin, w_a, w_p, w_u, n_tag, tag_div, n_cat, *tag_scalars):
         ctx.set_materialize_grads(False)
+        ctx.expect_g = 0.0
+        if isinstance(n_cat, tuple):  # (n_cat, the loss gradient the tag heads' early backward was seeded with: checked in the backward launch)
+            n_cat, ctx.expect_g = n_cat
         ctx.n_cat = n_cat
         want = z is not None and ctx.needs_input_grad[3]
         aligns, preds, accs = list(tag_scalars[:n_tag]), list(tag_scalars[n_tag:2 * n_tag]), list(tag_scalars[2 * n_tag:3 * n_tag])
@@ -417,7 +426,7 @@ class StepLossFn(Function):
             return (None,) * (13 + 3 * n_tag)
         y, x = ctx.saved_tensors
         g_y, scal, g_z = _C.loss_bwd(g.contiguous(), y, x, L, w_a / tag_div, w_p / tag_div, w_u, ctx.g_rows,
-                                     want_gz=has_z and ctx.g_rows is not None, n_cat=ctx.n_cat)
+                                     want_gz=has_z and ctx.g_rows is not None, n_cat=ctx.n_cat, expect_g=ctx.expect_g)
         per_item = scal[0].expand(B)  # stride-0 view: the kernels downstream read one device scalar
         tags = (scal[1],) * n_tag + (scal[2],) * n_tag + (None,) * n_tag
         return (g_y, None, per_item, g_z, None, None, None, None, None, None, None, None, None) + tags

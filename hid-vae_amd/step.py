@@ -55,6 +55,10 @@ class GraphedTrainStep:
         self.overlap = overlap
         self.graphs = None
         self.in_graph = False  # True once the collectives were captured inside the (single) step graph
+        # the gradient every micro-batch's loss receives below (total.backward(gradient=1) through loss / ga): announced to the model so
+        # the tag heads can run their backward right after their forward (HRqVae.loss_grad_hint; HIDVAE_EARLY_HEADS=0 turns it off)
+        if self.tagged and hasattr(model, "n_layers") and os.environ.get("HIDVAE_EARLY_HEADS", "1") != "0":
+            model.loss_grad_hint = float(torch.tensor(1.0, dtype=torch.float32) / self.ga) if self.ga > 1 else 1.0
 
     # -- the step, as plain code (this is what gets captured)
     def _overlapped(self):
@@ -142,6 +146,9 @@ class GraphedTrainStep:
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self._part1()
+                if self.tagged:  # the heads' early backward runs on the level streams: this graph ends here, so they join here
+                    from .tagpath import join_tag_streams
+                    join_tag_streams(self.static[0].x.device)
             with torch.cuda.graph(g2, pool=g1.pool()):
                 self._part2()
             self.opt.grad_scale = 1.0 / self.dp.world

@@ -42,6 +42,58 @@ class ConcatViewsFn(Function):
         return _C.sum_prefix_slices(live, ctx.shape[0], ctx.shape[1]), None, None, None
 
 
+class HeadsGradPort:
+    """Where d loss / d emb_cat waits when the tag heads ran their own backward EARLY (tag_heads_forward with loss_grad): every level's
+    branch runs forward and then straight on into its backward on its own stream, seeded with the loss gradient the caller announced
+    (HRqVae.loss_grad_hint), instead of idling until the decoder, the loss launch and the start of loss.backward() have gone by on the
+    caller's stream.  The heads read emb_cat through detached leaf views; their gradients stay here until the quantiser's backward
+    (ops.RQFn / ops.BottleneckFn) asks for them: collect() joins the level streams into the current one and folds the leaves' gradients
+    into one [B, L*D] tensor in ONE launch -- the launch ConcatViewsFn.backward issues on the ordinary path, same operands, same order."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+        self.leaves, self.streams = [], []
+
+    def collect(self):
+        main = torch.cuda.current_stream()
+        capturing = torch.cuda.is_current_stream_capturing()
+        for st in self.streams:
+            if st is None:
+                continue
+            if capturing:
+                with torch.cuda.stream(st):
+                    if not torch.cuda.is_current_stream_capturing():
+                        continue  # a graph of its own for this half of the backward: the level streams were joined at the end of the previous one
+            main.wait_stream(st)
+        live = []
+        for leaf in self.leaves:
+            g, leaf.grad = leaf.grad, None
+            if g is not None:
+                g = g.contiguous()
+                g.record_stream(main)
+                live.append(g)
+        self.leaves, self.streams = [], []
+        if not live:
+            return None
+        _C.phase_mark("bwd:heads joined (port)")
+        return _C.sum_prefix_slices(live, self.shape[0], self.shape[1])
+
+
+def _loss_seeds(model, g, device):
+    """the gradients loss.backward(g) hands the per-level alignment / prediction scalars: g * w_a / L and g * w_p / L in float32, exactly
+    what hidvae_loss_bwd computes (ops.StepLossFn.backward); device scalars built once per (g, weights) -- before any graph capture"""
+    L = float(model.n_layers)
+    key = (float(g), float(model.tag_alignment_weight), float(model.tag_prediction_weight), L, str(device))
+    cache = model.__dict__.setdefault("_seed_cache", {})
+    if key not in cache:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("tag heads: the loss-gradient seeds must exist before a graph capture (run one eager step first)")
+        g32 = np.float32(g)
+        cache[key] = (torch.tensor(float(g32 * np.float32(model.tag_alignment_weight / L)), dtype=torch.float32, device=device),
+                      torch.tensor(float(g32 * np.float32(model.tag_prediction_weight / L)), dtype=torch.float32, device=device))
+    return cache[key]
+
+
 class MulFn(Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -126,6 +178,17 @@ def flush_layernorm_finals():
             _C.layernorm_param_final_many(launch)
 
 
+class ResidualLink:
+    """The gradient of a residual connection f_{n+1} = LN(..) + f_n, carried beside autograd: the LayerNorm that consumes f_n as its
+    residual (`res_link`) leaves the gradient of its output here, and the LayerNorm that PRODUCED f_n (`extra_grad`) adds it to the one
+    autograd hands it inside its backward launch (gy2 of hidvae_layernorm_bwd_partial).  The residual input itself enters detached, so
+    autograd never sees f_n's second consumer and never issues the add."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
 class LayerNormFn(Function):
     """y = dropout(relu?(LayerNorm(x))) + residual in one launch.
     Backward: ONE launch for gx and the per-4-row partial sums of (d gamma, d beta); the partials of all LayerNorms of a backward pass
@@ -135,27 +198,37 @@ class LayerNormFn(Function):
     LayerNorm as its only consumer, and gx is returned already taken through that gate (that Linear is built with act_bwd_done)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, mask, mask_scale, residual, in_relu_scale=0.0):
+    def forward(ctx, x, gamma, beta, eps, relu, mask, mask_scale, residual, in_relu_scale=0.0, res_link=None, extra_grad=None):
         ctx.set_materialize_grads(False)
         y, mean, rstd = _C.layernorm_fwd(x, gamma, beta, eps, relu, mask, mask_scale, residual)
         ctx.save_for_backward(x, gamma, beta, mean, rstd, y if relu else None)
         ctx.cfg = (relu, float(mask_scale) if mask is not None else 1.0, residual is not None, float(in_relu_scale))
         ctx.gamma_param, ctx.beta_param = gamma, beta
+        ctx.res_link, ctx.extra_grad = res_link, extra_grad  # (ResidualLink: the residual's gradient travels beside autograd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         if gy is None:
-            return (None,) * 9
+            return (None,) * 11
         x, gamma, beta, mean, rstd, y = ctx.saved_tensors
         relu, scale, has_res, in_relu_scale = ctx.cfg
         gy = gy.contiguous()
+        gy2 = None
+        if ctx.extra_grad is not None:  # this output also fed a residual connection: its gradient waits in the link
+            gy2, ctx.extra_grad.g = ctx.extra_grad.g, None
+        link = ctx.res_link
+        res_grad = gy if (has_res and link is None) else None  # (with a link the residual input was detached)
         if x.shape[1] > 1024:  # rows too wide for the register-resident kernel: the two-launch form, gradients through autograd
             from .ops import grad_sink
             gdst, gacc = grad_sink(ctx.gamma_param)
             bdst, bacc = grad_sink(ctx.beta_param)
             if gdst is None or bdst is None or gacc != bacc:
                 gdst = bdst = None
+            if gy2 is not None:
+                gy = gy + gy2
+            if link is not None:
+                link.g = gy
             gate = None if y is None else (y > 0).to(x.dtype)
             gx, gg, gb = _C.layernorm_bwd_all(gy, x, gamma, beta, mean, rstd, relu, gate, scale, need_gx=ctx.needs_input_grad[0],
                                               gg=gdst, gb=bdst, accumulate=gacc)
@@ -163,13 +236,20 @@ class LayerNormFn(Function):
                 gx = _C.act_bwd(gx, x, _C.EPI_RELU, x, in_relu_scale)
             if gdst is not None:
                 gg = gb = None
-            return gx, gg, gb, None, None, None, None, (gy if has_res else None), None
-        gx, part = _C.layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y, scale, in_relu_scale, need_gx=ctx.needs_input_grad[0])
+            return gx, gg, gb, None, None, None, None, res_grad, None, None, None
+        if link is not None and gy2 is not None:
+            gx, part, link.g = _C.layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y, scale, in_relu_scale,
+                                                        need_gx=ctx.needs_input_grad[0], gy2=gy2, want_sum=True)
+        else:
+            if link is not None:
+                link.g = gy
+            gx, part = _C.layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y, scale, in_relu_scale,
+                                                need_gx=ctx.needs_input_grad[0], gy2=gy2)
         if not _LN_PENDING:
             from torch.autograd import Variable
             Variable._execution_engine.queue_callback(flush_layernorm_finals)
         _LN_PENDING.append((torch.cuda.current_stream(), part, x.shape[0], x.shape[1], ctx.gamma_param, ctx.beta_param))
-        return gx, None, None, None, None, None, None, (gy if has_res else None), None
+        return gx, None, None, None, None, None, None, res_grad, None, None, None
 
 
 class GateFn(Function):
@@ -340,12 +420,13 @@ def _mask(rand, shape, p, device, training):
     return rand.dropout_keep(shape, p, device), _keep_scale(p)
 
 
-def _lin_norm_relu_drop(x, lin, norm, p, rand, training, in_gate=None):
+def _lin_norm_relu_drop(x, lin, norm, p, rand, training, in_gate=None, extra_grad=None):
     """Linear -> (LayerNorm) -> ReLU -> Dropout as two launches (GEMM+bias, LN+ReLU+mask) or one (GEMM+bias+ReLU+mask).
-    -> (y, scale): y = relu(.) * keep * scale."""
+    -> (y, scale): y = relu(.) * keep * scale.  extra_grad: a ResidualLink whose gradient the LayerNorm's backward adds in (LayerNorm only)."""
     mask, scale = _mask(rand, (x.shape[0], lin.out_features), p, x.device, training)
     if isinstance(norm, nn.LayerNorm):
-        return LayerNormFn.apply(_lin(x, lin, dx_gate=in_gate), norm.weight, norm.bias, norm.eps, True, mask, scale, None), scale
+        return LayerNormFn.apply(_lin(x, lin, dx_gate=in_gate), norm.weight, norm.bias, norm.eps, True, mask, scale, None, 0.0, None,
+                                 extra_grad), scale
     return _lin(x, lin, _C.EPI_RELU, mask, scale, dx_gate=in_gate), scale
 
 
@@ -384,13 +465,22 @@ def tag_predictor_forward(pred, x, x_gate=None, rand=None):
             h = L2NormFn.apply(h, 1e-12)
     p = pred.dropout_p
     fe = pred.feature_extractor
-    f, _ = _lin_norm_relu_drop(h, fe[0], fe[1], p, rand, training)
-    for rb in (pred.residual_block1, pred.residual_block2):
+    blocks = (pred.residual_block1, pred.residual_block2)
+    # the residual connections' gradients travel beside autograd when every hop is a LayerNorm (ResidualLink): f_n's producer adds the
+    # gradient of f_{n+1} inside its own backward launch instead of autograd adding the two in a launch of its own (6 per step)
+    linked = (torch.is_grad_enabled() and isinstance(fe[1], nn.LayerNorm) and all(isinstance(rb[7], nn.LayerNorm) for rb in blocks)
+              and max(fe[0].out_features, *(rb[4].out_features for rb in blocks)) <= 1024)
+    link = ResidualLink() if linked else None
+    f, _ = _lin_norm_relu_drop(h, fe[0], fe[1], p, rand, training, extra_grad=link)
+    for n, rb in enumerate(blocks):
         r, _ = _lin_norm_relu_drop(f, rb[0], rb[1], p, rand, training)
         mask, scale = _mask(rand, (r.shape[0], rb[4].out_features), p, r.device, training)
         if isinstance(rb[7], nn.LayerNorm):  # Linear -> ReLU -> Dropout -> LayerNorm (+ f): the LayerNorm backward applies the gate
             r = _lin(r, rb[4], _C.EPI_RELU, mask, scale, act_bwd_done=True)
-            f = LayerNormFn.apply(r, rb[7].weight, rb[7].bias, rb[7].eps, False, None, 1.0, f, scale)  # LN(r) + f in one launch
+            nxt = ResidualLink() if (linked and n + 1 < len(blocks)) else None
+            f = LayerNormFn.apply(r, rb[7].weight, rb[7].bias, rb[7].eps, False, None, 1.0, f.detach() if linked else f, scale,
+                                  link, nxt)  # LN(r) + f in one launch
+            link = nxt
         else:
             f = AddFn.apply(f, _lin(r, rb[4], _C.EPI_RELU, mask, scale))
     cl = pred.classifier
@@ -433,6 +523,15 @@ def _tag_streams(device, n):
     return st
 
 
+def join_tag_streams(device):
+    """the current stream waits for everything queued on the tag-level streams (a graph that ends while the heads' early backward is
+    still on its own streams would end with unjoined work)"""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    main = torch.cuda.current_stream()
+    for st in _TAG_STREAMS.get(key, [None])[1:]:
+        main.wait_stream(st)
+
+
 def early_rand(rand, targets, device, n_levels, want_mixup):
     """The step's random draws need nothing from the model: the generator's step counter (one tiny launch) and the mixup pairing (one
     launch; needs only the tag indices) are issued at the START of the forward on the first tag stream, where they run beside the
@@ -460,17 +559,25 @@ def early_rand(rand, targets, device, n_levels, want_mixup):
     return True
 
 
-def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False):
+def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, port=None, loss_grad=None):
     """-> tuple (A_0..A_{L-1}, P_0..P_{L-1}, acc_0..acc_{L-1}) of 0-d device tensors.
     defer_join: -> (that tuple, join) where join() makes the caller's stream wait for the level branches; the caller issues its own
-    work (the decoder) in between, so it runs beside the branches."""
+    work (the decoder) in between, so it runs beside the branches.
+    port (HeadsGradPort) + loss_grad (the gradient the caller will hand loss.backward): every level's branch continues into its OWN
+    backward right after its forward (see HeadsGradPort); the scalars come back detached."""
     # (round 2 also carried a lockstep form with grouped launches -- 119 launches per step instead of 211 -- which was never faster
     #  than the per-level branches below, 1.96 vs 1.53 ms in round 3: one stream means the sum of the kernel times; it was removed)
     L, D = model.n_layers, model.embed_dim
     rand = model._rand()
     training = model.training
     B = emb_cat.shape[0]
-    views = ConcatViewsFn.apply(emb_cat, L, D, 2)  # two consumers per level: InfoNCE, the predictor (its gate launch covers both uses)
+    early_bwd = port is not None and loss_grad is not None and training and torch.is_grad_enabled()
+    if early_bwd:
+        base = emb_cat.detach()
+        views = tuple(base[:, : (i + 1) * D].requires_grad_() for i in range(L) for _ in range(2))  # leaf views: one per consumer
+        seed_a, seed_p = _loss_seeds(model, loss_grad, emb_cat.device)
+    else:
+        views = ConcatViewsFn.apply(emb_cat, L, D, 2)  # two consumers per level: InfoNCE, the predictor (its gate launch covers both uses)
     te = tags_emb.reshape(B, -1)  # [B, L_tags*768]: level i is the column block i (a strided view, no copy)
     E = model.tag_embed_dim
     aligns, preds, accs = [], [], []
@@ -508,6 +615,7 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False):
         if early:
             for st in branch[2:]:
                 st.wait_stream(branch[1])
+    fwd_done = []
     for i in range(L):
         st = lvl_stream(i)
         with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
@@ -519,6 +627,15 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False):
             logits = tag_predictor_forward(model.tag_predictors[i], c_att, None, rand)
             loss, acc = tag_prediction_loss(model.tag_prediction_loss, logits, tags_indices[:, i].contiguous(), 0, rand, level=i)
             _C.phase_mark(f"fwd:level {i} done")
+            if early_bwd:
+                if st is not None:  # the caller's loss launch waits for the level's FORWARD only
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    fwd_done.append(ev)
+                # (called with the level's stream current: the engine's end-of-pass synchronisation and the LayerNorm-finals callback
+                #  stay on this stream; the caller's stream never waits for this backward before HeadsGradPort.collect)
+                torch.autograd.backward([align, loss], [seed_a, seed_p])
+                align, loss = align.detach(), loss.detach()
         if st is not None:
             for t in (align, loss, acc):
                 t.record_stream(main)  # consumed by the total-loss launch on the caller's stream
@@ -526,9 +643,14 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False):
         preds.append(loss)
         accs.append(acc)
     out = tuple(aligns) + tuple(preds) + tuple(accs)
+    if early_bwd:
+        port.leaves, port.streams = list(views), [lvl_stream(i) for i in range(L)]
 
     def join():
-        if branch is not None:
+        if early_bwd:
+            for ev in fwd_done:
+                main.wait_event(ev)
+        elif branch is not None:
             for st in branch[1:]:
                 main.wait_stream(st)
 

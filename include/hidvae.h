@@ -267,14 +267,17 @@ int hidvae_total_loss_bwd(const float *g_loss, int64_t B, int L, float w_a, floa
  * loss_fwd: recon[b] = |normalize(y[b]) - x[b]|^2 (encoder.py:32, loss.py:11-12) for every row, then the total loss as
  *   hidvae_total_loss.
  * loss_bwd: g_y = (g_loss/B) d recon/d y;  scal / g_z exactly as hidvae_total_loss_bwd.
- * n_cat: categorical columns at the end of the row, as in hidvae_recon_fwd_bwd (0 on every shipped config). */
+ * n_cat: categorical columns at the end of the row, as in hidvae_recon_fwd_bwd (0 on every shipped config).
+ * expect_g (loss_bwd; 0 = no check): the loss gradient part of the backward was already seeded with (the tag heads' early backward,
+ *   hidvae_amd/tagpath.py HeadsGradPort); if *g_loss differs, every output of the launch is NaN -- the step fails visibly instead of
+ *   mixing two scalings. */
 int hidvae_loss_fwd(const float *y, const float *x, int64_t B, int64_t N, int n_cat, const float *qloss,
                     const float *const *align_host, const float *const *pred_host, const float *const *acc_host, int n_tag,
                     float tag_div, const int64_t *ids, const float *z, int L, float uniq_weight, float uniq_margin, float w_a,
                     float w_p, float w_u, float *recon, float *loss, float *uniq, float *g_rows, float *tagstats,
                     float *summary, int embed_dim, void *stream);
 int hidvae_loss_bwd(const float *g_loss, const float *y, const float *x, int64_t B, int64_t N, int n_cat, int L, float w_a, float w_p,
-                    float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, int embed_dim, void *stream);
+                    float w_u, const float *g_rows, float *g_y, float *scal, float *g_z, int embed_dim, float expect_g, void *stream);
 
 /* ---- a14 as stand-alone modules: ReconstructionLoss.forward (loss.py:7-12) and the two halves of QuantizeLoss.forward
  * (loss.py:36-44) are sums s[m] = sum_j (a[m,j]-b[m,j])^2 over rows (lda/ldb row strides in elements):
@@ -371,7 +374,11 @@ int hidvae_layernorm_bwd_all(const float *gy, const float *x, const float *gamma
  *                                      y_out (required when relu): the forward OUTPUT y = relu(h) * keep * keep_scale, off which the
  *                                      ReLU -> Dropout gate is read (y > 0 exactly where the unit was active and kept: no mask, no h);
  *                                      in_relu_scale != 0: the LayerNorm's INPUT was itself relu(.) * keep * in_relu_scale (Linear -> ReLU ->
- *                                      Dropout -> LayerNorm, h_rqvae.py:157-162) and gx is returned already taken through that gate
+ *                                      Dropout -> LayerNorm, h_rqvae.py:157-162) and gx is returned already taken through that gate;
+ *                                      gy2 (optional, [M,N]): a second gradient of the same output, added to gy on the way in -- the residual
+ *                                      path of TagPredictor's blocks (h_rqvae.py:165-186) hands the producer of f_n two gradients, which
+ *                                      autograd would add in a launch of its own; gsum (optional, [M,N]): gy + gy2 written out (the next
+ *                                      residual hop needs it)
  *   hidvae_layernorm_param_final_many  the fixed-order finish of MANY such partial sets in ONE launch (n <= 32 per launch; more are
  *                                      issued in slices): ggamma / gbeta (+)= column sums, same order as hidvae_layernorm_bwd_all */
 typedef struct {
@@ -381,7 +388,7 @@ typedef struct {
 } hidvae_ln_final;
 int hidvae_layernorm_bwd_partial(const float *gy, const float *x, const float *gamma, const float *beta, const float *mean,
                                  const float *rstd, int64_t M, int64_t N, int relu, const float *y_out, float keep_scale,
-                                 float in_relu_scale, float *gx, float *partials, void *stream);
+                                 float in_relu_scale, const float *gy2, float *gsum, float *gx, float *partials, void *stream);
 int hidvae_layernorm_param_final_many(const hidvae_ln_final *problems_host, int n, void *stream);
 /* The attention gate of TagPredictor (h_rqvae.py:128-139, :196-206) as ONE row-local launch each way (E = 32 (i+1) <= 128, a multiple of 4):
  *   a1 = relu(x W0^T + b0) [B,E/4], a2 = gelu(pre2 = a1 W2^T + b2) [B,E/2], a3 = sigmoid(a2 W4^T + b4) [B,E],

@@ -48,12 +48,19 @@ def supported(name):
     return True
 
 
+@pytest.mark.parametrize("early_heads", [False, True])
 @pytest.mark.parametrize("name", [n for n in H.case_names("case") if supported(n)])
-def test_forward_backward_matches_reference_goldens(name):
+def test_forward_backward_matches_reference_goldens(name, early_heads):
+    """early_heads: the training loop's form of the tagged step -- it announces the loss gradient (HRqVae.loss_grad_hint) and every
+    level's heads run their backward right after their forward (tagpath.HeadsGradPort); same fixtures, same bars."""
     fx, desc = H.load(name)
+    if early_heads and not (desc["training"] and desc["tagged"] and desc["cfg"]["codebook_mode"] != O.GUMBEL):
+        pytest.skip("the early heads backward exists on the tagged training step only")
     cfg, P, x, te, ti = H.inputs_of(desc)
     m = build_model(cfg, P)
     m.train(desc["training"])
+    if early_heads:
+        m.loss_grad_hint = 1.0
     from hidvae_amd.rand import InjectedRand
     m.rand = InjectedRand(O.FormulaRand(**desc["rand"]))
     batch = make_batch(x, te, ti)
@@ -303,6 +310,36 @@ def test_plain_rqvae_matches_reference_goldens(name):
     assert H.rel_err(q.embeddings.cpu().numpy(), fx["embeddings"]) <= TOL
     assert H.rel_err(q.residuals.cpu().numpy(), fx["residuals"]) <= TOL
     assert H.rel_err(q.quantize_loss.cpu().numpy(), fx["quantize_loss"]) <= TOL
+
+
+def test_early_heads_backward_is_the_same_step_and_refuses_another_loss_gradient():
+    """The tagged step with the heads' backward run early (the loss gradient announced by the training loop) against the ordinary
+    loss.backward(): every gradient bit for bit, with in-kernel dropout / mixup (DeviceRand) -- and a loss gradient other than the
+    announced one must not go unnoticed."""
+    from hidvae_amd.rand import DeviceRand
+    fx, desc = H.load("rot_train_tag_b128")
+    cfg, P, x, te, ti = H.inputs_of(desc)
+    grads = []
+    for hint in (None, 1.0):
+        m = build_model(cfg, P)
+        m.train(True)
+        m.rand = DeviceRand(cfg.mixup_alpha, seed=1234)
+        if hint is not None:
+            m.loss_grad_hint = hint
+        out = m(make_batch(x, te, ti), gumbel_t=0.2)
+        out.loss.backward()
+        grads.append((float(out.loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert grads[0][0] == grads[1][0]
+    assert set(grads[0][1]) == set(grads[1][1])
+    for k, g in grads[0][1].items():
+        assert torch.equal(g, grads[1][1][k]), k
+    m = build_model(cfg, P)
+    m.train(True)
+    m.rand = DeviceRand(cfg.mixup_alpha, seed=1234)
+    m.loss_grad_hint = 1.0
+    out = m(make_batch(x, te, ti), gumbel_t=0.2)
+    (out.loss * 0.5).backward()  # not what was announced
+    assert not torch.isfinite(m.encoder.weights()[0].grad).all()
 
 
 def test_forward_without_backward_leaves_no_autograd_graph_behind():
