@@ -73,6 +73,7 @@ class HeadsGradPort:
                 g.record_stream(main)
                 live.append(g)
         self.leaves, self.streams = [], []
+        flush_layernorm_finals()  # the affine gradients of every LayerNorm of the heads: one launch per step (deferred from their backward)
         if not live:
             return None
         _C.phase_mark("bwd:heads joined (port)")
@@ -120,6 +121,7 @@ class AddFn(Function):
         return g, g
 
 
+_LN_DEFER = [False]  # True while the heads' early backward is being issued: the finishing launch is left to HeadsGradPort.collect (one per step)
 _LN_PENDING = []  # (stream, partials, M, N, gamma Parameter, beta Parameter) of LayerNorm backwards whose affine gradients are not finished yet
 
 
@@ -245,7 +247,7 @@ class LayerNormFn(Function):
                 link.g = gy
             gx, part = _C.layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y, scale, in_relu_scale,
                                                 need_gx=ctx.needs_input_grad[0], gy2=gy2)
-        if not _LN_PENDING:
+        if not _LN_PENDING and not _LN_DEFER[0]:
             from torch.autograd import Variable
             Variable._execution_engine.queue_callback(flush_layernorm_finals)
         _LN_PENDING.append((torch.cuda.current_stream(), part, x.shape[0], x.shape[1], ctx.gamma_param, ctx.beta_param))
@@ -579,6 +581,7 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
     else:
         views = ConcatViewsFn.apply(emb_cat, L, D, 2)  # two consumers per level: InfoNCE, the predictor (its gate launch covers both uses)
     te = tags_emb.reshape(B, -1)  # [B, L_tags*768]: level i is the column block i (a strided view, no copy)
+    ti_rows = tags_indices[:, :L].t().contiguous()  # [L, B]: every level's targets contiguous from ONE copy (not one strided-column copy per level)
     E = model.tag_embed_dim
     aligns, preds, accs = [], [], []
     lm = model.tag_prediction_loss
@@ -600,6 +603,8 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
     # HIDVAE_TAG_STREAMS: 2 (default) = EVERY level on a stream of its own, the caller's stream is left to the decoder and the loss
     # (1.78-1.79 ms against 1.85-1.86 ms with level 0 on the caller's stream, B = 2048: 2.84 vs 2.91 ms); 1 = level 0 stays with the caller
     mode = os.environ.get("HIDVAE_TAG_STREAMS", "2")
+    if early_bwd:
+        mode = "0"  # (the early-backward form deals its own streams below)
     branch = _tag_streams(emb_cat.device, L + (1 if mode == "2" else 0)) if (L > 1 and mode != "0") else None
     if branch is not None and mode == "2":
         branch = [None] + branch[1:]
@@ -607,7 +612,7 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
     else:
         lvl_stream = lambda i: (branch[i] if branch is not None and i > 0 else None)
     if branch is not None:
-        for t in (emb_cat, tags_emb, tags_indices):  # main-stream allocations that the branches (and their backward) read
+        for t in (emb_cat, tags_emb, tags_indices, ti_rows):  # main-stream allocations that the branches (and their backward) read
             for st in branch[1:]:
                 t.record_stream(st)
         for st in branch[1:]:
@@ -616,6 +621,68 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
             for st in branch[2:]:
                 st.wait_stream(branch[1])
     fwd_done = []
+    if early_bwd:
+        # Every level on a side stream of its own, the caller's stream keeps the decoder and the loss.  Forwards are issued in the
+        # reference's order (level by level, projector first: the random draws are numbered in that order), then every level's backward
+        # on the same stream.  (Dealing the 2 L units -- projector + alignment, predictor + loss -- over three streams by estimated
+        # duration, the caller's included, balanced the streams' end times but not the step: 1.39 vs 1.39 ms, B = 2048 2.36 vs 2.33.)
+        plan = {(k, i): i + 1 for i in range(L) for k in ("pred", "align")}
+        side = _tag_streams(emb_cat.device, L + 1)
+        lanes = [None] + list(side[1:])
+        for st in lanes[1:]:
+            for t in (emb_cat, tags_emb, tags_indices, ti_rows):
+                t.record_stream(st)
+            st.wait_stream(main)
+        if early and len(side) > 1:  # this step's generator advance and mixup pairing were issued on the first tag stream (early_rand)
+            main.wait_stream(side[1])
+            for st in side[2:]:
+                st.wait_stream(side[1])
+        scal = {}
+        for i in range(L):
+            for kind in ("align", "pred"):
+                st = lanes[plan[(kind, i)]]
+                with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+                    if kind == "align":
+                        _C.phase_mark(f"fwd:level {i} start")
+                        proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
+                        scal[(kind, i)] = (model.tag_alignment_loss(views[2 * i], proj, i),)
+                        _C.phase_mark(f"fwd:level {i} projector+infonce done")
+                    else:
+                        logits = tag_predictor_forward(model.tag_predictors[i], views[2 * i + 1], None, rand)
+                        scal[(kind, i)] = tag_prediction_loss(model.tag_prediction_loss, logits, ti_rows[i], 0, rand, level=i)
+                        _C.phase_mark(f"fwd:level {i} done")
+                if st is not None:
+                    for t in scal[(kind, i)]:
+                        t.record_stream(main)  # consumed by the total-loss launch on the caller's stream
+        for st in lanes[1:]:  # the caller's loss launch waits for the units' FORWARD only
+            ev = torch.cuda.Event()
+            ev.record(st)
+            fwd_done.append(ev)
+        _LN_DEFER[0] = True  # (the LayerNorms' affine gradients are finished by ONE launch, in HeadsGradPort.collect)
+        try:
+            for i in range(L):
+                for kind in ("pred", "align"):
+                    st = lanes[plan[(kind, i)]]
+                    # (called with the unit's stream current: the engine's end-of-pass synchronisation stays on that stream; the
+                    #  caller's stream does not wait for a side stream's backward before HeadsGradPort.collect)
+                    with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+                        torch.autograd.backward([scal[(kind, i)][0]], [seed_a if kind == "align" else seed_p])
+                aligns.append(scal[("align", i)][0].detach())
+                preds.append(scal[("pred", i)][0].detach())
+                accs.append(scal[("pred", i)][1])
+        finally:
+            _LN_DEFER[0] = False
+        port.leaves, port.streams = list(views), lanes[1:]
+        out = tuple(aligns) + tuple(preds) + tuple(accs)
+
+        def join():
+            for ev in fwd_done:
+                main.wait_event(ev)
+
+        if defer_join:
+            return out, join
+        join()
+        return out
     for i in range(L):
         st = lvl_stream(i)
         with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
@@ -625,17 +692,8 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
             align = model.tag_alignment_loss(c_nce, proj, i)
             _C.phase_mark(f"fwd:level {i} projector+infonce done")
             logits = tag_predictor_forward(model.tag_predictors[i], c_att, None, rand)
-            loss, acc = tag_prediction_loss(model.tag_prediction_loss, logits, tags_indices[:, i].contiguous(), 0, rand, level=i)
+            loss, acc = tag_prediction_loss(model.tag_prediction_loss, logits, ti_rows[i], 0, rand, level=i)
             _C.phase_mark(f"fwd:level {i} done")
-            if early_bwd:
-                if st is not None:  # the caller's loss launch waits for the level's FORWARD only
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                    fwd_done.append(ev)
-                # (called with the level's stream current: the engine's end-of-pass synchronisation and the LayerNorm-finals callback
-                #  stay on this stream; the caller's stream never waits for this backward before HeadsGradPort.collect)
-                torch.autograd.backward([align, loss], [seed_a, seed_p])
-                align, loss = align.detach(), loss.detach()
         if st is not None:
             for t in (align, loss, acc):
                 t.record_stream(main)  # consumed by the total-loss launch on the caller's stream
@@ -643,14 +701,9 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
         preds.append(loss)
         accs.append(acc)
     out = tuple(aligns) + tuple(preds) + tuple(accs)
-    if early_bwd:
-        port.leaves, port.streams = list(views), [lvl_stream(i) for i in range(L)]
 
     def join():
-        if early_bwd:
-            for ev in fwd_done:
-                main.wait_event(ev)
-        elif branch is not None:
+        if branch is not None:
             for st in branch[1:]:
                 main.wait_stream(st)
 
