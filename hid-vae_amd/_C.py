@@ -24,7 +24,7 @@ _vp, _i, _i64, _f, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.
 
 _SIGNATURES = {
     "hidvae_gemm_f32": [_i, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _f, _vp, _u32, _u32, _i, _vp, _i, _vp],
-    "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _f, _vp, _i, _vp, _vp],
+    "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _f, _vp, _i, _vp, _i, _vp],
     "hidvae_layernorm_bwd_partial": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_layernorm_param_final_many": [_vp, _i, _vp],
     "hidvae_gate_fwd": [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -324,8 +324,14 @@ _WS_LANE_BUFFERS = {}
 _WS_RETIRED = []  # outgrown buffers stay alive: a captured graph may still hold their address
 
 
+_SIDE_STREAMS = set()  # handles of the streams that run launches BESIDE the caller's stream (the tag heads' level streams)
+
+
 def register_ws_lane(stream):
-    """kept for callers that announce their side streams; every stream gets a workspace of its own on first use anyway"""
+    """Announce a side stream.  Every stream gets a hidvae_linear_bwd workspace of its own on first use anyway; what the announcement
+    changes is the launch shape: Linear backwards issued on an announced stream ask for workgroups that leave room on the CUs for the
+    other streams' launches (co_resident of hidvae_linear_bwd)."""
+    _SIDE_STREAMS.add(int(stream.cuda_stream))
     return int(stream.cuda_stream)
 
 
@@ -450,7 +456,8 @@ def linear_bwd(g, x, w, need_dx=True, epilogue=EPI_NONE, aux=None, dW=None, accu
     rc = lib().hidvae_linear_bwd(_p(g), _row_stride(g, "g"), _p(x), _row_stride(x, "x"), _p(w if need_dx else None),
                                  _row_stride(w, "W") if need_dx else 0, B, n_out, n_in, _p(dW), n_in, int(bool(accumulate)), _p(dX), n_in,
                                  int(epilogue), _p(aux), _row_stride(aux, "aux") if aux is not None else 0, float(dx_scale),
-                                 _p(db if bias else None), int(bool(accumulate_db)), _p(ws), _stream())
+                                 _p(db if bias else None), int(bool(accumulate_db)), _p(ws),
+                                 int(int(torch.cuda.current_stream(g.device).cuda_stream) in _SIDE_STREAMS), _stream())
     if rc != 0:
         msg = lib().hidvae_last_error().decode()
         reset_lane_workspaces()  # the zero-on-entry contract of the arrival counters may no longer hold

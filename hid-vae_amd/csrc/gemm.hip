@@ -14,6 +14,7 @@
 // Global loads for tile t+1 are issued before the MFMAs of tile t (register prefetch, two LDS buffers, one
 // barrier per k-tile).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "rules.h"
 
@@ -1808,7 +1809,7 @@ extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, 
 static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
                            int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
                            int dx_epilogue, float *aux, int64_t ldaux, float dx_scale, float *db, int accumulate_db, float *workspace,
-                           void *stream, bool balanced_ok) {
+                           void *stream, bool balanced_ok, bool co_resident = false) {
     HV_REQUIRE(g && x && dW && B >= 1 && n_out >= 1 && n_in >= 1, "linear_bwd: bad arguments");
     HV_REQUIRE(ldg >= n_out && ldx >= n_in && lddw >= n_in, "linear_bwd: leading dimension too small");
     HV_REQUIRE(dX == nullptr || (W != nullptr && ldw >= n_in && lddx >= n_in), "linear_bwd: dX needs W");
@@ -1822,11 +1823,12 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
     const bool pair32 = small && !use_direct16(n_out, n_in, B) && !use_direct16(B, n_in, n_out) && s32_0 <= 8 && s32_1 <= 8;
     const bool pair = pair16 || pair32;
     // LDS-shared 64x64 tiles, evenly dealt (gemm_mid_sk_kernel<4, 2>: 16 waves = 2x2 quarters x 4 k-groups, register prefetch two steps
-    // ahead; measured and not kept: 8-wave workgroups two per CU, four prefetch stages -- DESIGN.md)
+    // ahead; <2, 2>: 8 waves, for launches that share the chip with other streams' -- see co_resident below; not kept: four prefetch stages)
     constexpr int mid_minq = 6;  // shortest range worth a workgroup (steps)
     if (balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, dX != nullptr) &&
         fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && (dX == nullptr || fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw))) {
-        constexpr int KG = 4, BKS = 16 * KG;
+        auto run_mid = [&](auto kg_tag) -> int {
+        constexpr int KG = decltype(kg_tag)::value, BKS = 16 * KG;
         SkArgs a{};
         PairArgs &p = a.p;
         p.g0.M = n_out; p.g0.N = n_in; p.g0.K = B; p.g0.A = g; p.g0.lda = ldg; p.g0.B = x; p.g0.ldb = ldx; p.g0.C = dW; p.g0.ldc = lddw;
@@ -1845,7 +1847,7 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         a.nbc = db != nullptr ? (int)hv_cdiv(n_out, 32) : 0;
         a.cu = (int)hv_cdiv(B, 512);  // a 32-column strip of B rows, priced against a step's MFMAs (~1 us either way)
         a.S = p.nb0 * a.n0 + p.nb1 * a.n1 + a.nbc * a.cu;
-        constexpr int slots = 256;  // one 16-wave workgroup per CU
+        constexpr int slots = 1024 / KG;  // workgroups the chip holds at once: one sixteen-wave workgroup per CU (KG = 4), two eight-wave ones (KG = 2), four four-wave ones (KG = 1)
         int G = a.S / mid_minq;
         if (G > slots) G = slots;
         if (G < 1) G = 1;
@@ -1859,15 +1861,26 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         if (tiles) {
             a.q = 0;
             a.G = p.nb0 + p.nb1 + a.nbc;
-        }
+        } else if (KG != 4) return 1;  // the smaller workgroups take whole tiles only
         if (p.nb0 + p.nb1 <= HV_SK_COUNTERS && (tiles || a.G <= HV_SK_MAX_G)) {
             a.counters = reinterpret_cast<int *>(workspace);
             a.slabs = workspace + HV_SK_COUNTERS;
-            const int rc = launch_mid_sk<4, 2>(a, (hipStream_t)stream);
+            const int rc = launch_mid_sk<KG, 2>(a, (hipStream_t)stream);
             HV_REQUIRE(rc == 0, "linear_bwd: could not size the LDS of gemm_mid_sk_kernel");
             HV_LAUNCH_CHECK("linear_bwd mid");
             return HIDVAE_OK;
         }
+        return 1;  // not taken
+        };
+        // co_resident (the caller runs launches on other streams beside this one -- the tag heads' level streams): EIGHT-wave workgroups,
+        // one whole tile each, two fit a CU.  Alone such a launch is 0-6 % slower than the sixteen-wave form (768 x 512 at B = 1024:
+        // 29.2 vs 27.7 us; 691 x 768: 41.4 vs 44.8), but the sixteen-wave workgroup takes every register of its CU for 30-45 us, so
+        // nothing of another stream can start there; with the smaller workgroups the launches of the three level streams overlap each
+        // other's fill and drain: tagged step 1.385 -> 1.320 ms (four-wave workgroups, four per CU: 1.340).  Whole tiles only -- more
+        // tiles than the chip holds, or K > 1536, stay on the sixteen-wave ranges (B = 2048: no difference either way).
+        int rc_mid = co_resident ? run_mid(std::integral_constant<int, 2>{}) : 1;
+        if (rc_mid == 1) rc_mid = run_mid(std::integral_constant<int, 4>{});
+        if (rc_mid != 1) return rc_mid;
     }
     // (a workspace of a balanced-kernel shape keeps its leading counters to itself, whichever path this call takes)
     if (balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, true)) workspace += HV_SK_COUNTERS;
@@ -1917,9 +1930,9 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
 extern "C" int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
                                  int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
                                  int dx_epilogue, float *aux, int64_t ldaux, float dx_scale, float *db, int accumulate_db, float *workspace,
-                                 void *stream) {
+                                 int co_resident, void *stream) {
     return linear_bwd_impl(g, ldg, x, ldx, W, ldw, B, n_out, n_in, dW, lddw, accumulate_dw, dX, lddx, dx_epilogue, aux, ldaux, dx_scale, db,
-                           accumulate_db, workspace, stream, true);
+                           accumulate_db, workspace, stream, true, co_resident != 0);
 }
 
 extern "C" int hidvae_colsum(const float *X, int64_t M, int64_t N, int64_t ldx, float *out, int accumulate,

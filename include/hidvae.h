@@ -118,12 +118,17 @@ int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K,
  * db (optional): the bias gradient db[n_out] = column sums of g, from the same launch (fixed summation order; the fallback
  * uses hidvae_colsum and needs its workspace of ceil(B/64)*n_out floats when B > 16384).  workspace (optional) is also what lets the
  * unpaired dW product of a LARGE batch (B >= 4096) run as K-slabs on the LDS-tiled kernel: give it max(that, 16*n_out*n_in) floats.
+ *   co_resident != 0: the caller runs launches on OTHER streams beside this one (the per-level streams of the tag heads).  The
+ *             balanced kernel then takes eight-wave workgroups (two fit a CU) instead of sixteen-wave ones that hold every register
+ *             of their CU for the whole launch: 0-6 % slower alone, but the streams' launches overlap each other's fill and drain
+ *             (tagged step 1.385 -> 1.320 ms).  Results differ from the sixteen-wave form in the last bits (two k-groups per tile
+ *             instead of four: another fixed summation order); each form is deterministic.
  *   dx_scale  multiplies the HIDVAE_EPI_DRELU result (1.0 elsewhere): the backward through ReLU -> Dropout(keep_scale) read off that
  *             layer's saved OUTPUT (aux = y = relu(.) * keep * keep_scale; y > 0 exactly where the unit was active and kept). */
 int hidvae_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx, const float *W, int64_t ldw, int64_t B,
                       int64_t n_out, int64_t n_in, float *dW, int64_t lddw, int accumulate_dw, float *dX, int64_t lddx,
                       int dx_epilogue, float *aux, int64_t ldaux, float dx_scale, float *db, int accumulate_db, float *workspace,
-                      void *stream);
+                      int co_resident, void *stream);
 
 /* ---- grouped launches: the SAME layer of several independent heads in one grid (the three tag-head levels of h_rqvae.py:526-549
  * run structurally identical Linear / LayerNorm chains of different widths).  problems_host: HOST array of n descriptors whose

@@ -357,6 +357,36 @@ def test_linear_bwd_balanced_kernel_against_float64_and_itself(C, B, n_out, n_in
     assert C.lane_counters_clean()
 
 
+@pytest.mark.parametrize("B,n_out,n_in", [(1024, 768, 512), (1024, 691, 768), (1000, 460, 512), (1024, 345, 691), (2048, 512, 256)])
+def test_linear_bwd_on_an_announced_side_stream_takes_the_small_workgroups(C, B, n_out, n_in):
+    """co_resident: on a stream announced with register_ws_lane the balanced kernel runs eight-wave workgroups (two per CU) where it
+    can take whole tiles -- same contract: float64 parity incl. the gated epilogue, accumulate, db; launch-to-launch bit identity;
+    clean counters; within rounding of the sixteen-wave form"""
+    g, x, w = dev(fill.gauss((B, n_out), 84)), dev(fill.gauss((B, n_in), 85)), dev(fill.gauss((n_out, n_in), 86))
+    y = dev(np.maximum(fill.gauss((B, n_in), 87), 0.0))
+    gd, xd, wd = g.cpu().double(), x.cpu().double(), w.cpu().double()
+    main_form = C.linear_bwd(g, x, w, True, C.EPI_DRELU, y, bias=True, dx_scale=1.25)
+    side = torch.cuda.Stream()
+    C.register_ws_lane(side)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dW0, db0 = torch.ones(n_out, n_in, device="cuda"), torch.ones(n_out, device="cuda")
+        dW, dX, db = C.linear_bwd(g, x, w, True, C.EPI_DRELU, y, dW=dW0, accumulate=True, bias=True, db=db0, accumulate_db=True, dx_scale=1.25)
+        first = C.linear_bwd(g, x, w, True, C.EPI_DRELU, y, bias=True, dx_scale=1.25)
+        for _ in range(4):
+            again = C.linear_bwd(g, x, w, True, C.EPI_DRELU, y, bias=True, dx_scale=1.25)
+            assert all(torch.equal(a, b) for a, b in zip(first, again))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    want_dX = (gd @ wd) * (y.cpu().double() > 0) * 1.25
+    assert H.rel_err(dW.cpu().numpy(), (1.0 + gd.T @ xd).float().numpy()) < 2e-6
+    assert H.rel_err(dX.cpu().numpy(), want_dX.float().numpy()) < 2e-6
+    assert H.close(db.cpu().numpy(), (1.0 + gd.sum(0)).float().numpy(), 1e-5, 1e-5)
+    for a, b in zip(first, main_form):
+        assert H.rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
+    assert C.lane_counters_clean()
+
+
 @pytest.mark.parametrize("B,mode,norm", [(1024, 3, True), (50, 3, True), (16, 2, False), (333, 3, False)])
 def test_bottleneck_launch_is_bit_identical_to_the_separate_launches(C, B, mode, norm):
     """enc(256->128->32) + 3x256 RQ + dec(32->128->256) in one launch vs gemm / rq_forward one by one"""
