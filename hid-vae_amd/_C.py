@@ -335,17 +335,35 @@ def register_ws_lane(stream):
     return int(stream.cuda_stream)
 
 
+_WS_LAST_CALLER = {}  # device index -> key of the lane most recently used, outside a capture, by a stream that was never announced
+
+
 def _lane_ws(device, nbytes):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(device).cuda_stream))
+    """the hidvae_linear_bwd workspace of the current stream (its leading arrival counters are zero between launches and must never be
+    shared by launches that run at the same time): one persistent zero-filled buffer per (device, stream).  A graph capture runs on a
+    stream of its own that no eager step ever saw; it stands in for the caller's stream -- the replay will run there, serialised with
+    the caller's other launches -- so it takes the buffer of the unannounced stream that ran the eager warm-up steps.  (Round 3 first
+    gave a capturing stream a fresh torch.zeros per CALL: one 17 MB fill kernel per balanced launch and replay, +4-5 % on the untagged
+    steps.)"""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    handle = int(torch.cuda.current_stream(device).cuda_stream)
+    key = (dev, handle)
     buf = _WS_LANE_BUFFERS.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if buf is None and capturing and handle not in _SIDE_STREAMS:
+        stand_in = _WS_LANE_BUFFERS.get(_WS_LAST_CALLER.get(dev))
+        if stand_in is not None and stand_in.numel() * 4 >= nbytes:
+            return stand_in
     if buf is None or buf.numel() * 4 < nbytes:
-        if torch.cuda.is_current_stream_capturing():
-            # first use inside a capture: a buffer of the capture's own (its zero-fill replays with the graph); never shared
+        if capturing:
+            # first use inside a capture with nothing to stand in: a buffer of the capture's own (its zero-fill replays with the graph)
             return torch.zeros((nbytes // 4,), device=device, dtype=torch.float32)
         if buf is not None:
             _WS_RETIRED.append(buf)
         buf = torch.zeros((nbytes // 4,), device=device, dtype=torch.float32)
         _WS_LANE_BUFFERS[key] = buf
+    if not capturing and handle not in _SIDE_STREAMS:
+        _WS_LAST_CALLER[dev] = key
     return buf
 
 

@@ -1845,7 +1845,7 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         } else a.n1 = 1;
         p.cs_x = g; p.cs_ld = ldg; p.cs_rows = B; p.cs_cols = n_out; p.cs_out = db; p.cs_accumulate = accumulate_db;
         a.nbc = db != nullptr ? (int)hv_cdiv(n_out, 32) : 0;
-        a.cu = (int)hv_cdiv(B, 512);  // a 32-column strip of B rows, priced against a step's MFMAs (~1 us either way)
+        a.cu = (int)hv_cdiv(B, 128 * KG);  // a 32-column strip of B rows, priced against a step's MFMAs (~1 us per 512 rows either way)
         a.S = p.nb0 * a.n0 + p.nb1 * a.n1 + a.nbc * a.cu;
         constexpr int slots = 1024 / KG;  // workgroups the chip holds at once: one sixteen-wave workgroup per CU (KG = 4), two eight-wave ones (KG = 2), four four-wave ones (KG = 1)
         int G = a.S / mid_minq;
@@ -1861,7 +1861,7 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         if (tiles) {
             a.q = 0;
             a.G = p.nb0 + p.nb1 + a.nbc;
-        } else if (KG != 4) return 1;  // the smaller workgroups take whole tiles only
+        }
         if (p.nb0 + p.nb1 <= HV_SK_COUNTERS && (tiles || a.G <= HV_SK_MAX_G)) {
             a.counters = reinterpret_cast<int *>(workspace);
             a.slabs = workspace + HV_SK_COUNTERS;
@@ -1876,8 +1876,8 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
         // one whole tile each, two fit a CU.  Alone such a launch is 0-6 % slower than the sixteen-wave form (768 x 512 at B = 1024:
         // 29.2 vs 27.7 us; 691 x 768: 41.4 vs 44.8), but the sixteen-wave workgroup takes every register of its CU for 30-45 us, so
         // nothing of another stream can start there; with the smaller workgroups the launches of the three level streams overlap each
-        // other's fill and drain: tagged step 1.385 -> 1.320 ms (four-wave workgroups, four per CU: 1.340).  Whole tiles only -- more
-        // tiles than the chip holds, or K > 1536, stay on the sixteen-wave ranges (B = 2048: no difference either way).
+        // other's fill and drain: tagged step 1.385 -> 1.320 ms (four-wave workgroups, four per CU: 1.340).  Same scheduling rules with
+        // 512 workgroup slots instead of 256 (whole tiles when they fit and K <= 1536, equal ranges otherwise: B = 2048 2.32 -> 2.27 ms).
         int rc_mid = co_resident ? run_mid(std::integral_constant<int, 2>{}) : 1;
         if (rc_mid == 1) rc_mid = run_mid(std::integral_constant<int, 4>{});
         if (rc_mid != 1) return rc_mid;
