@@ -98,7 +98,7 @@ def test_overlapped_dp_step_equals_the_plain_step_bit_for_bit(tagged, in_graph):
         assert torch.equal(sd1[k], sd0[k]), k
 
 
-def _rank_worker(rank, world, port, out_dir, steps, B):
+def _rank_worker(rank, world, port, out_dir, steps, B, tagged=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -111,17 +111,38 @@ def _rank_worker(rank, world, port, out_dir, steps, B):
     cfg = O.Cfg(**CFG)
     # replicas start DIFFERENT on purpose: broadcast_parameters must make them rank 0's
     m = build_model(cfg, O.formula_params(cfg, seed=100 + 13 * rank, with_tags=True)).train()
-    opt = HidvaeAdamW(_groups(m, False), cosine=(1000, 7e-8), flat_grads=True, first_bucket=m.dp_first_bucket(B)).prepare()
+    opt = HidvaeAdamW(_groups(m, tagged), cosine=(1000, 7e-8), flat_grads=True, first_bucket=m.dp_first_bucket(B)).prepare()
     dp = DataParallel(m, opt.grad_buffer)
     dp.broadcast_parameters(0)
-    st = GraphedTrainStep(m, opt, [_batch(cfg, B, 700, False)], dp=dp, gumbel_t=0.2, warmup=2, overlap=True)
+    st = GraphedTrainStep(m, opt, [_batch(cfg, B, 700, tagged)], dp=dp, gumbel_t=0.2, warmup=2, overlap=True)
     for it in range(steps):
-        st([_batch(cfg, B, 700 + 2 * it + rank, False)])
+        st([_batch(cfg, B, 700 + 2 * it + rank, tagged)])
     torch.cuda.synchronize()
     assert st.graphs is not None and len(st.graphs) == 3
-    torch.save({k: v.detach().cpu() for k, v in m.state_dict().items() if not k.startswith("tag_")}, os.path.join(out_dir, f"rank{rank}.pt"))
+    # (BatchNorm running statistics stay rank-local, as under DDP: each rank saw its own batches)
+    keep = (lambda k: "running_" not in k and "num_batches" not in k) if tagged else (lambda k: not k.startswith("tag_"))
+    torch.save({k: v.detach().cpu() for k, v in m.state_dict().items() if keep(k)}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_tagged_ranks_stay_bit_identical(tmp_path):
+    """The TAGGED overlapped step on two ranks (gloo, both on this GPU): tag streams + the heads' early backward + the split backward +
+    two exchanges between three graphs -- replicas that start different must end bit-identical in every parameter, tag heads included,
+    and must have moved."""
+    import torch.multiprocessing as mp
+    world, steps, B = 2, 4, 64
+    mp.spawn(_rank_worker, args=(world, _free_port(), str(tmp_path), steps, B, True), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert any(k.startswith("tag_predictors") for k in r0) and any(k.startswith("tag_projectors") for k in r0)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f"replicas diverged: {k}"
+        assert torch.isfinite(r0[k]).all(), k
+    cfg = O.Cfg(**CFG)
+    start = O.formula_params(cfg, seed=100, with_tags=True)
+    moved = [k for k in r0 if k in start and r0[k].dtype.is_floating_point and not torch.equal(r0[k], start[k])]
+    assert len(moved) > 0.9 * sum(1 for k in r0 if k in start and r0[k].dtype.is_floating_point)
 
 
 @pytest.mark.timeout(600)
