@@ -206,36 +206,37 @@ constexpr int LNF_ROWS = 4, LNF_NV = 16;  // one row per wave: rows in flight, n
 //   the gate of ReLU -> Dropout needs neither the keep-mask nor h.
 // in_relu_scale (0 = off): this LayerNorm's INPUT x was itself relu(.) * keep * in_relu_scale (Linear -> ReLU -> Dropout -> LayerNorm,
 //   h_rqvae.py:157-162): gx leaves the launch already taken through that ReLU / Dropout, gx * (x > 0 ? in_relu_scale : 0).
-__device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*red)[3][64 * LNF_NV], const float *gy, const float *x,
-                                                         const float *gamma, const float *beta, const float *mean, const float *rstd,
-                                                         int64_t M, int64_t N, int relu, const float *mask, float scale, float *gx,
-                                                         float *part, const float *yout = nullptr, float in_relu_scale = 0.0f,
-                                                         const float *gy2 = nullptr, float *gsum = nullptr) {
+// NV: columns per lane (N <= 64 NV); instantiated for 4, 8, 12, 16 so that the common widths keep a small register footprint -- the one
+//   NV = 16 form took 256 VGPRs + 42 AGPRs, ONE wave per SIMD: it could start only on a SIMD with nothing else on it, which beside the
+//   other streams' GEMM launches meant waiting for them (25 us in-step for a 4.5 us kernel)
+template <int NV>
+__device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float *red, const float *gy, const float *x, const float *gamma,
+                                                         const float *beta, const float *mean, const float *rstd, int64_t M, int64_t N,
+                                                         int relu, const float *mask, float scale, float *gx, float *part,
+                                                         const float *yout, float in_relu_scale, const float *gy2, float *gsum) {
     // gy2 (optional): a second gradient of the same output, added on the way in (the residual path of TagPredictor's blocks,
     //   h_rqvae.py:165-186: f_{n+1} = LN(..) + f_n hands f_n's producer two gradients); gsum (optional): that sum, written out for the
     //   next residual hop
+    // red: [2][3][64 NV] floats of LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float ga[LNF_NV], be[LNF_NV], sg[LNF_NV], sb[LNF_NV];
+    const int64_t row = blk * LNF_ROWS + wave;  // one row per wave
+    float g[NV], xh[NV], ga[NV];
+    unsigned xpos = 0u;  // bit j: the LayerNorm input of column lane + 64 j is > 0 (in_relu_scale)
+    float s1 = 0.0f, s2 = 0.0f, rs = 0.0f;
+    const bool live = row < M;
 #pragma unroll
-    for (int j = 0; j < LNF_NV; j++) {
+    for (int j = 0; j < NV; j++) {
         const int64_t c = lane + 64 * j;
+        g[j] = 0.0f;
+        xh[j] = 0.0f;
         ga[j] = c < N ? gamma[c] : 0.0f;
-        be[j] = c < N ? beta[c] : 0.0f;
-        sg[j] = 0.0f;
-        sb[j] = 0.0f;
     }
-    for (int rr = wave; rr < LNF_ROWS; rr += 4) {
-        const int64_t row = blk * LNF_ROWS + rr;
-        if (row >= M) break;
-        const float mu = mean[row], rs = rstd[row];
-        float g[LNF_NV], xh[LNF_NV];
-        float s1 = 0.0f, s2 = 0.0f;
-        unsigned xpos = 0u;  // bit j: the LayerNorm input of column lane + 64 j is > 0 (in_relu_scale)
+    if (live) {
+        const float mu = mean[row];
+        rs = rstd[row];
 #pragma unroll
-        for (int j = 0; j < LNF_NV; j++) {
+        for (int j = 0; j < NV; j++) {
             const int64_t c = lane + 64 * j;
-            g[j] = 0.0f;
-            xh[j] = 0.0f;
             if (c < N) {
                 const float xraw = x[row * N + c];
                 if (xraw > 0.0f) xpos |= 1u << j;
@@ -247,7 +248,7 @@ __device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*re
                     if (relu) gv = yout[row * N + c] > 0.0f ? gv * scale : 0.0f;
                 } else {
                     if (mask != nullptr) gv = gv * (mask[row * N + c] * scale);
-                    if (relu && !(xh[j] * ga[j] + be[j] > 0.0f)) gv = 0.0f;
+                    if (relu && !(xh[j] * ga[j] + beta[c] > 0.0f)) gv = 0.0f;
                 }
                 g[j] = gv;
                 const float dy = gv * ga[j];
@@ -255,49 +256,61 @@ __device__ __forceinline__ void layernorm_bwd_fused_body(int64_t blk, float (*re
                 s2 += dy * xh[j];
             }
         }
-        s1 = hv_wave_sum(s1) / (float)N;
-        s2 = hv_wave_sum(s2) / (float)N;
-#pragma unroll
-        for (int j = 0; j < LNF_NV; j++) {
-            const int64_t c = lane + 64 * j;
-            if (c < N) {
-                if (gx != nullptr) {
-                    float o = rs * ((g[j] * ga[j] - s1) - xh[j] * s2);
-                    if (in_relu_scale != 0.0f) o = ((xpos >> j) & 1u) ? o * in_relu_scale : 0.0f;
-                    gx[row * N + c] = o;
-                }
-                sg[j] += g[j] * xh[j];
-                sb[j] += g[j];
-            }
-        }
     }
-    if (wave > 0) {
+    s1 = hv_wave_sum(s1) / (float)N;
+    s2 = hv_wave_sum(s2) / (float)N;
 #pragma unroll
-        for (int j = 0; j < LNF_NV; j++) {
-            red[0][wave - 1][lane + 64 * j] = sg[j];
-            red[1][wave - 1][lane + 64 * j] = sb[j];
+    for (int j = 0; j < NV; j++) {
+        const int64_t c = lane + 64 * j;
+        if (live && c < N && gx != nullptr) {
+            float o = rs * ((g[j] * ga[j] - s1) - xh[j] * s2);
+            if (in_relu_scale != 0.0f) o = ((xpos >> j) & 1u) ? o * in_relu_scale : 0.0f;
+            gx[row * N + c] = o;
+        }
+        // the row's terms of the affine gradients: waves 1..3 hand theirs to wave 0, which adds the four in a fixed order
+        const float tg = 0.0f + g[j] * xh[j], tb = 0.0f + g[j];
+        if (wave > 0) {
+            red[(0 * 3 + wave - 1) * 64 * NV + lane + 64 * j] = tg;
+            red[(1 * 3 + wave - 1) * 64 * NV + lane + 64 * j] = tb;
+        } else {
+            g[j] = tg;
+            xh[j] = tb;
         }
     }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int j = 0; j < LNF_NV; j++) {
+        for (int j = 0; j < NV; j++) {
             const int64_t c = lane + 64 * j;
             if (c < N) {
-                part[(blk * 2 + 0) * N + c] = (sg[j] + red[0][0][c]) + (red[0][1][c] + red[0][2][c]);
-                part[(blk * 2 + 1) * N + c] = (sb[j] + red[1][0][c]) + (red[1][1][c] + red[1][2][c]);
+                part[(blk * 2 + 0) * N + c] = (g[j] + red[(0 * 3 + 0) * 64 * NV + c]) + (red[(0 * 3 + 1) * 64 * NV + c] + red[(0 * 3 + 2) * 64 * NV + c]);
+                part[(blk * 2 + 1) * N + c] = (xh[j] + red[(1 * 3 + 0) * 64 * NV + c]) + (red[(1 * 3 + 1) * 64 * NV + c] + red[(1 * 3 + 2) * 64 * NV + c]);
             }
         }
     }
 }
 
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *gy, const float *x, const float *gamma, const float *beta,
                                                                   const float *mean, const float *rstd, int64_t M, int64_t N, int relu,
                                                                   const float *mask, float scale, float *gx, float *part,
                                                                   const float *yout, float in_relu_scale, const float *gy2, float *gsum) {
-    __shared__ float red[2][3][64 * LNF_NV];
-    layernorm_bwd_fused_body((int64_t)blockIdx.x, red, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, part, yout, in_relu_scale,
-                             gy2, gsum);
+    __shared__ float red[2 * 3 * 64 * NV];
+    layernorm_bwd_fused_body<NV>((int64_t)blockIdx.x, red, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, part, yout, in_relu_scale,
+                                 gy2, gsum);
+}
+
+static void launch_layernorm_bwd_fused(int64_t chunks, hipStream_t s, const float *gy, const float *x, const float *gamma, const float *beta,
+                                       const float *mean, const float *rstd, int64_t M, int64_t N, int relu, const float *mask, float scale,
+                                       float *gx, float *part, const float *yout, float in_relu_scale, const float *gy2, float *gsum) {
+    const dim3 grid((unsigned)chunks), block(256);
+#define HV_LNB(NVV) hipLaunchKernelGGL(layernorm_bwd_fused_kernel<NVV>, grid, block, 0, s, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, \
+                                       part, yout, in_relu_scale, gy2, gsum)
+    if (N <= 256) HV_LNB(4);
+    else if (N <= 512) HV_LNB(8);
+    else if (N <= 768) HV_LNB(12);
+    else HV_LNB(16);
+#undef HV_LNB
 }
 // 32 columns x 32 chunk groups per workgroup: group q adds chunks q, q+32, ... in ascending order, then the groups are added
 // in ascending order (the fused backward leaves one partial per 4 rows, so depth matters more than work here)
@@ -1057,8 +1070,8 @@ extern "C" int hidvae_layernorm_bwd_all(const float *gy, const float *x, const f
     }
     const int64_t chunks = hv_cdiv(M, LNF_ROWS);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(layernorm_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 0, s, gy, x, gamma, beta, mean, rstd, M, N, relu,
-                       keep_mask, keep_scale, gx, workspace, (const float *)nullptr, 0.0f, (const float *)nullptr, (float *)nullptr);
+    launch_layernorm_bwd_fused(chunks, s, gy, x, gamma, beta, mean, rstd, M, N, relu, keep_mask, keep_scale, gx, workspace, nullptr, 0.0f, nullptr,
+                               nullptr);
     HV_LAUNCH_CHECK("layernorm_bwd_fused");
     hipLaunchKernelGGL(layernorm_param_final_kernel, dim3((unsigned)hv_cdiv(N, 32)), dim3(1024), 0, s, workspace, chunks, N, ggamma,
                        gbeta, accumulate);
@@ -1073,8 +1086,8 @@ extern "C" int hidvae_layernorm_bwd_partial(const float *gy, const float *x, con
     HV_REQUIRE(N <= 64 * LNF_NV, "layernorm_bwd_partial: N=%lld exceeds the register-resident form (%d)", (long long)N, 64 * LNF_NV);
     HV_REQUIRE(!relu || y_out != nullptr, "layernorm_bwd_partial: the ReLU gate is read off the forward output");
     const int64_t chunks = hv_cdiv(M, LNF_ROWS);
-    hipLaunchKernelGGL(layernorm_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, gy, x, gamma, beta, mean, rstd,
-                       M, N, relu, (const float *)nullptr, keep_scale, gx, partials, y_out, in_relu_scale, gy2, gsum);
+    launch_layernorm_bwd_fused(chunks, (hipStream_t)stream, gy, x, gamma, beta, mean, rstd, M, N, relu, nullptr, keep_scale, gx, partials, y_out,
+                               in_relu_scale, gy2, gsum);
     HV_LAUNCH_CHECK("layernorm_bwd_partial");
     return HIDVAE_OK;
 }
