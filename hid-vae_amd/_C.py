@@ -730,11 +730,19 @@ def adamw_prepare(desc, step_dev, beta1, beta2, eta_min, T_max, step_size=0, gam
            "hidvae_adamw_prepare")
 
 
-def adamw_step(desc, beta1, beta2, eps, grad_scale):
-    """desc: device tables built by optim.HidvaeAdamW (p/m/v pointer tables, numel, hyper) + the host gradient table."""
-    _check(lib().hidvae_adamw_step(_p(desc["p"]), desc["g_host"], _p(desc["m"]), _p(desc["v"]), _p(desc["numel"]), _p(desc["hyper"]),
-                                   int(desc["n"]), int(desc["max_numel"]), float(beta1), float(beta2), float(eps), float(grad_scale),
-                                   _stream()), "hidvae_adamw_step")
+def adamw_step(desc, beta1, beta2, eps, grad_scale, lo=0, hi=None, g_host=None):
+    """desc: device tables built by optim.HidvaeAdamW (p/m/v pointer tables, numel, hyper) + the host gradient table.
+    lo / hi: only the tensors [lo, hi) of the tables (g_host then holds just their gradient pointers): the tables are plain arrays, so a
+    sub-range is the same call on offset pointers."""
+    n = int(desc["n"])
+    hi = n if hi is None else int(hi)
+    lo = int(lo)
+    if not 0 <= lo < hi <= n:
+        raise RuntimeError(f"adamw_step: tensor range [{lo}, {hi}) of {n}")
+    off = lambda t, k: ctypes.c_void_p(t.data_ptr() + k * t.element_size())
+    _check(lib().hidvae_adamw_step(off(desc["p"], lo), desc["g_host"] if g_host is None else g_host, off(desc["m"], lo), off(desc["v"], lo),
+                                   off(desc["numel"], lo), off(desc["hyper"], 3 * lo), hi - lo, int(desc["max_numel"]), float(beta1),
+                                   float(beta2), float(eps), float(grad_scale), _stream()), "hidvae_adamw_step")
 
 
 def uniq_loss(ids, z, weight, margin, want_grad=False):

@@ -133,9 +133,53 @@ class HidvaeAdamW(torch.optim.Optimizer):
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     raise RuntimeError("HidvaeAdamW: gradients must be contiguous float32")
                 ptrs.append(g.data_ptr())
-        self._desc["g_host"] = (ctypes.c_void_p * len(ptrs))(*ptrs)
-        _C.adamw_step(self._desc, self.betas[0], self.betas[1], self.eps, self.grad_scale)
+        early, self._early = sorted(getattr(self, "_early", [])), []
+        if not early:
+            self._desc["g_host"] = (ctypes.c_void_p * len(ptrs))(*ptrs)
+            _C.adamw_step(self._desc, self.betas[0], self.betas[1], self.eps, self.grad_scale)
+        else:  # some tensors already took this step's update (step_early): the rest, range by range
+            lo = 0
+            for a, b in early + [(len(ptrs), len(ptrs))]:
+                if a > lo:
+                    _C.adamw_step(self._desc, self.betas[0], self.betas[1], self.eps, self.grad_scale, lo=lo, hi=a,
+                                  g_host=(ctypes.c_void_p * (a - lo))(*ptrs[lo:a]))
+                lo = max(lo, b)
         self._prepared = False
+
+    def tensor_ranges_of(self, params):
+        """[(lo, hi), ...]: the positions of `params` in the optimizer's tensor tables, merged into contiguous ranges (None if one of
+        them is not an optimized tensor)"""
+        self.prepare()
+        pos = {id(p): i for i, p in enumerate(self._params)}
+        idx = sorted({pos.get(id(p), -1) for p in params if p.requires_grad})
+        if not idx or idx[0] < 0:
+            return None
+        out, lo = [], idx[0]
+        for a, b in zip(idx, idx[1:] + [None]):
+            if b != a + 1:
+                out.append((lo, a + 1))
+                lo = b
+        return out
+
+    @torch.no_grad()
+    def step_early(self, ranges):
+        """This step's update for the tensors of `ranges` NOW, on the current stream -- their gradients are complete (a tag level's heads
+        after that level's backward) while the rest of the backward is still running; step() then updates only the others.  Needs the
+        step's scalars to be on their way already (the forward's codebook_prepare launch carried them) and per-parameter gradients
+        (no flat buffer: under data parallelism the exchange comes first).  -> False if it did nothing."""
+        if self._desc is None or not self._prepared or self.flat_grads or not ranges:
+            return False
+        for lo, hi in ranges:
+            ptrs = []
+            for p in self._params[lo:hi]:
+                g = p.grad
+                if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                    raise RuntimeError("HidvaeAdamW: gradients must be contiguous float32")
+                ptrs.append(self._zero.data_ptr() if g is None else g.data_ptr())
+            _C.adamw_step(self._desc, self.betas[0], self.betas[1], self.eps, self.grad_scale, lo=lo, hi=hi,
+                          g_host=(ctypes.c_void_p * (hi - lo))(*ptrs))
+        self._early = getattr(self, "_early", []) + list(ranges)
+        return True
 
     # ---- checkpoint interchange: the "optimizer" entry of a checkpoint is a genuine torch.optim.AdamW state_dict (reference
     # train_hidvae.py:1166 writes optimizer.state_dict(), :625 feeds it to optimizer.load_state_dict) -----------------------------

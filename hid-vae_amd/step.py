@@ -59,6 +59,14 @@ class GraphedTrainStep:
         # the tag heads can run their backward right after their forward (HRqVae.loss_grad_hint; HIDVAE_EARLY_HEADS=0 turns it off)
         if self.tagged and hasattr(model, "n_layers") and os.environ.get("HIDVAE_EARLY_HEADS", "1") != "0":
             model.loss_grad_hint = float(torch.tensor(1.0, dtype=torch.float32) / self.ga) if self.ga > 1 else 1.0
+            # ... and, with one micro-batch per step and no gradient exchange, a level's head parameters take their AdamW update on that
+            # level's stream as soon as its backward is done (90 % of the tagged model's bytes leave the serial tail of the step)
+            model._level_done_hook = None
+            if dp is None and self.ga == 1 and hasattr(opt, "step_early") and hasattr(model, "tag_predictors"):
+                ranges = [opt.tensor_ranges_of(list(model.tag_predictors[i].parameters()) + list(model.tag_projectors[i].parameters()))
+                          for i in range(model.n_layers)]
+                if all(r is not None for r in ranges):
+                    model._level_done_hook = lambda i: opt.step_early(ranges[i])
 
     # -- the step, as plain code (this is what gets captured)
     def _overlapped(self):
@@ -133,6 +141,9 @@ class GraphedTrainStep:
         from . import _C
         _C.phase_mark("backward done")
         self.opt.step()
+        if self.tagged and getattr(self.model, "_level_done_hook", None) is not None:
+            from .tagpath import join_tag_streams
+            join_tag_streams(self.static[0].x.device)  # the levels' own optimizer updates ran on their streams, beside the core's backward
         _C.phase_mark("adamw done")
 
     def _capture(self):

@@ -52,19 +52,22 @@ class HeadsGradPort:
 
     def __init__(self, shape):
         self.shape = tuple(shape)
-        self.leaves, self.streams = [], []
+        self.leaves, self.streams, self.done = [], [], []
 
     def collect(self):
         main = torch.cuda.current_stream()
         capturing = torch.cuda.is_current_stream_capturing()
-        for st in self.streams:
+        for k, st in enumerate(self.streams):
             if st is None:
                 continue
             if capturing:
                 with torch.cuda.stream(st):
                     if not torch.cuda.is_current_stream_capturing():
                         continue  # a graph of its own for this half of the backward: the level streams were joined at the end of the previous one
-            main.wait_stream(st)
+            if k < len(self.done) and self.done[k] is not None:
+                main.wait_event(self.done[k])  # the level's BACKWARD; what the level does after it (its own optimizer update) is not waited for here
+            else:
+                main.wait_stream(st)
         live = []
         for leaf in self.leaves:
             g, leaf.grad = leaf.grad, None
@@ -72,7 +75,7 @@ class HeadsGradPort:
                 g = g.contiguous()
                 g.record_stream(main)
                 live.append(g)
-        self.leaves, self.streams = [], []
+        self.leaves, self.streams, self.done = [], [], []
         flush_layernorm_finals()  # the affine gradients of every LayerNorm of the heads: one launch per step (deferred from their backward)
         if not live:
             return None
@@ -138,12 +141,17 @@ def _param_grad_slot(p):
     return p.grad, True
 
 
-def flush_layernorm_finals():
+def flush_layernorm_finals(only_stream=None):
     """ONE launch finishing the affine gradients (d gamma, d beta) of every LayerNorm backward issued since the last flush
     (hidvae_layernorm_param_final_many).  Queued as an end-of-backward callback by LayerNormFn; runs on the stream backward() was
-    called on, after making it wait for the streams the partial sums were produced on."""
+    called on, after making it wait for the streams the partial sums were produced on.  only_stream: just the LayerNorms whose
+    backward ran on that stream (a level's heads finishing their own gradients before their own optimizer update)."""
     global _LN_PENDING
-    pend, _LN_PENDING = _LN_PENDING, []
+    if only_stream is None:
+        pend, _LN_PENDING = _LN_PENDING, []
+    else:
+        pend = [e for e in _LN_PENDING if e[0].cuda_stream == only_stream.cuda_stream]
+        _LN_PENDING = [e for e in _LN_PENDING if e[0].cuda_stream != only_stream.cuda_stream]
     if not pend:
         return
     main = torch.cuda.current_stream()
@@ -659,6 +667,8 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
             ev.record(st)
             fwd_done.append(ev)
         _LN_DEFER[0] = True  # (the LayerNorms' affine gradients are finished by ONE launch, in HeadsGradPort.collect)
+        bwd_done = [None] * L
+        level_done = getattr(model, "_level_done_hook", None)  # the training loop's: this level's parameters may take their optimizer update
         try:
             for i in range(L):
                 for kind in ("pred", "align"):
@@ -667,12 +677,18 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
                     #  caller's stream does not wait for a side stream's backward before HeadsGradPort.collect)
                     with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
                         torch.autograd.backward([scal[(kind, i)][0]], [seed_a if kind == "align" else seed_p])
+                        if kind == "align" and level_done is not None and st is not None:
+                            ev = torch.cuda.Event()  # the gradient hand-over waits for the backward only ...
+                            ev.record(st)
+                            bwd_done[i] = ev
+                            flush_layernorm_finals(only_stream=st)  # ... then the level's LayerNorms finish their affine gradients
+                            level_done(i)  # and its parameters take their update, beside the rest of the backward
                 aligns.append(scal[("align", i)][0].detach())
                 preds.append(scal[("pred", i)][0].detach())
                 accs.append(scal[("pred", i)][1])
         finally:
             _LN_DEFER[0] = False
-        port.leaves, port.streams = list(views), lanes[1:]
+        port.leaves, port.streams, port.done = list(views), lanes[1:], bwd_done
         out = tuple(aligns) + tuple(preds) + tuple(accs)
 
         def join():
