@@ -62,6 +62,14 @@ for _ in range(10):
     _C.layernorm_bwd_partial(xt, xt, gam, bet, ml, rl, True, yl, 1.0, 0.0)
     hh, sv = _C.gate_fwd(xc, *gW, True)
     _C.gate_bwd(hh, xc, gW[0], gW[2], gW[4], True, sv)
+# the same widest backward launch in the form it takes on the tag heads' level streams (co_resident: eight-wave workgroups, two per CU)
+side = torch.cuda.Stream()
+_C.register_ws_lane(side)
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(10):
+        _C.linear_bwd(gt, xt, wt, True, _C.EPI_DRELU, yt, bias=True, dx_scale=1.6)
+torch.cuda.current_stream().wait_stream(side)
 for _ in range(5):
     _C.rq_forward(y_big, cb, cc, True, 3, True, 0.4)
     _C.rq_ids(y_big, cb, cc, True)                                     # the tokenizer's corpus pass: only the ids leave the launch
