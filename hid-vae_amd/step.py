@@ -147,10 +147,20 @@ class GraphedTrainStep:
         _C.phase_mark("adamw done")
 
     def _capture(self):
-        if self.dp is not None and self._collectives_capturable():
+        if self.dp is not None and self._collectives_capturable() and not getattr(self, "_in_graph_failed", False):
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self._eager()  # the collectives become nodes of the graph (they fork to RCCL's stream and join back)
+            try:
+                with torch.cuda.graph(g1):
+                    self._eager()  # the collectives become nodes of the graph (they fork to RCCL's stream and join back)
+            except RuntimeError as e:
+                # (never seen with RCCL here -- one rank on this box, the only configuration that could be run; if a multi-rank
+                #  communicator refuses to be captured, the step falls back to the between-graphs form instead of dying)
+                import sys
+                print(f"[hidvae] capturing the collectives inside the step graph failed ({str(e).splitlines()[0]}); "
+                      "keeping them between graphs", file=sys.stderr)
+                self._in_graph_failed = True
+                torch.cuda.synchronize()
+                return self._capture()
             self.graphs = (g1,)
             self.in_graph = True
         elif self._overlapped():

@@ -175,3 +175,27 @@ def test_two_ranks_stay_bit_identical_and_match_the_big_batch(tmp_path):
         #  |g| ~ eps; the bulk must agree tightly, nothing may be off by more than a fraction of its possible travel)
         assert float(d.max()) <= 0.5 * lr_travel, (k, float(d.max()))
         assert float(d.median()) <= 0.01 * lr_travel, (k, float(d.median()))
+
+
+def test_the_levels_early_optimizer_update_is_the_same_update():
+    """Without a gradient exchange a tag level's head parameters take their AdamW update on that level's stream right after its
+    backward (HidvaeAdamW.step_early through GraphedTrainStep's hook), the rest at the end: every parameter and every logged row after
+    6 graphed steps must equal the run that updates everything at the end, bit for bit."""
+    from hidvae_amd.optim import HidvaeAdamW
+    from hidvae_amd.step import GraphedTrainStep
+    cfg = O.Cfg(**CFG)
+    out = []
+    for early in (True, False):
+        m = build_model(cfg, O.formula_params(cfg, seed=100, with_tags=True)).train()
+        torch.manual_seed(1234)
+        opt = HidvaeAdamW(_groups(m, True), cosine=(1000, 7e-8)).prepare()
+        st = GraphedTrainStep(m, opt, [_batch(cfg, 128, 500, True)], gumbel_t=0.2, warmup=2)
+        assert m._level_done_hook is not None and m.loss_grad_hint == 1.0
+        if not early:
+            m._level_done_hook = None
+        rows = [st([_batch(cfg, 128, 500 + it, True)]).clone() for it in range(6)]
+        assert st.graphs is not None and len(st.graphs) == 1
+        out.append((torch.stack(rows).cpu(), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
+    assert torch.equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k

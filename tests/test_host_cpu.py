@@ -230,3 +230,18 @@ def test_flat_grad_buffer_first_bucket_is_self_checking():
     buf.seal()
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(ps, buf.views))
     assert buf.flat.tolist() == [3.0] * 8 + [5.0] * 4
+
+
+def test_optimizer_tensor_ranges_for_an_early_update():
+    """HidvaeAdamW.tensor_ranges_of: where a set of parameters sits in the optimizer's tensor tables, as contiguous ranges -- what
+    GraphedTrainStep hands step_early() for a tag level's heads (the update itself is a HIP launch: GPU tests)"""
+    import torch
+    from hidvae_amd.optim import HidvaeAdamW
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (3, 5, 2, 7, 4, 1)]
+    frozen = torch.nn.Parameter(torch.zeros(2), requires_grad=False)
+    opt = HidvaeAdamW([{"params": ps[:2]}, {"params": ps[2:4] + [frozen]}, {"params": ps[4:]}], lr=1e-3)
+    assert opt.tensor_ranges_of(ps[2:4]) == [(2, 4)]
+    assert opt.tensor_ranges_of([ps[0], ps[1], ps[4], ps[5]]) == [(0, 2), (4, 6)]
+    assert opt.tensor_ranges_of([ps[3], frozen]) == [(3, 4)]           # a frozen parameter is not an optimized tensor: ignored
+    assert opt.tensor_ranges_of([torch.nn.Parameter(torch.zeros(1))]) is None   # a stranger: no early update for that set
+    assert opt.step_early([(0, 2)]) is False                            # nothing prepared (and CPU tensors): it must decline, not raise
