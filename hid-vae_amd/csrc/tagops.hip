@@ -131,6 +131,62 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *x, int6
     layernorm_fwd_body<RESIDENT>((int64_t)blockIdx.x, x, M, N, gamma, beta, eps, y, mean, rstd, relu, mask, scale, res, drop);
 }
 
+// The same forward with a row shared by S waves (S = 2 or 4; a workgroup is 4 rows x S waves): at the tag heads' sizes (1024-2048 rows)
+// one wave per row leaves one wave per SIMD and nothing to hide its three dependent phases behind.  Each wave keeps its slice of the row
+// (columns q*64*NV + lane + 64 j) in registers; the row sums are added over the S slices in ascending order through LDS.
+template <int NV, int S>
+__global__ __launch_bounds__(256 * S) void layernorm_fwd_split_kernel(const float *x, int64_t M, int64_t N, const float *gamma, const float *beta,
+                                                                      float eps, float *y, float *mean, float *rstd, int relu,
+                                                                      const float *mask, float scale, const float *res, HvDrop drop) {
+    __shared__ float part[2][4][S];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = wave / S, q = wave % S;
+    const int64_t row = (int64_t)blockIdx.x * 4 + r;
+    const bool live = row < M;
+    const int64_t c0 = (int64_t)q * 64 * NV + lane;
+    float xv[NV];
+    float sm = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int64_t i = c0 + 64 * j;
+        xv[j] = (live && i < N) ? x[row * N + i] : 0.0f;
+        sm += xv[j];
+    }
+    sm = hv_wave_sum(sm);
+    if (lane == 0) part[0][r][q] = sm;
+    __syncthreads();
+    float tot = part[0][r][0];
+#pragma unroll
+    for (int k = 1; k < S; k++) tot += part[0][r][k];
+    const float mu = tot / (float)N;
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const float d = xv[j] - mu;
+        if (c0 + 64 * j < N) v += d * d;
+    }
+    v = hv_wave_sum(v);
+    if (lane == 0) part[1][r][q] = v;
+    __syncthreads();
+    float vt = part[1][r][0];
+#pragma unroll
+    for (int k = 1; k < S; k++) vt += part[1][r][k];
+    const float rs = 1.0f / sqrtf(vt / (float)N + eps);
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int64_t i = c0 + 64 * j;
+        if (i < N) {
+            float o = (xv[j] - mu) * rs * gamma[i] + beta[i];
+            if (relu) o = fmaxf(o, 0.0f);
+            if (mask != nullptr) o = o * (mask[row * N + i] * scale);
+            else if (drop.state != nullptr) o = hv_drop_keep(drop, (unsigned long long)(row * N + i)) ? o * scale : 0.0f;
+            if (res != nullptr) o = o + res[row * N + i];
+            y[row * N + i] = o;
+        }
+    }
+    if (q == 0 && lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
 // gh = gy * mask*scale * (h > 0 if relu), h = xhat*gamma+beta;  dy = gh*gamma
 // gx = rstd * (dy - mean(dy) - xhat * mean(dy*xhat))
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *gy, const float *x, const float *gamma, const float *beta,
@@ -300,16 +356,110 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float *g
                                  gy2, gsum);
 }
 
+// the fused backward with a row shared by S waves (see layernorm_fwd_split_kernel): a workgroup is 4 rows x S waves; the two row sums are
+// added over the S slices in ascending order through LDS, the column partials over the 4 rows exactly as in the one-wave-per-row form
+template <int NV, int S>
+__global__ __launch_bounds__(256 * S) void layernorm_bwd_split_kernel(const float *gy, const float *x, const float *gamma, const float *beta,
+                                                                      const float *mean, const float *rstd, int64_t M, int64_t N, int relu,
+                                                                      const float *mask, float scale, float *gx, float *part,
+                                                                      const float *yout, float in_relu_scale, const float *gy2, float *gsum) {
+    constexpr int W = 64 * NV * S;  // columns the workgroup covers
+    __shared__ float red[2 * 3 * W];
+    __shared__ float rsum[2][4][S];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = wave / S, q = wave % S;
+    const int64_t blk = blockIdx.x, row = blk * LNF_ROWS + r;
+    const bool live = row < M;
+    const int c0 = q * 64 * NV + lane;
+    float g[NV], xh[NV], ga[NV];
+    unsigned xpos = 0u;
+    float s1 = 0.0f, s2 = 0.0f, rs = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int c = c0 + 64 * j;
+        g[j] = 0.0f;
+        xh[j] = 0.0f;
+        ga[j] = c < N ? gamma[c] : 0.0f;
+    }
+    if (live) {
+        const float mu = mean[row];
+        rs = rstd[row];
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int c = c0 + 64 * j;
+            if (c < N) {
+                const float xraw = x[row * N + c];
+                if (xraw > 0.0f) xpos |= 1u << j;
+                xh[j] = (xraw - mu) * rs;
+                float gv = gy[row * N + c];
+                if (gy2 != nullptr) gv += gy2[row * N + c];
+                if (gsum != nullptr) gsum[row * N + c] = gv;
+                if (yout != nullptr) {
+                    if (relu) gv = yout[row * N + c] > 0.0f ? gv * scale : 0.0f;
+                } else {
+                    if (mask != nullptr) gv = gv * (mask[row * N + c] * scale);
+                    if (relu && !(xh[j] * ga[j] + beta[c] > 0.0f)) gv = 0.0f;
+                }
+                g[j] = gv;
+                const float dy = gv * ga[j];
+                s1 += dy;
+                s2 += dy * xh[j];
+            }
+        }
+    }
+    s1 = hv_wave_sum(s1);
+    s2 = hv_wave_sum(s2);
+    if (lane == 0) { rsum[0][r][q] = s1; rsum[1][r][q] = s2; }
+    __syncthreads();
+    s1 = rsum[0][r][0];
+    s2 = rsum[1][r][0];
+#pragma unroll
+    for (int k = 1; k < S; k++) { s1 += rsum[0][r][k]; s2 += rsum[1][r][k]; }
+    s1 = s1 / (float)N;
+    s2 = s2 / (float)N;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int c = c0 + 64 * j;
+        if (live && c < N && gx != nullptr) {
+            float o = rs * ((g[j] * ga[j] - s1) - xh[j] * s2);
+            if (in_relu_scale != 0.0f) o = ((xpos >> j) & 1u) ? o * in_relu_scale : 0.0f;
+            gx[row * N + c] = o;
+        }
+        const float tg = 0.0f + g[j] * xh[j], tb = 0.0f + g[j];
+        if (r > 0) {
+            red[(0 * 3 + r - 1) * W + c] = tg;
+            red[(1 * 3 + r - 1) * W + c] = tb;
+        } else {
+            g[j] = tg;
+            xh[j] = tb;
+        }
+    }
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int c = c0 + 64 * j;
+            if (c < N) {
+                part[(blk * 2 + 0) * N + c] = (g[j] + red[(0 * 3 + 0) * W + c]) + (red[(0 * 3 + 1) * W + c] + red[(0 * 3 + 2) * W + c]);
+                part[(blk * 2 + 1) * N + c] = (xh[j] + red[(1 * 3 + 0) * W + c]) + (red[(1 * 3 + 1) * W + c] + red[(1 * 3 + 2) * W + c]);
+            }
+        }
+    }
+}
+
 static void launch_layernorm_bwd_fused(int64_t chunks, hipStream_t s, const float *gy, const float *x, const float *gamma, const float *beta,
                                        const float *mean, const float *rstd, int64_t M, int64_t N, int relu, const float *mask, float scale,
                                        float *gx, float *part, const float *yout, float in_relu_scale, const float *gy2, float *gsum) {
     const dim3 grid((unsigned)chunks), block(256);
 #define HV_LNB(NVV) hipLaunchKernelGGL(layernorm_bwd_fused_kernel<NVV>, grid, block, 0, s, gy, x, gamma, beta, mean, rstd, M, N, relu, mask, scale, gx, \
                                        part, yout, in_relu_scale, gy2, gsum)
+#define HV_LNS(NVV, SS) hipLaunchKernelGGL((layernorm_bwd_split_kernel<NVV, SS>), grid, dim3(256 * SS), 0, s, gy, x, gamma, beta, mean, rstd, M, N, relu, \
+                                           mask, scale, gx, part, yout, in_relu_scale, gy2, gsum)
+    const bool split = M <= 16384;  // few rows: share a row between waves (more waves in flight); many rows: one wave per row fills the chip
     if (N <= 256) HV_LNB(4);
-    else if (N <= 512) HV_LNB(8);
-    else if (N <= 768) HV_LNB(12);
-    else HV_LNB(16);
+    else if (N <= 512) { if (split) HV_LNS(4, 2); else HV_LNB(8); }
+    else if (N <= 768) { if (split) HV_LNS(3, 4); else HV_LNB(12); }
+    else { if (split) HV_LNS(4, 4); else HV_LNB(16); }
+#undef HV_LNS
 #undef HV_LNB
 }
 // 32 columns x 32 chunk groups per workgroup: group q adds chunks q, q+32, ... in ascending order, then the groups are added
@@ -1018,7 +1168,17 @@ extern "C" int hidvae_layernorm_fwd(const float *x, int64_t M, int64_t N, const 
     HV_REQUIRE(x && gamma && beta && y && mean && rstd && M >= 1 && N >= 1, "layernorm_fwd: bad arguments");
     HV_REQUIRE(!(keep_mask && rng_state), "layernorm_fwd: a keep-mask OR the in-kernel generator, not both");
     const HvDrop drop{rng_state, rng_site, drop_threshold};
-    if (N <= 1024)
+    const dim3 grid4((unsigned)hv_cdiv(M, 4));
+    if (N > 256 && N <= 512 && M <= 16384)
+        hipLaunchKernelGGL((layernorm_fwd_split_kernel<4, 2>), grid4, dim3(512), 0, (hipStream_t)stream, x, M, N, gamma, beta, eps, y, mean, rstd,
+                           relu, keep_mask, keep_scale, residual, drop);
+    else if (N > 512 && N <= 768 && M <= 16384)
+        hipLaunchKernelGGL((layernorm_fwd_split_kernel<3, 4>), grid4, dim3(1024), 0, (hipStream_t)stream, x, M, N, gamma, beta, eps, y, mean, rstd,
+                           relu, keep_mask, keep_scale, residual, drop);
+    else if (N > 768 && N <= 1024 && M <= 16384)
+        hipLaunchKernelGGL((layernorm_fwd_split_kernel<4, 4>), grid4, dim3(1024), 0, (hipStream_t)stream, x, M, N, gamma, beta, eps, y, mean, rstd,
+                           relu, keep_mask, keep_scale, residual, drop);
+    else if (N <= 1024)
         hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, N, gamma, beta,
                            eps, y, mean, rstd, relu, keep_mask, keep_scale, residual, drop);
     else
