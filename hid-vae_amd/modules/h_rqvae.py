@@ -309,9 +309,9 @@ class HRqVae(nn.Module, _HubMixin):
                           self._normalize_flags(), want_res, getattr(self, "_prepared", None), getattr(self, "_heads_port", None),
                           *self._tables())
 
-    def _tag_heads(self, emb_cat, tags_emb, tags_indices, defer_join=False, port=None, loss_grad=None):
+    def _tag_heads(self, emb_cat, tags_emb, tags_indices, defer_join=False, port=None, loss_grad=None, projs=None):
         from ..tagpath import tag_heads_forward
-        return tag_heads_forward(self, emb_cat, tags_emb, tags_indices, defer_join=defer_join, port=port, loss_grad=loss_grad)
+        return tag_heads_forward(self, emb_cat, tags_emb, tags_indices, defer_join=defer_join, port=port, loss_grad=loss_grad, projs=projs)
 
     def get_semantic_ids(self, encoded_x: Tensor, tags_emb: Optional[Tensor] = None, tags_indices: Optional[Tensor] = None,
                          gumbel_t: float = 0.001) -> HRqVaeOutput:
@@ -380,6 +380,10 @@ class HRqVae(nn.Module, _HubMixin):
             self._heads_port = HeadsGradPort((x.shape[0], self.n_layers * self.embed_dim))
         else:
             self._heads_port = None
+        early_projs = None
+        if early_heads:  # the projectors need only the batch: beside the encoder, on the level streams (tagpath.tag_projectors_early)
+            from ..tagpath import tag_projectors_early
+            early_projs = tag_projectors_early(self, tags_emb.float(), self._rand())
         y_dec = None
         embs_norm = p_unique = None  # (the fused middle launch produces them itself when it can)
         fused = self._bottleneck_ok(x)
@@ -405,7 +409,7 @@ class HRqVae(nn.Module, _HubMixin):
         tag_scalars, tag_join = (), None
         if tagged:
             tag_scalars, tag_join = self._tag_heads(emb_cat, tags_emb.float(), tags_indices, defer_join=True, port=self._heads_port,
-                                                    loss_grad=hint if early_heads else None)  # (A_0.., P_0.., acc_0..)
+                                                    loss_grad=hint if early_heads else None, projs=early_projs)  # (A_0.., P_0.., acc_0..)
         self._heads_port = None
         if fused:
             dec_in = self._cut_here(pre_d1)

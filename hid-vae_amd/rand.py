@@ -3,6 +3,8 @@ The reference pulls them from torch's global generator (nn.Dropout, torch.randpe
 modules/loss.py:144-147); a device stream can never reproduce a CPU stream, so the kernels take masks / pairings as
 INPUTS and the provider is injectable -- parity tests inject the formula provider that also drove the reference when the
 golden vectors were captured."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -53,6 +55,17 @@ class DeviceRand:
         spec = _C.DropSpec(self.state(device), self._site, p)
         self._site += 1
         return spec
+
+    @contextlib.contextmanager
+    def at_site(self, base):
+        """number the dropout layers requested inside from `base` on: the tag heads give every unit of work (level i's projector, level
+        i's predictor) a block of site numbers of its own, so the draws do not depend on the ORDER the units are issued in (the projectors
+        run ahead of the encoder when they can: tagpath.tag_projectors_early).  Sites stay unique per step either way."""
+        saved, self._site = self._site, int(base)
+        try:
+            yield self
+        finally:
+            self._site = max(saved, self._site)
 
     def _lam(self, device, n):
         if self._beta is None:  # built once (a host->device scalar copy is not allowed inside a graph capture)
@@ -115,6 +128,10 @@ class InjectedRand:
 
     def __init__(self, source):
         self.source = source
+
+    @contextlib.contextmanager
+    def at_site(self, base):  # the injected draws are numbered in CALL order (as the reference consumed them): nothing to scope
+        yield self
 
     def dropout_keep(self, shape, p, device):
         return self.source.dropout_keep(shape, p).to(device)

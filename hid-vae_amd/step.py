@@ -147,6 +147,15 @@ class GraphedTrainStep:
         _C.phase_mark("adamw done")
 
     def _capture(self):
+        if self.dp is not None and not getattr(self, "_settled", False):
+            # The process group's watchdog thread polls the completion events of the collectives the eager warm-up steps issued; an event
+            # query from ANOTHER thread while this one is capturing is an error on this runtime and takes the process down (seen as an
+            # intermittent abort of the first captured data-parallel step, main thread anywhere inside the capture).  The device is idle
+            # (the caller synchronised): give the watchdog a few of its 100 ms polling periods to retire that work before capturing.
+            import time
+            torch.cuda.synchronize()
+            time.sleep(0.5)
+            self._settled = True
         if self.dp is not None and self._collectives_capturable() and not getattr(self, "_in_graph_failed", False):
             g1 = torch.cuda.CUDAGraph()
             try:

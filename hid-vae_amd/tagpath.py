@@ -542,6 +542,44 @@ def join_tag_streams(device):
         main.wait_stream(st)
 
 
+def _sites(rand, level, kind):
+    """the block of dropout-site numbers of one unit of work (see rand.DeviceRand.at_site); providers without site numbers: no-op"""
+    scope = getattr(rand, "at_site", None)
+    return scope(32 * level + (16 if kind == "pred" else 0)) if scope is not None else contextlib.nullcontext()
+
+
+def tag_projectors_early(model, tags_emb, rand):
+    """The projectors read only the batch's tag embeddings, not the model's encoder: with every level on a stream of its own they are
+    issued at the START of the forward, beside the encoder and the quantiser (78 us during which the level streams had nothing to do),
+    instead of after them.  -> {level: projected tags} for the levels that went early, or None (a provider whose draws are numbered in call order -- the parity tests'
+    injected masks -- keeps the reference's order: projector i right before InfoNCE i).  Needs early_rand to have issued this step's
+    generator advance on the first tag stream."""
+    L = model.n_layers
+    if not (hasattr(rand, "at_site") and hasattr(rand, "state") and getattr(rand, "_early", False)) or L < 2 or tags_emb.dim() != 3:
+        return None
+    ev = getattr(rand, "_advanced", None)
+    if ev is None:
+        return None
+    B = tags_emb.shape[0]
+    te = tags_emb.reshape(B, -1)
+    E = model.tag_embed_dim
+    side = _tag_streams(tags_emb.device, L + 1)
+    main = torch.cuda.current_stream()
+    out = {}
+    # (levels 1.. only: the replayed graph runs on three hardware queues, and during the encoder the caller's stream, the first tag
+    #  stream -- busy with the step's random draws -- and two projectors are what fits: all three projectors early starve the encoder,
+    #  78 -> 147 us, and the step gains nothing (1.201 vs 1.204 ms); levels 1 and 2 early: 1.19 ms)
+    for i in range(1, L):
+        st = side[i + 1]
+        st.wait_stream(main)  # the batch is in place
+        if i > 0:
+            st.wait_event(ev)  # this step's generator advance (first tag stream)
+        tags_emb.record_stream(st)
+        with torch.cuda.stream(st), _sites(rand, i, "align"):
+            out[i] = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], model.training, rand)
+    return out
+
+
 def early_rand(rand, targets, device, n_levels, want_mixup):
     """The step's random draws need nothing from the model: the generator's step counter (one tiny launch) and the mixup pairing (one
     launch; needs only the tag indices) are issued at the START of the forward on the first tag stream, where they run beside the
@@ -556,6 +594,8 @@ def early_rand(rand, targets, device, n_levels, want_mixup):
     targets.record_stream(st[1])
     with torch.cuda.stream(st[1]):
         rand.begin_step(device)
+        rand._advanced = torch.cuda.Event()  # (what the other levels' early projectors wait for: not the mixup launch behind it)
+        rand._advanced.record(st[1])
         made = []
         if want_mixup:
             rand.prepare_mixup(targets, device)
@@ -569,7 +609,7 @@ def early_rand(rand, targets, device, n_levels, want_mixup):
     return True
 
 
-def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, port=None, loss_grad=None):
+def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, port=None, loss_grad=None, projs=None):
     """-> tuple (A_0..A_{L-1}, P_0..P_{L-1}, acc_0..acc_{L-1}) of 0-d device tensors.
     defer_join: -> (that tuple, join) where join() makes the caller's stream wait for the level branches; the caller issues its own
     work (the decoder) in between, so it runs beside the branches.
@@ -652,11 +692,16 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
                 with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
                     if kind == "align":
                         _C.phase_mark(f"fwd:level {i} start")
-                        proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
+                        if projs is not None and i in projs:
+                            proj = projs[i]  # (issued on this stream at the start of the forward: tag_projectors_early)
+                        else:
+                            with _sites(rand, i, "align"):
+                                proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
                         scal[(kind, i)] = (model.tag_alignment_loss(views[2 * i], proj, i),)
                         _C.phase_mark(f"fwd:level {i} projector+infonce done")
                     else:
-                        logits = tag_predictor_forward(model.tag_predictors[i], views[2 * i + 1], None, rand)
+                        with _sites(rand, i, "pred"):
+                            logits = tag_predictor_forward(model.tag_predictors[i], views[2 * i + 1], None, rand)
                         scal[(kind, i)] = tag_prediction_loss(model.tag_prediction_loss, logits, ti_rows[i], 0, rand, level=i)
                         _C.phase_mark(f"fwd:level {i} done")
                 if st is not None:
@@ -704,10 +749,12 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
         with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
             c_nce, c_att = views[2 * i], views[2 * i + 1]
             _C.phase_mark(f"fwd:level {i} start")
-            proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
+            with _sites(rand, i, "align"):
+                proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
             align = model.tag_alignment_loss(c_nce, proj, i)
             _C.phase_mark(f"fwd:level {i} projector+infonce done")
-            logits = tag_predictor_forward(model.tag_predictors[i], c_att, None, rand)
+            with _sites(rand, i, "pred"):
+                logits = tag_predictor_forward(model.tag_predictors[i], c_att, None, rand)
             loss, acc = tag_prediction_loss(model.tag_prediction_loss, logits, ti_rows[i], 0, rand, level=i)
             _C.phase_mark(f"fwd:level {i} done")
         if st is not None:
