@@ -78,24 +78,30 @@ def _run(tagged, dp_mode, steps=6, B=128, in_graph=True):
     return torch.stack(rows).cpu(), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
 
 
-@pytest.mark.parametrize("in_graph", [True, False], ids=["collectives_in_the_graph", "collectives_between_graphs"])
-@pytest.mark.parametrize("tagged", [False, True], ids=["untagged", "tagged"])
-def test_overlapped_dp_step_equals_the_plain_step_bit_for_bit(tagged, in_graph):
+def _one_rank_rccl_worker(rank, port, tagged, in_graph):
+    """body of test_overlapped_dp_step_equals_the_plain_step_bit_for_bit, in a process of its own: a process group (RCCL: watchdog and
+    proxy threads) lives and dies with it instead of being created and destroyed inside the pytest process"""
+    sys.path.insert(0, ROOT)
     import torch.distributed as dist
-    created = False
-    if not dist.is_initialized():
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL, one rank: the --dist 1 rehearsal as a test
-        created = True
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL, one rank: the --dist 1 rehearsal as a test
     try:
         rows1, sd1 = _run(tagged, "overlap", in_graph=in_graph)
         rows0, sd0 = _run(tagged, None)
     finally:
-        if created:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
     assert torch.equal(rows1, rows0), "logged loss rows differ between the overlapped DP step and the plain step"
     for k in sd0:
         assert torch.equal(sd1[k], sd0[k]), k
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("in_graph", [True, False], ids=["collectives_in_the_graph", "collectives_between_graphs"])
+@pytest.mark.parametrize("tagged", [False, True], ids=["untagged", "tagged"])
+def test_overlapped_dp_step_equals_the_plain_step_bit_for_bit(tagged, in_graph):
+    import torch.multiprocessing as mp
+    mp.spawn(_one_rank_rccl_worker, args=(_free_port(), tagged, in_graph), nprocs=1, join=True)
 
 
 def _rank_worker(rank, world, port, out_dir, steps, B, tagged=False):
