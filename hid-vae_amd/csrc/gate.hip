@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int GATE_ROWS = 8;  // rows per workgroup (4 waves x 2)
+constexpr int GATE_ROWS = 4;  // rows per workgroup (one per wave: 256 workgroups at 1024 rows; two per wave left half the CUs without one)
 
 struct GateArgs {
     const float *x; int64_t ldx;
