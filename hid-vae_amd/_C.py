@@ -39,6 +39,8 @@ _SIGNATURES = {
     "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_total_loss_bwd": [_vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _i, _vp],
     "hidvae_codebook_grad": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
+    "hidvae_l2norm_fwd_pair": [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _f, _vp],
+    "hidvae_l2norm_bwd_pair": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _f, _vp],
     "hidvae_recon_fwd_bwd": [_vp, _vp, _i64, _i64, _i, _f, _vp, _i64, _vp, _vp, _vp, _vp],
     "hidvae_l2norm_fwd": [_vp, _i64, _i64, _i64, _f, _vp, _i64, _vp, _vp],
     "hidvae_l2norm32_fwd": [_vp, _i64, _i64, _f, _vp, _i64, _vp, _vp],
@@ -696,6 +698,27 @@ def l2norm_fwd(x, eps=1e-12):
     else:
         _check(lib().hidvae_l2norm_fwd(_p(x), M, N, ldx, float(eps), _p(out), N, _p(norms), _stream()), "hidvae_l2norm_fwd")
     return out, norms
+
+
+def l2norm_fwd_pair(x0, x1, eps=1e-12):
+    """two row normalisations of the same number of rows in one launch -> (out0, norms0, out1, norms1)"""
+    _f32(x0, "x0"), _f32(x1, "x1")
+    M = x0.shape[0]
+    if x1.shape[0] != M or x0.dim() != 2 or x1.dim() != 2:
+        raise RuntimeError(f"l2norm_fwd_pair: row counts differ ({tuple(x0.shape)} vs {tuple(x1.shape)})")
+    f = lambda *shape: torch.empty(shape, device=x0.device, dtype=torch.float32)
+    o0, n0, o1, n1 = f(M, x0.shape[1]), f(M), f(M, x1.shape[1]), f(M)
+    _check(lib().hidvae_l2norm_fwd_pair(_p(x0), _row_stride(x0, "x0"), x0.shape[1], _p(o0), _p(n0), _p(x1), _row_stride(x1, "x1"), x1.shape[1],
+                                        _p(o1), _p(n1), M, float(eps), _stream()), "hidvae_l2norm_fwd_pair")
+    return o0, n0, o1, n1
+
+
+def l2norm_bwd_pair(g0, out0, norms0, g1, out1, norms1, eps=1e-12):
+    M = out0.shape[0]
+    gx0, gx1 = torch.empty_like(out0), torch.empty_like(out1)
+    _check(lib().hidvae_l2norm_bwd_pair(_p(g0), _row_stride(g0, "g0"), _p(out0), _p(norms0), out0.shape[1], _p(gx0), _p(g1), _row_stride(g1, "g1"),
+                                        _p(out1), _p(norms1), out1.shape[1], _p(gx1), M, float(eps), _stream()), "hidvae_l2norm_bwd_pair")
+    return gx0, gx1
 
 
 def l2norm_bwd(g, out, norms, eps=1e-12, gx=None, accumulate=False):

@@ -183,6 +183,50 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *g, int64_t
     }
 }
 
+// two independent row normalisations of M rows each in ONE launch (InfoNCE normalises the codebook embeddings and the projected tags,
+// loss.py:66-67; their backward likewise): problem 0 on the first ceil(M/4) workgroups, problem 1 on the rest; per row exactly the
+// arithmetic of l2norm_fwd_kernel / l2norm_bwd_kernel
+struct L2Pair {
+    const float *a[2]; int64_t lda[2];   // fwd: x;  bwd: g
+    const float *b[2]; int64_t ldb[2];   // bwd: out (the normalised rows)
+    const float *norms_in[2];            // bwd
+    float *out[2]; int64_t ldo[2];       // fwd: out;  bwd: gx
+    float *norms_out[2];                 // fwd
+    int64_t N[2];
+    int64_t M;
+    float eps;
+};
+__global__ __launch_bounds__(256) void l2norm_fwd_pair_kernel(L2Pair p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t per = (p.M + 3) / 4;
+    const int k = (int64_t)blockIdx.x >= per ? 1 : 0;
+    const int64_t row = ((int64_t)blockIdx.x - k * per) * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const float *x = p.a[k] + row * p.lda[k];
+    const int64_t N = p.N[k];
+    float ss = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) ss += x[i] * x[i];
+    ss = hv_wave_sum(ss);
+    const float nrm = sqrtf(ss), den = fmaxf(nrm, p.eps);
+    for (int64_t i = lane; i < N; i += 64) p.out[k][row * p.ldo[k] + i] = x[i] / den;
+    if (lane == 0) p.norms_out[k][row] = nrm;
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_pair_kernel(L2Pair p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t per = (p.M + 3) / 4;
+    const int k = (int64_t)blockIdx.x >= per ? 1 : 0;
+    const int64_t row = ((int64_t)blockIdx.x - k * per) * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const float *g = p.a[k] + row * p.lda[k], *o = p.b[k] + row * p.ldb[k];
+    const int64_t N = p.N[k];
+    float t = 0.0f;
+    for (int64_t i = lane; i < N; i += 64) t += o[i] * g[i];
+    t = hv_wave_sum(t);
+    const float nrm = p.norms_in[k][row];
+    const float den = fmaxf(nrm, p.eps), proj = nrm > p.eps ? t : 0.0f;
+    for (int64_t i = lane; i < N; i += 64) p.out[k][row * p.ldo[k] + i] = (g[i] - o[i] * proj) / den;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // AdamW.  blockIdx.y = tensor, blockIdx.x strides over its elements.
 // ---------------------------------------------------------------------------------------------------
@@ -419,6 +463,35 @@ extern "C" int hidvae_l2norm_fwd(const float *x, int64_t M, int64_t N, int64_t l
     hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)hv_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, M, N, ldx, eps, out,
                        ldo, norms);
     HV_LAUNCH_CHECK("l2norm_fwd");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_l2norm_fwd_pair(const float *x0, int64_t ldx0, int64_t N0, float *out0, float *norms0, const float *x1, int64_t ldx1,
+                                      int64_t N1, float *out1, float *norms1, int64_t M, float eps, void *stream) {
+    HV_REQUIRE(x0 && x1 && out0 && out1 && norms0 && norms1 && M >= 1 && N0 >= 1 && N1 >= 1 && ldx0 >= N0 && ldx1 >= N1, "l2norm_fwd_pair: bad arguments");
+    L2Pair p{};
+    p.a[0] = x0; p.lda[0] = ldx0; p.a[1] = x1; p.lda[1] = ldx1;
+    p.out[0] = out0; p.ldo[0] = N0; p.out[1] = out1; p.ldo[1] = N1;
+    p.norms_out[0] = norms0; p.norms_out[1] = norms1;
+    p.N[0] = N0; p.N[1] = N1; p.M = M; p.eps = eps;
+    hipLaunchKernelGGL(l2norm_fwd_pair_kernel, dim3((unsigned)(2 * hv_cdiv(M, 4))), dim3(256), 0, (hipStream_t)stream, p);
+    HV_LAUNCH_CHECK("l2norm_fwd_pair");
+    return HIDVAE_OK;
+}
+
+extern "C" int hidvae_l2norm_bwd_pair(const float *g0, int64_t ldg0, const float *out0, const float *norms0, int64_t N0, float *gx0,
+                                      const float *g1, int64_t ldg1, const float *out1, const float *norms1, int64_t N1, float *gx1, int64_t M,
+                                      float eps, void *stream) {
+    HV_REQUIRE(g0 && g1 && out0 && out1 && norms0 && norms1 && gx0 && gx1 && M >= 1 && N0 >= 1 && N1 >= 1 && ldg0 >= N0 && ldg1 >= N1,
+               "l2norm_bwd_pair: bad arguments");
+    L2Pair p{};
+    p.a[0] = g0; p.lda[0] = ldg0; p.a[1] = g1; p.lda[1] = ldg1;
+    p.b[0] = out0; p.ldb[0] = N0; p.b[1] = out1; p.ldb[1] = N1;
+    p.norms_in[0] = norms0; p.norms_in[1] = norms1;
+    p.out[0] = gx0; p.ldo[0] = N0; p.out[1] = gx1; p.ldo[1] = N1;
+    p.N[0] = N0; p.N[1] = N1; p.M = M; p.eps = eps;
+    hipLaunchKernelGGL(l2norm_bwd_pair_kernel, dim3((unsigned)(2 * hv_cdiv(M, 4))), dim3(256), 0, (hipStream_t)stream, p);
+    HV_LAUNCH_CHECK("l2norm_bwd_pair");
     return HIDVAE_OK;
 }
 

@@ -341,8 +341,7 @@ class InfoNCEFn(Function):
     @staticmethod
     def forward(ctx, c, t, tau, scale):
         ctx.set_materialize_grads(False)
-        cn, nc = _C.l2norm_fwd(c)
-        tn, nt = _C.l2norm_fwd(t)
+        cn, nc, tn, nt = _C.l2norm_fwd_pair(c, t)  # both normalisations in one launch
         B = cn.shape[0]
         ctx.cfg = (tau, scale)
         if B >= INFONCE_CHUNK_FROM:
@@ -393,6 +392,12 @@ class InfoNCEFn(Function):
             return gc, gt, None, None
         cn, nc, tn, nt, P = ctx.saved_tensors
         dS = _C.infonce_dlogits(P, tau, scale, g.contiguous())
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # d cn = dS tn and d tn = dS^T cn are the dX and the dW of one "Linear" whose weight is tn: ONE paired launch; then both
+            # normalisations' backward in one launch (5 launches -> 3)
+            gtn, gcn = _C.linear_bwd(dS, cn, tn, True)
+            gc, gt = _C.l2norm_bwd_pair(gcn, cn, nc, gtn, tn, nt)
+            return gc, gt, None, None
         if ctx.needs_input_grad[0]:
             gc = _C.l2norm_bwd(_C.gemm(_C.GEMM_NN, dS, tn, split_k=0), cn, nc)
         if ctx.needs_input_grad[1]:

@@ -246,6 +246,13 @@ int hidvae_l2norm32_fwd(const float *x, int64_t M, int64_t ldx, float eps, float
                         void *stream);
 int hidvae_l2norm_bwd(const float *g, int64_t ldg, const float *out, int64_t ldo, const float *norms,
                       int64_t M, int64_t N, float eps, float *gx, int64_t ldgx, int accumulate, void *stream);
+/* two such normalisations of M rows each (widths N0, N1; contiguous outputs) in ONE launch, and their backward: TagAlignmentLoss
+ * normalises the concatenated codebook embeddings and the projected tags side by side (loss.py:66-67).  Per row the arithmetic of
+ * hidvae_l2norm_fwd / hidvae_l2norm_bwd (generic summation order at every width). */
+int hidvae_l2norm_fwd_pair(const float *x0, int64_t ldx0, int64_t N0, float *out0, float *norms0, const float *x1, int64_t ldx1, int64_t N1,
+                           float *out1, float *norms1, int64_t M, float eps, void *stream);
+int hidvae_l2norm_bwd_pair(const float *g0, int64_t ldg0, const float *out0, const float *norms0, int64_t N0, float *gx0, const float *g1,
+                           int64_t ldg1, const float *out1, const float *norms1, int64_t N1, float *gx1, int64_t M, float eps, void *stream);
 
 /* ---- a12: SemanticIdUniquenessLoss exactly as HRqVae.forward calls it (h_rqvae.py:41-105 with the [L,B]
  * transposed ids of :630-631): level pairs (a<b) whose id vectors agree over the whole batch contribute

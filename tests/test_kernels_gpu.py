@@ -250,6 +250,23 @@ def test_categorical_decoder_tail_against_autograd(C, B, N, c):
         C.recon_fwd_bwd(dev(y), dev(x), n_cat=N)
 
 
+def test_l2norm_pair_launches_equal_the_single_launches(C):
+    """two row normalisations (and their backward) in one launch each -- what TagAlignmentLoss issues -- against the one-problem entry
+    points, bit for bit, incl. a strided first operand (a column prefix of emb_cat)"""
+    base = dev(fill.gauss((300, 96), 91))
+    c = base[:, :64]                      # row stride 96
+    t = dev(fill.gauss((300, 40), 92))
+    oc, nc, ot, nt = C.l2norm_fwd_pair(c, t)
+    rc, rnc = C.l2norm_fwd(c.contiguous())
+    rt, rnt = C.l2norm_fwd(t)
+    assert torch.equal(oc, rc) and torch.equal(nc, rnc) and torch.equal(ot, rt) and torch.equal(nt, rnt)
+    gc, gt = dev(fill.gauss((300, 64), 93)), dev(fill.gauss((300, 40), 94))
+    xc, xt = C.l2norm_bwd_pair(gc, oc, nc, gt, ot, nt)
+    assert torch.equal(xc, C.l2norm_bwd(gc, rc, rnc)) and torch.equal(xt, C.l2norm_bwd(gt, rt, rnt))
+    with pytest.raises(RuntimeError):
+        C.l2norm_fwd_pair(c, t[:10])
+
+
 def test_id_stats(C):
     ids = torch.from_numpy(fill.ints((5000, 3), 50, 12)).cuda()
     emb = dev(fill.gauss((5000, 96), 51))
