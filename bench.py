@@ -53,6 +53,10 @@ def parse():
                     "`large_batch_step`; 0 = skip): shows the throughput-bound regime next to the latency-bound headline batch")
     ap.add_argument("--also-other", type=int, default=1, help="also time the other variant of the step (untagged core when --tagged 1, "
                     "tagged when --tagged 0), reported as `untagged_core_step` / `tagged_step`")
+    ap.add_argument("--also-tagged", dest="also_other", type=int, help=argparse.SUPPRESS)  # round 1-2 name of --also-other (scratch/r3/*.sh)
+    ap.add_argument("--time-limit", type=float, default=float(os.environ.get("HIDVAE_BENCH_TIME_LIMIT", "900")),
+                    help="launcher only (--gpus N without torch.distributed.run): seconds after which the rank processes are terminated "
+                         "and the launcher exits non-zero -- a rank stuck in a collective must not hold the job (0 = no limit)")
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the MEDIAN window is reported")
     return ap.parse_args()
 
@@ -431,7 +435,7 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv, child=None, env=None):
+def launch_ranks(n, argv, child=None, env=None, time_limit=None):
     """`python bench.py --gpus N` with no launcher around it: start N rank processes, one per device, and relay rank 0's JSON line.
 
     Runs BEFORE anything in this process touches the GPU (the parent never does: it only waits).  Every child is this script again
@@ -439,7 +443,9 @@ def launch_ranks(n, argv, child=None, env=None):
     --nproc-per-node N` gives it, so both ways of starting the N > 1 bench run the same code.  (The reference gets its ranks from
     `accelerate launch`, train_hidvae.py:186-189.)  Rank 0's stdout is relayed to ours, the other ranks' stdout goes to stderr; the
     exit code is the first non-zero child code; when one rank dies the others are terminated (by PID) instead of left waiting in a
-    collective.  `child` replaces the command (tests)."""
+    collective.  time_limit (seconds): a run that is still going then -- a rank stuck in a collective or in a capture, which no
+    exception handler inside the rank can catch -- is terminated (SIGTERM, then SIGKILL, by PID: the children are fresh processes of
+    this launcher, nothing is re-executed) and the launcher returns 124, the code `timeout` uses.  `child` replaces the command (tests)."""
     import subprocess
     base = dict(os.environ if env is None else env)
     base.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -460,9 +466,20 @@ def launch_ranks(n, argv, child=None, env=None):
     pump = threading.Thread(target=relay, daemon=True)
     pump.start()
     rc = 0
+    deadline = time.monotonic() + time_limit if time_limit else None
     try:
         pending = list(procs)
         while pending:
+            if deadline is not None and time.monotonic() > deadline:
+                print(f"[bench] the {n}-rank run exceeded its time limit of {time_limit:.0f} s "
+                      f"(ranks still running: {[procs.index(p) for p in pending]}); terminating them", file=sys.stderr, flush=True)
+                for q in pending:
+                    q.terminate()
+                t_kill = time.monotonic() + 10
+                while any(q.poll() is None for q in pending) and time.monotonic() < t_kill:
+                    time.sleep(0.05)
+                rc = 124
+                break
             for p in list(pending):
                 code = p.poll()
                 if code is None:
@@ -485,14 +502,21 @@ def launch_ranks(n, argv, child=None, env=None):
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher: become one (before any GPU call in this process; device_count() does not initialise the GPU)
+        # no launcher: become one.  (device_count() may call hipGetDeviceCount here; that is harmless because this process only spawns
+        # children and never execs or launches anything itself)
         if os.environ.get("HIDVAE_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
             print(f"[bench] --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible (RCCL wants one device per rank)", file=sys.stderr)
             sys.exit(2)
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], time_limit=args.time_limit or None))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.time_limit:
+        # a rank of a multi-rank run (our launcher's child, or torch.distributed.run's): a hang in a collective or in a graph capture
+        # raises nothing, so nothing below could handle it -- after the limit this prints every thread's stack and ends the process
+        # with a non-zero code (the launcher / the elastic agent then stops the other ranks)
+        import faulthandler
+        faulthandler.dump_traceback_later(args.time_limit, exit=True)
     if args.gpus != world and not (args.gpus == 1 and world == 1):
         if "WORLD_SIZE" in os.environ and args.gpus > 1:
             print(f"[bench] --gpus {args.gpus} disagrees with WORLD_SIZE={world} of the launcher", file=sys.stderr)
@@ -623,11 +647,17 @@ def main():
             line["large_batch_step"] = large_extra
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        degraded = bool(args.graph) and not use_graph  # the step could not be captured and ran eagerly (host-bound, ~6x slower)
+        if degraded:
+            line["degraded"] = True
         print(json.dumps(line), flush=True)
     if dist is not None:
         if world > 1:
             dist.barrier()  # the other ranks wait for rank 0's kernel timings instead of tearing the group down under it
         dist.destroy_process_group()
+    if bool(args.graph) and not use_graph:
+        print("[bench] the step was asked to replay from a HIP graph and could not be captured: the line above is marked degraded", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

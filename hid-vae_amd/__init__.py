@@ -7,20 +7,79 @@ import os
 import sys
 
 
-def _runtime_defaults():
-    """HIP-runtime settings the step's graph wants, applied before the runtime initialises (it reads them at the first HIP call of the
-    process, so `import hidvae_amd` must come before the first torch.cuda call; later is harmless but has no effect).
+def _hw_queue_cap(env=None):
+    """hardware queues the HIP runtime creates per device: GPU_MAX_HW_QUEUES, 4 unless the user raised it"""
+    env = os.environ if env is None else env
+    try:
+        return max(1, int(env.get("GPU_MAX_HW_QUEUES", "4")))
+    except ValueError:
+        return 4
 
-    DEBUG_HIP_FORCE_GRAPH_QUEUES: the number of hardware queues hipGraphLaunch spreads a graph's parallel branches over.  The tagged
-    step forks into one branch per level (plus the decoder on the caller's stream and RCCL's stream under data parallelism).  Measured
-    on MI355X / ROCm 7.2 (bench.py --tagged 1, B = 1024, same box): the runtime's default and an explicit 4 give 1.79 ms -- two of the
-    heavy branches end up behind each other --, 3 queues 1.507-1.514 ms, 5 / 6 / 8 / 12 queues 1.52-1.56 ms; B = 2048: 2.81 -> 2.46 ms;
-    the untagged step (one branch) is unchanged.  More than 4 is NOT safe: a process that instantiates many graphs (the GPU test
-    suite) segfaults inside hipGraphLaunch with 5, 6 and 12 queues unless GPU_MAX_HW_QUEUES is raised too; 3 passes the whole suite.
-    An explicit DEBUG_HIP_FORCE_GRAPH_QUEUES in the environment wins; HIDVAE_GRAPH_QUEUES=0 leaves the runtime's default alone."""
-    q = os.environ.get("HIDVAE_GRAPH_QUEUES", "3")
-    if q != "0":
-        os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", q)
+
+def _graph_queues(env=None):
+    """-> (value for DEBUG_HIP_FORCE_GRAPH_QUEUES or None = leave the runtime alone, list of warnings).  Pure: tests call it.
+
+    What the knob is: the number of hardware queues hipGraphLaunch spreads a graph's parallel branches over.  The tagged step forks into
+    one branch per level (plus the decoder on the caller's stream and RCCL's stream under data parallelism).  Measured on MI355X /
+    ROCm 7.2 (bench.py, B = 1024, same box): the runtime's default 4 replays the tagged step in 1.79 ms -- two heavy branches end up
+    behind each other --, 3 in 1.51 ms; the untagged step (one branch) is unchanged.
+    What is NOT safe: more graph queues than the runtime has hardware queues (GPU_MAX_HW_QUEUES, default 4).  Round 3's suite died
+    with a segmentation fault inside hipGraphLaunch at 5, 6 and 12 forced queues and passed at 8 once GPU_MAX_HW_QUEUES=8 was set with
+    it (gpurun_out/r3c_tests.log, r3f_tests_q6.log, r3f_tests_q12.log, r3g_tests_q5.log, r3d_tests_nodp.log): every crash had the forced count
+    above the hardware-queue count and no run at or below it ever crashed (the runtime's source is not in this image, so the mechanism
+    inside hipGraphLaunch is not established beyond that).  So the value is CLAMPED to the cap, whoever asked for it -- HIDVAE_GRAPH_QUEUES or
+    a DEBUG_HIP_FORCE_GRAPH_QUEUES already in the environment -- and the clamp is reported.
+    HIDVAE_GRAPH_QUEUES=0 leaves the runtime's setting alone (a DEBUG_HIP_FORCE_GRAPH_QUEUES above the cap is still clamped)."""
+    env = os.environ if env is None else env
+    notes, cap = [], _hw_queue_cap(env)
+
+    def parse(name, default):
+        raw = env.get(name, default)
+        try:
+            return int(raw)
+        except (TypeError, ValueError):
+            notes.append(f"{name}={raw!r} is not an integer; using {default}")
+            return int(default)
+
+    explicit = env.get("DEBUG_HIP_FORCE_GRAPH_QUEUES")
+    if explicit is not None:
+        q = parse("DEBUG_HIP_FORCE_GRAPH_QUEUES", "3")
+        who = "DEBUG_HIP_FORCE_GRAPH_QUEUES"
+    else:
+        q = parse("HIDVAE_GRAPH_QUEUES", "3")
+        who = "HIDVAE_GRAPH_QUEUES"
+        if q == 0:
+            return None, notes
+    if q < 1:
+        notes.append(f"{who}={q} is out of range; using 1")
+        q = 1
+    if q > cap:
+        notes.append(f"{who}={q} exceeds the runtime's {cap} hardware queues (GPU_MAX_HW_QUEUES): hipGraphLaunch segfaults there; "
+                     f"clamped to {cap} (raise GPU_MAX_HW_QUEUES with it if you mean it)")
+        q = cap
+    return str(q), notes
+
+
+GRAPH_QUEUES = None  # what this import left in DEBUG_HIP_FORCE_GRAPH_QUEUES (None: the runtime's own default); bench.py records it
+
+
+def _runtime_defaults():
+    """HIP-runtime settings the step's graph wants, applied before the runtime initialises: it reads them at the first HIP call of the
+    process, so `import hidvae_amd` must come before the first torch.cuda call; a later import cannot take effect and says so."""
+    import warnings
+    global GRAPH_QUEUES
+    q, notes = _graph_queues()
+    for n in notes:
+        warnings.warn("hidvae_amd: " + n, RuntimeWarning, stacklevel=3)
+    if q is not None:
+        changed = os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES") != q
+        tc = sys.modules.get("torch")
+        if changed and tc is not None and getattr(tc, "cuda", None) is not None and tc.cuda.is_initialized():
+            warnings.warn("hidvae_amd was imported after the HIP runtime initialised: the graph-queue setting "
+                          f"(DEBUG_HIP_FORCE_GRAPH_QUEUES={q}) cannot take effect in this process and the tagged step replays ~20 % slower; "
+                          "import hidvae_amd before the first torch.cuda call", RuntimeWarning, stacklevel=3)
+        os.environ["DEBUG_HIP_FORCE_GRAPH_QUEUES"] = q
+    GRAPH_QUEUES = os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES")
 
 
 _runtime_defaults()

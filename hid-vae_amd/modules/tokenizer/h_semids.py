@@ -78,6 +78,10 @@ class HSemanticIdTokenizer(nn.Module):
         """feats [..., input_dim] -> ids [n_items, sem_ids_dim-ish] (semantic ids, plus tag ids in the combined modes)."""
         flat = feats.reshape(-1, feats.shape[-1]).to(self.hrq_vae.device)
         if not (self.use_concatenated_ids or self.use_interleaved_ids):
+            if self.hrq_vae.training:
+                # (a parent module's .train() reached the tokenizer's model: the reference calls get_semantic_ids whatever the mode,
+                #  h_semids.py:128,271; the ids-only launch is the eval-mode search)
+                return self.hrq_vae.get_semantic_ids(self.hrq_vae.encode(flat)).sem_ids
             return self.hrq_vae.semantic_ids_only(self.hrq_vae.encode(flat))  # only the ids leave the launch
         sem = self.hrq_vae.get_semantic_ids(self.hrq_vae.encode(flat)).sem_ids
         tags = self.hrq_vae.predict_tags(flat)["predictions"]

@@ -1,9 +1,9 @@
 """One optimizer step of the tokenizer as a replayable HIP graph.
 
 train_hidvae.train() and bench.py run the same sequence every iteration -- copy the batch into fixed input buffers, forward,
-backward, (all-reduce,) AdamW -- about 25 launches in the untagged case and 300 with the tag heads, most of them a few
-microseconds long.  Issued one by one from Python the step is host-bound (0.80 ms untagged / 7.2 ms tagged on MI355X); captured
-once and replayed it is 0.28 / 2.3 ms.  Nothing in the step synchronises with the host (losses, the mixup weight, the AdamW step
+backward, (all-reduce,) AdamW -- 19 launches in the untagged case and about 170 with the tag heads, most of them a few
+microseconds long.  Issued one by one from Python the step is host-bound (several ms with the tag heads on MI355X); captured
+once and replayed it is bound by the device (DESIGN.md section 4 carries the current figures).  Nothing in the step synchronises with the host (losses, the mixup weight, the AdamW step
 counter and the learning-rate schedule live on the device), which is what makes the capture legal.
 
 Data parallel.  Over RCCL (backend "nccl") the gradient all-reduce is captured INSIDE the step's graph -- RCCL collectives are
@@ -22,6 +22,7 @@ the backward, inside the same graph:
 Backends whose collectives run on the host (gloo: CPU tests, several ranks on one GPU) cannot be captured; there the collectives
 stay between graphs as before: graph[fwd, bwd part 1] -> all-reduce || graph[bwd part 2] -> all-reduce -> graph[AdamW], or
 graph[fwd, bwd] -> all-reduce -> graph[AdamW].  HIDVAE_DP_GRAPH_COLLECTIVES=0/1 overrides the choice."""
+import contextlib
 import os
 import types
 
@@ -55,18 +56,32 @@ class GraphedTrainStep:
         self.overlap = overlap
         self.graphs = None
         self.in_graph = False  # True once the collectives were captured inside the (single) step graph
-        # the gradient every micro-batch's loss receives below (total.backward(gradient=1) through loss / ga): announced to the model so
-        # the tag heads can run their backward right after their forward (HRqVae.loss_grad_hint; HIDVAE_EARLY_HEADS=0 turns it off)
+        # the gradient every micro-batch's loss receives below (total.backward(gradient=1) through loss / ga): announced to the model
+        # FOR THE DURATION OF THIS STEPPER'S OWN FORWARD CALLS (_armed) so the tag heads can run their backward right after their forward
+        # (HRqVae.loss_grad_hint; HIDVAE_EARLY_HEADS=0 turns it off).  Outside those calls the model carries neither the hint nor the
+        # hook: a user's own train-mode forward (another scaling of the loss, another accumulation count, a second stepper) has no side
+        # effects on .grad or on the optimizer.
+        self.loss_grad_hint, self.level_done_hook = None, None
         if self.tagged and hasattr(model, "n_layers") and os.environ.get("HIDVAE_EARLY_HEADS", "1") != "0":
-            model.loss_grad_hint = float(torch.tensor(1.0, dtype=torch.float32) / self.ga) if self.ga > 1 else 1.0
+            self.loss_grad_hint = float(torch.tensor(1.0, dtype=torch.float32) / self.ga) if self.ga > 1 else 1.0
             # ... and, with one micro-batch per step and no gradient exchange, a level's head parameters take their AdamW update on that
             # level's stream as soon as its backward is done (90 % of the tagged model's bytes leave the serial tail of the step)
-            model._level_done_hook = None
             if dp is None and self.ga == 1 and hasattr(opt, "step_early") and hasattr(model, "tag_predictors"):
                 ranges = [opt.tensor_ranges_of(list(model.tag_predictors[i].parameters()) + list(model.tag_projectors[i].parameters()))
                           for i in range(model.n_layers)]
                 if all(r is not None for r in ranges):
-                    model._level_done_hook = lambda i: opt.step_early(ranges[i])
+                    self.level_done_hook = lambda i: opt.step_early(ranges[i])
+
+    @contextlib.contextmanager
+    def _armed(self):
+        """the model knows the loss gradient / the per-level optimizer hook only inside this block"""
+        m = self.model
+        saved = (getattr(m, "loss_grad_hint", None), getattr(m, "_level_done_hook", None))
+        m.loss_grad_hint, m._level_done_hook = self.loss_grad_hint, self.level_done_hook
+        try:
+            yield
+        finally:
+            m.loss_grad_hint, m._level_done_hook = saved
 
     # -- the step, as plain code (this is what gets captured)
     def _overlapped(self):
@@ -83,10 +98,11 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         self.opt.zero_grad()
         total = None
-        for s in self.static:
-            out = self.model(s, gumbel_t=self.t)
-            part = out.loss / self.ga if self.ga > 1 else out.loss
-            total = part if total is None else total + part
+        with self._armed():
+            for s in self.static:
+                out = self.model(s, gumbel_t=self.t)
+                part = out.loss / self.ga if self.ga > 1 else out.loss
+                total = part if total is None else total + part
         total.backward(gradient=self.one)
         if self.opt.flat_grads:
             self.opt.grad_buffer.seal()
@@ -97,7 +113,8 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         self.model.dp_cut = True
         try:
-            out = self.model(self.static[0], gumbel_t=self.t)
+            with self._armed():
+                out = self.model(self.static[0], gumbel_t=self.t)
         finally:
             self.model.dp_cut = False
         out.loss.backward(gradient=self.one)
@@ -141,61 +158,93 @@ class GraphedTrainStep:
         from . import _C
         _C.phase_mark("backward done")
         self.opt.step()
-        if self.tagged and getattr(self.model, "_level_done_hook", None) is not None:
+        if self.tagged and self.level_done_hook is not None:
             from .tagpath import join_tag_streams
             join_tag_streams(self.static[0].x.device)  # the levels' own optimizer updates ran on their streams, beside the core's backward
         _C.phase_mark("adamw done")
 
+    def _capture_mode(self):
+        """hipStreamCaptureMode of this step's captures.
+
+        torch's default ("global") makes a potentially unsafe HIP call from ANY thread an error while this thread captures.  A process
+        group's watchdog thread is such a caller: every 100 ms it polls the completion events (hipEventQuery) of collectives that were
+        issued eagerly and that it has not yet seen complete -- the warm-up steps' collectives, for up to a polling period after the
+        device went idle.  Under a global-mode capture that query returns hipErrorStreamCaptureUnsupported, the watchdog turns it into
+        an exception nobody catches on its (C++-only) thread and the process aborts: round 3's intermittent "Fatal Python error: Aborted"
+        of the first captured data-parallel step, signal raised on a thread without Python state (gpurun_out/r3f.log, r4a.log; the C++
+        message went into pytest's captured stderr and was lost with the process).  tests/test_dp_gpu.py
+        test_event_query_from_another_thread_* shows the mechanism in isolation, deterministically: the same query from a second thread
+        fails a global-mode capture every time and is legal under a thread-local one.
+        "thread_local" restricts the prohibition to the capturing thread -- which still must not (and does not) make unsafe calls --
+        so other threads' event queries are none of this capture's business.  Kernel launches from autograd's device thread are
+        captured as before: capture is a property of the stream, not of the thread."""
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return "thread_local"
+        except Exception:  # noqa: BLE001  (a build without distributed support has no watchdog either)
+            pass
+        return "global"
+
+    def _graph(self, g, **kw):
+        return torch.cuda.graph(g, capture_error_mode=self._capture_mode(), **kw)
+
+    def _reset_after_failed_capture(self):
+        """a capture that raised part-way leaves host-side bookkeeping of a step that never ran: undo it before anything steps again"""
+        from . import _C
+        dev = self.static[0].x.device
+        torch.cuda.synchronize()
+        _C.take_pending_adamw(dev, owner=self.opt)       # a deferred schedule launch registered inside the failed capture
+        self.opt._prepared = False                        # ... or issued inside it: the scalars were never computed
+        self.opt._early = []
+        self.opt.zero_grad()                              # drops .grad, un-seals the flat buffer, forgets first-bucket marks
+        if getattr(self.model, "dp_cut", False):
+            self.model.dp_cut = False
+        if self.tagged:
+            from .tagpath import join_tag_streams
+            join_tag_streams(dev)
+
     def _capture(self):
-        if self.dp is not None and not getattr(self, "_settled", False):
-            # The process group's watchdog thread polls the completion events of the collectives the eager warm-up steps issued; an event
-            # query from ANOTHER thread while this one is capturing is an error on this runtime and takes the process down (seen as an
-            # intermittent abort of the first captured data-parallel step, main thread anywhere inside the capture).  The device is idle
-            # (the caller synchronised): give the watchdog a few of its 100 ms polling periods to retire that work before capturing.
-            import time
-            torch.cuda.synchronize()
-            time.sleep(0.5)
-            self._settled = True
         if self.dp is not None and self._collectives_capturable() and not getattr(self, "_in_graph_failed", False):
             g1 = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g1):
+                with self._graph(g1):
                     self._eager()  # the collectives become nodes of the graph (they fork to RCCL's stream and join back)
             except RuntimeError as e:
-                # (never seen with RCCL here -- one rank on this box, the only configuration that could be run; if a multi-rank
-                #  communicator refuses to be captured, the step falls back to the between-graphs form instead of dying)
+                # a communicator that refuses to be captured: keep the collectives between graphs instead of dying.  (This catches an
+                # error, not a hang: bench.py's launcher bounds the run's wall time for that.)
                 import sys
                 print(f"[hidvae] capturing the collectives inside the step graph failed ({str(e).splitlines()[0]}); "
                       "keeping them between graphs", file=sys.stderr)
                 self._in_graph_failed = True
-                torch.cuda.synchronize()
+                self._reset_after_failed_capture()
                 return self._capture()
             self.graphs = (g1,)
             self.in_graph = True
         elif self._overlapped():
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with self._graph(g1):
                 self._part1()
                 if self.tagged:  # the heads' early backward runs on the level streams: this graph ends here, so they join here
                     from .tagpath import join_tag_streams
                     join_tag_streams(self.static[0].x.device)
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with self._graph(g2, pool=g1.pool()):
                 self._part2()
             self.opt.grad_scale = 1.0 / self.dp.world
-            with torch.cuda.graph(g3, pool=g1.pool()):
+            with self._graph(g3, pool=g1.pool()):
                 self.opt.step()
             self.graphs = (g1, g2, g3)
         elif self.dp is not None:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with self._graph(g1):
                 self._fwd_bwd()
             self.opt.grad_scale = 1.0 / self.dp.world
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with self._graph(g2, pool=g1.pool()):
                 self.opt.step()
             self.graphs = (g1, g2)
         else:
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with self._graph(g1):
                 self._eager()
             self.graphs = (g1,)
 

@@ -50,6 +50,44 @@ def test_launcher_propagates_a_dead_rank_and_stops_the_others(tmp_path):
     assert rc == 7 and time.time() - t0 < 60, "the surviving rank was left waiting"
 
 
+def test_launcher_time_limit_terminates_stuck_ranks_and_fails(tmp_path, capfd):
+    """a rank that never finishes (stuck in a collective / a capture: nothing inside the rank can catch that) must not hold the job"""
+    import time
+    import bench
+    child = ("import os, time\n"
+             "open(os.path.join(os.environ['OUT_DIR'], 'pid%s' % os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+             "time.sleep(300)\n")
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [], child=[sys.executable, "-c", child], env=dict(os.environ, OUT_DIR=str(tmp_path)), time_limit=3.0)
+    took = time.time() - t0
+    assert rc == 124 and 2.5 < took < 30, (rc, took)
+    assert "time limit" in capfd.readouterr().err
+    for r in range(2):  # the children are gone (terminated by PID)
+        pid = int((tmp_path / f"pid{r}").read_text())
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)
+
+
+def test_graph_queue_setting_is_clamped_to_the_hardware_queue_count():
+    """DEBUG_HIP_FORCE_GRAPH_QUEUES above GPU_MAX_HW_QUEUES (default 4) is what segfaulted hipGraphLaunch in round 3: never let it through"""
+    import hidvae_amd
+    f = hidvae_amd._graph_queues
+    assert f({}) == ("3", [])
+    assert f({"HIDVAE_GRAPH_QUEUES": "0"}) == (None, [])
+    assert f({"HIDVAE_GRAPH_QUEUES": "4"}) == ("4", [])
+    q, notes = f({"HIDVAE_GRAPH_QUEUES": "12"})
+    assert q == "4" and len(notes) == 1 and "clamped" in notes[0]
+    q, notes = f({"DEBUG_HIP_FORCE_GRAPH_QUEUES": "6"})
+    assert q == "4" and "clamped" in notes[0]
+    assert f({"DEBUG_HIP_FORCE_GRAPH_QUEUES": "8", "GPU_MAX_HW_QUEUES": "8"}) == ("8", [])
+    q, notes = f({"HIDVAE_GRAPH_QUEUES": "0", "DEBUG_HIP_FORCE_GRAPH_QUEUES": "5"})   # an explicit runtime setting is clamped too
+    assert q == "4" and notes
+    q, notes = f({"HIDVAE_GRAPH_QUEUES": "many"})
+    assert q == "3" and notes
+    assert f({"DEBUG_HIP_FORCE_GRAPH_QUEUES": "2", "HIDVAE_GRAPH_QUEUES": "4"}) == ("2", [])   # the runtime's own variable wins
+    assert hidvae_amd.GRAPH_QUEUES == os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES")
+
+
 def test_main_becomes_the_launcher_only_without_a_world_in_the_environment(monkeypatch):
     import bench
     calls = []

@@ -51,7 +51,7 @@ def _batch(cfg, B, seed, tagged):
     return b
 
 
-def _run(tagged, dp_mode, steps=6, B=128, in_graph=True):
+def _run(tagged, dp_mode, steps=6, B=128, in_graph=True, fail_first_capture=False):
     """dp_mode None: plain step; 'overlap': DataParallel over a one-rank RCCL group, collectives issued anyway.  in_graph: the
     collectives are captured inside the step's ONE graph (the default over RCCL); False: kept between three graphs (what host-side
     backends get)"""
@@ -70,15 +70,29 @@ def _run(tagged, dp_mode, steps=6, B=128, in_graph=True):
     st = GraphedTrainStep(m, opt, [_batch(cfg, B, 500, tagged)], dp=dp, gumbel_t=0.2, warmup=2, overlap=True if multi else None)
     if multi and not in_graph:
         st._collectives_capturable = lambda: False
+    if fail_first_capture:
+        # a communicator that refuses to be captured: the first collective issued under capture raises, once
+        real, state = dp.allreduce_part, {"raised": 0}
+
+        def refusing(lo, hi):
+            if torch.cuda.is_current_stream_capturing() and not state["raised"]:
+                state["raised"] += 1
+                raise RuntimeError("stand-in: this communicator cannot be captured")
+            return real(lo, hi)
+
+        dp.allreduce_part = refusing
     rows = []
     for it in range(steps):
         rows.append(st([_batch(cfg, B, 500 + it, tagged)]).clone())
-    assert st.graphs is not None and len(st.graphs) == (3 if (multi and not in_graph) else 1)
-    assert st.in_graph == (multi and in_graph)
+    between = multi and (not in_graph or fail_first_capture)
+    assert st.graphs is not None and len(st.graphs) == (3 if between else 1)
+    assert st.in_graph == (multi and not between)
+    if fail_first_capture:
+        assert state["raised"] == 1 and st._in_graph_failed
     return torch.stack(rows).cpu(), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
 
 
-def _one_rank_rccl_worker(rank, port, tagged, in_graph):
+def _one_rank_rccl_worker(rank, port, tagged, in_graph, fail_first_capture=False):
     """body of test_overlapped_dp_step_equals_the_plain_step_bit_for_bit, in a process of its own: a process group (RCCL: watchdog and
     proxy threads) lives and dies with it instead of being created and destroyed inside the pytest process"""
     sys.path.insert(0, ROOT)
@@ -87,7 +101,7 @@ def _one_rank_rccl_worker(rank, port, tagged, in_graph):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL, one rank: the --dist 1 rehearsal as a test
     try:
-        rows1, sd1 = _run(tagged, "overlap", in_graph=in_graph)
+        rows1, sd1 = _run(tagged, "overlap", in_graph=in_graph, fail_first_capture=fail_first_capture)
         rows0, sd0 = _run(tagged, None)
     finally:
         dist.destroy_process_group()
@@ -104,13 +118,77 @@ def test_overlapped_dp_step_equals_the_plain_step_bit_for_bit(tagged, in_graph):
     mp.spawn(_one_rank_rccl_worker, args=(_free_port(), tagged, in_graph), nprocs=1, join=True)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("tagged", [False, True], ids=["untagged", "tagged"])
+def test_a_refused_in_graph_capture_falls_back_to_collectives_between_graphs(tagged):
+    """GraphedTrainStep._capture's fallback: the capture with the collectives inside raises part-way (host bookkeeping of a step that
+    never ran is left behind: optimizer `_prepared` / `_early`, sealed flat buffer, first-bucket marks, forked level streams); the
+    step must reset that, re-capture in the between-graphs form and still equal the plain step bit for bit"""
+    import torch.multiprocessing as mp
+    mp.spawn(_one_rank_rccl_worker, args=(_free_port(), tagged, True, True), nprocs=1, join=True)
+
+
+def _event_query_worker(rank):
+    """What aborted round 3's first captured data-parallel step, in isolation: a completion-event query from ANOTHER thread (the process
+    group's watchdog does this every 100 ms for collectives it has not yet seen complete) while this thread captures."""
+    import threading
+    torch.cuda.set_device(0)
+    x = torch.ones(1024, device="cuda")
+    s = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    with torch.cuda.stream(s):
+        y = x * 2
+        ev.record(s)
+    torch.cuda.synchronize()
+
+    def capture(mode):
+        seen = {}
+
+        def poll():
+            try:
+                seen["done"] = ev.query()
+            except Exception as e:  # noqa: BLE001
+                seen["error"] = f"{type(e).__name__}: {str(e).splitlines()[0]}"
+
+        g = torch.cuda.CUDAGraph()
+        failed = None
+        try:
+            with torch.cuda.graph(g, capture_error_mode=mode):
+                z = y + 1
+                t = threading.Thread(target=poll)
+                t.start()
+                t.join()
+                z = z * 3
+        except RuntimeError as e:
+            failed = str(e).splitlines()[0]
+        return seen, failed, g, (None if failed else z)
+
+    # thread-local capture: the other thread's query is legal, the capture completes and replays
+    seen, failed, g, z = capture("thread_local")
+    assert seen == {"done": True} and failed is None, (seen, failed)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(z, torch.full_like(z, 9.0))
+    # global capture (torch's default): the same query is an error -- in the watchdog's C++ thread that error is an uncaught exception
+    seen, failed, g, z = capture("global")
+    assert "error" in seen or failed is not None, ("a query from another thread did not disturb a global-mode capture", seen, failed)
+    print(f"[event-query] global-mode capture: query -> {seen}; capture -> {failed}", flush=True)
+
+
+@pytest.mark.timeout(300)
+def test_event_query_from_another_thread_breaks_a_global_capture_and_not_a_thread_local_one():
+    """the mechanism behind GraphedTrainStep._capture_mode (no process group involved: deterministic, one run)"""
+    import torch.multiprocessing as mp
+    mp.spawn(_event_query_worker, nprocs=1, join=True)
+
+
 def _rank_worker(rank, world, port, out_dir, steps, B, tagged=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import hidvae_amd  # noqa: F401  (before the first HIP call: the graph-queue setting is read when the runtime initialises)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    import hidvae_amd  # noqa: F401
     from hidvae_amd.optim import HidvaeAdamW
     from hidvae_amd.parallel import DataParallel
     from hidvae_amd.step import GraphedTrainStep
@@ -196,9 +274,10 @@ def test_the_levels_early_optimizer_update_is_the_same_update():
         torch.manual_seed(1234)
         opt = HidvaeAdamW(_groups(m, True), cosine=(1000, 7e-8)).prepare()
         st = GraphedTrainStep(m, opt, [_batch(cfg, 128, 500, True)], gumbel_t=0.2, warmup=2)
-        assert m._level_done_hook is not None and m.loss_grad_hint == 1.0
+        assert st.level_done_hook is not None and st.loss_grad_hint == 1.0
+        assert getattr(m, "loss_grad_hint", None) is None and getattr(m, "_level_done_hook", None) is None  # armed only inside the stepper's forward
         if not early:
-            m._level_done_hook = None
+            st.level_done_hook = None
         rows = [st([_batch(cfg, 128, 500 + it, True)]).clone() for it in range(6)]
         assert st.graphs is not None and len(st.graphs) == 1
         out.append((torch.stack(rows).cpu(), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
