@@ -189,6 +189,13 @@ class GraphedTrainStep:
     def _graph(self, g, **kw):
         return torch.cuda.graph(g, capture_error_mode=self._capture_mode(), **kw)
 
+    def _rejoin_forked_streams(self):
+        """the current (capturing) stream waits for every stream this package may have forked work to"""
+        from .ops import join_side
+        from .tagpath import join_tag_streams
+        join_side()
+        join_tag_streams(self.static[0].x.device)
+
     def _reset_after_failed_capture(self):
         """a capture that raised part-way leaves host-side bookkeeping of a step that never ran: undo it before anything steps again"""
         from . import _C
@@ -207,15 +214,30 @@ class GraphedTrainStep:
     def _capture(self):
         if self.dp is not None and self._collectives_capturable() and not getattr(self, "_in_graph_failed", False):
             g1 = torch.cuda.CUDAGraph()
+            err = None
             try:
                 with self._graph(g1):
-                    self._eager()  # the collectives become nodes of the graph (they fork to RCCL's stream and join back)
-            except RuntimeError as e:
+                    try:
+                        self._eager()  # the collectives become nodes of the graph (they fork to RCCL's stream and join back)
+                    except RuntimeError as e:
+                        # The capture itself must still END cleanly: a capture_end that fails ("capturing stream has unjoined work" --
+                        # the level streams were forked into it) leaves torch's allocator and generator bookkeeping of this graph
+                        # behind and the next capture takes the process down (seen on the GPU: "The graph should be registered to the
+                        # state", thrown from ~CUDAGraph).  So: join every forked stream back, end the capture, discard the graph.
+                        err = e
+                        self._rejoin_forked_streams()
+            except RuntimeError as e2:
+                raise RuntimeError(
+                    "capturing the data-parallel step with its collectives inside the graph failed and the capture could not be ended "
+                    f"cleanly ({str(e2).splitlines()[0]}); this process cannot capture again -- restart with HIDVAE_DP_GRAPH_COLLECTIVES=0 "
+                    "to keep the collectives between graphs") from (err or e2)
+            if err is not None:
                 # a communicator that refuses to be captured: keep the collectives between graphs instead of dying.  (This catches an
-                # error, not a hang: bench.py's launcher bounds the run's wall time for that.)
+                # error, not a hang: bench.py's launcher / its per-rank time limit bound the run's wall time for that.)
                 import sys
-                print(f"[hidvae] capturing the collectives inside the step graph failed ({str(e).splitlines()[0]}); "
+                print(f"[hidvae] capturing the collectives inside the step graph failed ({str(err).splitlines()[0]}); "
                       "keeping them between graphs", file=sys.stderr)
+                del g1
                 self._in_graph_failed = True
                 self._reset_after_failed_capture()
                 return self._capture()

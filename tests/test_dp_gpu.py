@@ -96,6 +96,7 @@ def _one_rank_rccl_worker(rank, port, tagged, in_graph, fail_first_capture=False
     """body of test_overlapped_dp_step_equals_the_plain_step_bit_for_bit, in a process of its own: a process group (RCCL: watchdog and
     proxy threads) lives and dies with it instead of being created and destroyed inside the pytest process"""
     sys.path.insert(0, ROOT)
+    import hidvae_amd  # noqa: F401  (before the first HIP call: the graph-queue setting is read when the runtime initialises)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
