@@ -54,6 +54,23 @@ __device__ __forceinline__ float hv_dgelu(float a) {
     return cdf + a * pdf;
 }
 
+// GEMM epilogues (include/hidvae.h HIDVAE_EPI_*).  `scale` matters to DRELU only: the backward through ReLU -> Dropout(keep_scale) read off
+// the layer's OUTPUT y = relu(.) * keep * scale (y > 0 exactly where the unit was active AND kept, so neither the keep-mask nor the
+// pre-activation is needed)
+__device__ __forceinline__ float hv_apply_epilogue(int epi, float v, const float *aux, int64_t off, float scale = 1.0f) {
+    switch (epi) {
+        case HIDVAE_EPI_SILU: return hv_silu(v);
+        case HIDVAE_EPI_RELU: return fmaxf(v, 0.0f);
+        case HIDVAE_EPI_GELU: return hv_gelu(v);
+        case HIDVAE_EPI_SIGMOID: return hv_sigmoid(v);
+        case HIDVAE_EPI_DSILU: return v * hv_dsilu(aux[off]);
+        case HIDVAE_EPI_DRELU: return aux[off] > 0.0f ? v * scale : 0.0f;
+        case HIDVAE_EPI_DGELU: return v * hv_dgelu(aux[off]);
+        case HIDVAE_EPI_DSIGMOID: { const float s = aux[off]; return v * (s * (1.0f - s)); }
+        default: return v;
+    }
+}
+
 // per-step AdamW scalars in double precision, once per tensor (torch computes them on the host in double), and the step counter
 // itself.  Executed by ONE whole workgroup (adamw_prepare_kernel, or a spare workgroup of a launch that carries it).
 struct HvAdamPrepare {

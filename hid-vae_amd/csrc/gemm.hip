@@ -17,6 +17,7 @@
 #include <type_traits>
 #include "common.h"
 #include "rules.h"
+#include "gemm_ring.h"
 
 namespace {
 
@@ -51,20 +52,9 @@ __device__ __forceinline__ float dropout_factor(const GemmArgs &g, int64_t row, 
     return hv_drop_keep(g.drop, (unsigned long long)(row * g.N + col)) ? g.mask_scale : 0.0f;
 }
 
-// `scale` matters to DRELU only: the backward through ReLU -> Dropout(keep_scale) read off the layer's OUTPUT y = relu(.) * keep * scale
-// (y > 0 exactly where the unit was active AND kept, so neither the keep-mask nor the pre-activation is needed)
+// (the epilogue switch lives in common.h: gemm_ring.hip applies the same one)
 __device__ __forceinline__ float apply_epilogue(int epi, float v, const float *aux, int64_t off, float scale = 1.0f) {
-    switch (epi) {
-        case HIDVAE_EPI_SILU: return hv_silu(v);
-        case HIDVAE_EPI_RELU: return fmaxf(v, 0.0f);
-        case HIDVAE_EPI_GELU: return hv_gelu(v);
-        case HIDVAE_EPI_SIGMOID: return hv_sigmoid(v);
-        case HIDVAE_EPI_DSILU: return v * hv_dsilu(aux[off]);
-        case HIDVAE_EPI_DRELU: return aux[off] > 0.0f ? v * scale : 0.0f;
-        case HIDVAE_EPI_DGELU: return v * hv_dgelu(aux[off]);
-        case HIDVAE_EPI_DSIGMOID: { const float s = aux[off]; return v * (s * (1.0f - s)); }
-        default: return v;
-    }
+    return hv_apply_epilogue(epi, v, aux, off, scale);
 }
 
 // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), and every XCD has its own
@@ -1827,6 +1817,12 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
     constexpr int mid_minq = 6;  // shortest range worth a workgroup (steps)
     if (balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, dX != nullptr) &&
         fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && (dX == nullptr || fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw))) {
+        static const int ring_mode = getenv("HIDVAE_RING") ? atoi(getenv("HIDVAE_RING")) : 1;  // (development switch: 0 = the round-3 kernel)
+        if (ring_mode > 0) {
+            const int rc = hv_ring_linear_bwd(g, ldg, x, ldx, W, ldw, B, n_out, n_in, dW, lddw, accumulate_dw, dX, lddx, dx_epilogue, aux, ldaux,
+                                              dx_scale, db, accumulate_db, workspace, ring_mode == 2 ? 256 : 512, (hipStream_t)stream);
+            if (rc != 1) return rc;
+        }
         auto run_mid = [&](auto kg_tag) -> int {
         constexpr int KG = decltype(kg_tag)::value, BKS = 16 * KG;
         SkArgs a{};
