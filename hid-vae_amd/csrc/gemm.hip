@@ -1817,10 +1817,10 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
     constexpr int mid_minq = 6;  // shortest range worth a workgroup (steps)
     if (balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, dX != nullptr) &&
         fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && (dX == nullptr || fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw))) {
-        static const int ring_mode = getenv("HIDVAE_RING") ? atoi(getenv("HIDVAE_RING")) : 1;  // (development switch: 0 = the round-3 kernel)
-        if (ring_mode > 0) {
+        // from B = 2048 on: the LDS-DMA ring kernel (gemm_ring.hip) -- measured in the step, see its header; below, the kernels here
+        if (B >= 2048) {
             const int rc = hv_ring_linear_bwd(g, ldg, x, ldx, W, ldw, B, n_out, n_in, dW, lddw, accumulate_dw, dX, lddx, dx_epilogue, aux, ldaux,
-                                              dx_scale, db, accumulate_db, workspace, ring_mode == 2 ? 256 : 512, (hipStream_t)stream);
+                                              dx_scale, db, accumulate_db, workspace, 512, (hipStream_t)stream);
             if (rc != 1) return rc;
         }
         auto run_mid = [&](auto kg_tag) -> int {

@@ -1,19 +1,28 @@
 // Linear backward (dW = g^T x, dX = epi(g W), db = colsum(g)) on an LDS-DMA ring: the mid-size layers of the tag heads and of the
-// encoder / decoder (reference modules/h_rqvae.py:132-188,322-331; modules/encoder.py:23-36), B = 256 .. 16384.
+// encoder / decoder (reference modules/h_rqvae.py:132-188,322-331; modules/encoder.py:23-36) at B >= 2048.
 //
-// Why another kernel.  gemm_mid_sk_kernel (gemm.hip) stages every operand global -> VGPR -> ds_write, runs
-// sixteen (eight) waves per 64x64 tile in four (two) k-groups whose partial tiles meet in LDS at every segment end, and restarts its
-// pipeline at every segment: PMC, 1024 x 691 x 768: MFMA pipe 35 % busy, 13 % issue-active, 2.6-7.4x the operand bytes fetched.  Here
+// What differs from gemm_mid_sk_kernel (gemm.hip), which stages every operand global -> VGPR -> ds_write, runs sixteen (eight) waves per
+// 64x64 tile in four (two) k-groups whose partial tiles meet in LDS at every segment end, and restarts its pipeline at every segment:
 //   * a workgroup is FOUR waves, one 32x32 quarter of a 64x64 tile each and the whole K range of its segment: one accumulator chain
 //     per wave, no k-groups, nothing to add up in LDS;
 //   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR, no ds_write, one instruction per KiB), into a ring
 //     of RB_NS stages of 32 k; the loads of step s + 3 are issued right after the barrier of step s and run through segment and tile
-//     boundaries -- the ring never drains inside a workgroup's range, a boundary costs the accumulator's trip to memory and nothing
-//     else; counted s_waitcnt vmcnt(N), one raw s_barrier per step;
+//     boundaries -- the ring never drains inside a workgroup's range except where a partial tile is handed over; counted
+//     s_waitcnt vmcnt(N), one raw s_barrier per step;
 //   * the work is gemm_mid_sk_kernel's list of k-steps cut into equal contiguous ranges (every SIMD the same number of MFMAs whatever
-//     the tile count; partial tiles through the workspace, the last arriver adds them in ascending k order: deterministic), but over a
-//     tile list ordered in square-ish bands so that the eighth of the list an XCD works on touches few operand panels -- its 4 MB L2
-//     holds them (the row-major list of the old kernel: 40 % hits, 122 MB fetched for 17 MB).
+//     the tile count; partial tiles through the workspace, the last arriver adds them in ascending k order: deterministic), over a
+//     tile list ordered in square-ish bands;
+//   * the loader state (buffer descriptors, per-lane offsets, the cursor) lives in registers and is rebuilt only at a tile change:
+//     indexing the argument struct by a run-time product index turns every field into a scalar load from the argument segment, eight
+//     dependent ones per step (the first build: 1.7 us per step of nothing but that).
+// Measured (scratch/r4): alone, 10-25 % faster than gemm_mid_sk_kernel from B = 1024 up (2048 x 768 x 691: 55.6 vs
+// 64.0 us = 0.50 of the fp32 MFMA peak; 4096 x 768 x 512: 71.8 vs 80.6 = 0.57; 8192 x 512 x 256: 51.9 vs 60.8); inside the step it pays
+// from B = 2048 (tagged step 2.008 -> 1.881 ms, the B = 8192 shard 0.870 -> 0.830 ms) and ties at B = 1024, where the round-3 kernel
+// stays.  Variants that were built, tested and NOT kept (sources: scratch/r4/gemm_ring_v3c.hip.txt): a chunk-major step list (L2 hits
+// 39 % -> 81 %, fabric traffic 114 -> 27 MB per launch) with pieces parked in slabs and a second, combining launch -- slower in the
+// step for the second launch's gap; two dedicated loader waves beside four MFMA waves -- no change: what does not overlap is not the
+// DMA instructions' issue (ablation: MFMAs + LDS reads alone 17.4 us above the launch's fixed 8 us = the matrix pipe's floor at the
+// ~2.0 GHz the chip holds; DMAs alone 9.7 us; together 23.6).
 // LDS images (a stage = 16 KB = operand A, then operand B):
 //   k-major operand (g and x of dW; W of dX), element (k, c) at P[k * ld + c]:   [32 k][64 c] floats, filled by 8 pieces of 4 k-rows;
 //       the MFMA fragment of k-pair j is the dword at row 2j + h: 32 consecutive dwords per half-wave, conflict-free ds_read_b32;
@@ -22,9 +31,9 @@
 //       of the DMA (its LDS side is lane-linear) and again on the read: conflict-free ds_read_b128.
 // Edges: k rows past K are aimed out of the buffer (LDS-DMA writes zeros for them: scratch/r4/probe.hip); a 16-byte chunk of a
 // k-contiguous row that straddles K brings in finite neighbours which meet those zeros; rows / columns past M / N only reach
-// accumulator rows / columns that are never stored.  16-byte DMA needs dword alignment only (same probe), so 691-wide rows are fine.
+// accumulator rows / columns that are never stored; the hardware's range check is per dword (same probe).  16-byte DMA needs dword
+// alignment only, so 691-wide rows are fine.
 // Not the ORDER-G16 chain: gradients only (their tests compare against float64 and demand launch-to-launch bit identity).
-#include <stdlib.h>
 #include "common.h"
 #include "rules.h"
 #include "gemm_ring.h"
@@ -60,7 +69,6 @@ struct RingArgs {
     int S, q, G;    // total steps, steps per workgroup, workgroups
     float *slabs;   // [G][2][4096] partial tiles (accumulator layout)
     int *counters;  // [ntiles0 + ntiles1], zero between launches
-    int dbg;        // DEVELOPMENT: bit 0 no DMA, bit 1 no flush, bit 2 no MFMA, bit 3 no column sums
 };
 
 // tile t of the band order -> (by, bx): bands of `bh` tile rows, column-major inside a band
@@ -316,8 +324,8 @@ __device__ __forceinline__ void ring_segment(const RingArgs &a, Loader &L, int l
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" : : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         __builtin_amdgcn_s_barrier();  // every wave's share of stage s is in LDS; everybody is done reading stage s - 1
-        if (s + RB_D < nst && !(a.dbg & 1)) loader_issue(a, L, wave, lane, lds, (s + RB_D) % RB_NS);
-        if (!(a.dbg & 4)) ring_mfma<NN>(lds, s % RB_NS, wm, wn, i32, h, acc);
+        if (s + RB_D < nst) loader_issue(a, L, wave, lane, lds, (s + RB_D) % RB_NS);
+        ring_mfma<NN>(lds, s % RB_NS, wm, wn, i32, h, acc);
     }
 }
 
@@ -341,11 +349,9 @@ __global__ __launch_bounds__(256) void gemm_ring_bwd_kernel(RingArgs a) {
             loader_tile(a, L, wave, lane);
         }
         int prob = L.prob, tile = L.tile, ks = L.ks;  // the consumer's position
-        if (!(a.dbg & 1)) {
 #pragma unroll
-            for (int i = 0; i < RB_D; i++)
-                if (i < nst) loader_issue(a, L, wave, lane, ring_lds, i);
-        }
+        for (int i = 0; i < RB_D; i++)
+            if (i < nst) loader_issue(a, L, wave, lane, ring_lds, i);
         int s = 0;
         while (s < nst) {
             const int nT = prob ? n1 : n0;
@@ -356,8 +362,7 @@ __global__ __launch_bounds__(256) void gemm_ring_bwd_kernel(RingArgs a) {
             for (int r = 0; r < 16; r++) acc[r] = 0.0f;
             if (prob) ring_segment<true>(a, L, len, s, nst, wave, lane, ring_lds, acc);
             else ring_segment<false>(a, L, len, s, nst, wave, lane, ring_lds, acc);
-            if (!(a.dbg & 2))
-                ring_flush(a, a.p[prob], tile, (prob ? T0 : 0) + tile, ks, len, (prob ? S0 : 0) + tile * nT, v, wave, lane, acc, flag);
+            ring_flush(a, a.p[prob], tile, (prob ? T0 : 0) + tile, ks, len, (prob ? S0 : 0) + tile * nT, v, wave, lane, acc, flag);
             ks += len;
             if (ks == nT) {
                 ks = 0;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256) void gemm_ring_bwd_kernel(RingArgs a) {
         while (step < hi) {
             const int rel = step - Sg, u = (rel + a.cu - 1) / a.cu;
             if (u >= a.nbc || Sg + u * a.cu >= hi) break;
-            if (!(a.dbg & 8)) ring_colsum32(a, u * 32, ring_lds);
+            ring_colsum32(a, u * 32, ring_lds);
             step = Sg + u * a.cu + 1;
         }
     }
@@ -421,8 +426,6 @@ int hv_ring_linear_bwd(const float *g, int64_t ldg, const float *x, int64_t ldx,
     if (G < 1) G = 1;
     a.q = (int)hv_cdiv(a.S, G);
     a.G = (int)hv_cdiv(a.S, a.q);
-    static const int dbg = getenv("HIDVAE_RING_DBG") ? atoi(getenv("HIDVAE_RING_DBG")) : 0;
-    a.dbg = dbg;
     a.counters = reinterpret_cast<int *>(workspace);
     a.slabs = workspace + HV_SK_COUNTERS;
     constexpr size_t bytes = (size_t)RB_LDS_FLOATS * 4;
