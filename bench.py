@@ -23,12 +23,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
-import hidvae_amd  # noqa: E402,F401  (before the first HIP call of the process: it sets the graph-queue default the runtime reads at init)
+if "--cpu-point" not in sys.argv:  # (the CPU-baseline child never touches the GPU library)
+    import hidvae_amd  # noqa: E402,F401  (before the first HIP call of the process: it sets the graph-queue default the runtime reads at init)
 
 AMAZON = dict(commitment_weight=0.4, tag_alignment_weight=0.15, tag_prediction_weight=0.55, tag_class_counts=[38, 168, 348],
               use_focal_loss=True, focal_loss_params={"gamma_0": 2.7, "alpha_0": 0.24, "gamma_1": 2.7, "alpha_1": 0.24,
                                                       "gamma_2": 2.7, "alpha_2": 0.24},
               dropout_rate=0.4, alignment_temperature=0.1, sem_id_uniqueness_weight=1.5, sem_id_uniqueness_margin=0.0)
+# reference configs/h_rqvae_kuairand.gin:20,30-32,39-40,50 (BASELINE config 3)
+KUAIRAND = dict(commitment_weight=0.5, tag_alignment_weight=0.5, tag_prediction_weight=0.7, tag_class_counts=[37, 168, 353],
+                use_focal_loss=True, focal_loss_params={"gamma_0": 2.5, "alpha_0": 0.25}, dropout_rate=0.25, alignment_temperature=0.08,
+                sem_id_uniqueness_weight=0.5, sem_id_uniqueness_margin=0.5)
+HPARAMS = {"amazon": AMAZON, "kuairand": KUAIRAND}
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA = vector rate
 
@@ -43,6 +49,9 @@ def parse():
     ap.add_argument("--codes", type=int, default=256)
     ap.add_argument("--tagged", type=int, default=1, help="1 (default): the HiD-VAE step with its tag heads -- every shipped h-config feeds "
                     "tags (reference train_hidvae.py:698-709); 0: the untagged core step")
+    ap.add_argument("--hparams", choices=sorted(HPARAMS), default="amazon", help="hyper-parameters of configs/h_rqvae_<name>.gin")
+    ap.add_argument("--also-configs", type=int, default=1, help="also time BASELINE configs 3 (kuairand-shaped tagged step at batch 2048) and 5 "
+                    "(4 x 1024 codebooks at batch 4096, with the GPU k-means start-up), reported as `config3_step`, `config5_step`, `kmeans_init`")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--pool", type=int, default=8, help="resident synthetic batches cycled through")
@@ -61,6 +70,10 @@ def parse():
     return ap.parse_args()
 
 
+def _hp(args):
+    return HPARAMS[getattr(args, "hparams", "amazon")]
+
+
 def build_model(args, device):
     import hidvae_amd  # noqa: F401
     from hidvae_amd.modules.h_rqvae import HRqVae
@@ -68,7 +81,7 @@ def build_model(args, device):
     torch.manual_seed(0)
     m = HRqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=args.codes, codebook_kmeans_init=False,
                codebook_normalize=True, codebook_mode=QuantizeForwardMode.ROTATION_TRICK, n_layers=args.levels, n_cat_features=0,
-               tag_embed_dim=768, **{**AMAZON, "tag_class_counts": (AMAZON["tag_class_counts"] + [500] * 8)[: args.levels]})
+               tag_embed_dim=768, **{**_hp(args), "tag_class_counts": (_hp(args)["tag_class_counts"] + [500] * 8)[: args.levels]})
     # codebooks as k-means would leave them: residual-sized, spread (k-means itself is start-up work, not part of a step)
     with torch.no_grad():
         for i, layer in enumerate(m.layers):
@@ -94,7 +107,7 @@ def synth_pool(args, device, rank):
     te = ti = None
     if args.tagged:
         te = torch.randn(args.pool, args.batch, args.levels, 768, generator=g).to(device)
-        classes = (AMAZON["tag_class_counts"] + [500] * 8)[: args.levels]
+        classes = (_hp(args)["tag_class_counts"] + [500] * 8)[: args.levels]
         cols = [torch.randint(0, c, (args.pool, args.batch), generator=g) for c in classes]
         ti = torch.stack(cols, dim=-1)
         ti[torch.rand(ti.shape, generator=g) < 0.05] = -1
@@ -311,11 +324,11 @@ def pmc_traffic():
     return out
 
 
-def _cpu_steps(args, budget_s, threads):
+def _cpu_steps(args, budget_s, threads, warm=2):
     from oracle import torch_oracle as O
     torch.set_num_threads(threads)
     cfg = O.Cfg(n_layers=args.levels, codebook_size=args.codes, codebook_mode=O.ROTATION,
-                **{**AMAZON, "tag_class_counts": (AMAZON["tag_class_counts"] + [500] * 8)[: args.levels]})
+                **{**_hp(args), "tag_class_counts": (_hp(args)["tag_class_counts"] + [500] * 8)[: args.levels]})
     P = O.formula_params(cfg, seed=100, with_tags=bool(args.tagged))
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     opt = torch.optim.AdamW(list(Pg.values()), lr=2.8e-4, weight_decay=0.015)
@@ -332,30 +345,107 @@ def _cpu_steps(args, budget_s, threads):
         out["loss"].backward()
         opt.step()
         n += 1
-        if n == 2:
-            first = time.perf_counter()  # two warm-up steps
-        if first is not None and n > 2 and (time.perf_counter() - first > budget_s or n >= 2 + 200):
+        if n == warm:
+            first = time.perf_counter()  # warm-up steps
+        if first is not None and n > warm and (time.perf_counter() - first > budget_s or n >= warm + 200):
             break
-    return n - 2, time.perf_counter() - first
+    return n - warm, time.perf_counter() - first
 
 
-def cpu_baseline(args, budget_s):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_point_child(argv):
+    """`python bench.py --cpu-point THREADS BUDGET <workload flags>`: one thread-count point of the CPU baseline in a process of its own (no
+    GPU use), so the parent can bound it -- all cores of a 100+-core host take ~20 s per step on these small-op graphs"""
+    i = argv.index("--cpu-point")
+    threads, budget = int(argv[i + 1]), float(argv[i + 2])
+    sys.argv = [argv[0]] + argv[1:i] + argv[i + 3:]
+    a = parse()
+    steps, dt = _cpu_steps(a, budget, threads, warm=1)
+    print(json.dumps({"threads": threads, "steps": steps, "seconds": dt}), flush=True)
+
+
+def cpu_baseline(args, budget_s, all_cores=True):
     """The oracle's torch-CPU restatement of the SAME step (fwd + bwd + torch AdamW, reference op sequence incl. the
     O(B^2) p_unique_ids), timed on this host.  This is the checker being timed as a baseline, never the product.
-    Small-op PyTorch does not scale with cores, so two thread counts share the budget and the best one is reported."""
+    BASELINE.md section 3: CPU model and core count stated; points at 1 thread, 8 threads (the survey container's count: BASELINE.md
+    section 2 holds the true reference code's numbers at 8) and all cores.  Small-op PyTorch does not scale with cores, so the BEST
+    point is `value`; the all-core point runs in a child process under a time limit."""
+    import subprocess
     ncpu = os.cpu_count() or 8
-    tries = sorted({min(8, ncpu), min(32, ncpu)})  # (all cores of a 100+-core host is slower still: one step took 20 s)
-    best, notes = None, []
-    for th in tries:
-        steps, dt = _cpu_steps(args, budget_s / len(tries), th)
-        ips = args.batch * steps / dt
-        notes.append(f"{th} threads: {ips:.0f} items/s ({steps} steps, {dt:.1f} s)")
-        if best is None or ips > best[0]:
+    points, notes, best = [], [], None
+
+    def add(th, steps, dt, note=""):
+        nonlocal best
+        ips = args.batch * steps / dt if steps > 0 and dt > 0 else 0.0
+        points.append(dict(threads=th, items_per_s=ips, steps=steps, seconds=dt))
+        notes.append(f"{th} threads: {ips:.0f} items/s ({steps} steps, {dt:.1f} s){note}")
+        if ips > 0 and (best is None or ips > best[0]):
             best = (ips, th)
-    return dict(value=best[0], unit="items/s", cores=best[1], kind="port",
+
+    steps, dt = _cpu_steps(args, budget_s * 0.6, min(8, ncpu))
+    add(min(8, ncpu), steps, dt)
+    steps, dt = _cpu_steps(args, budget_s * 0.3, 1, warm=1)
+    add(1, steps, dt)
+    if ncpu > 8 and all_cores:
+        flags = ["--batch", str(args.batch), "--levels", str(args.levels), "--codes", str(args.codes), "--tagged", str(args.tagged),
+                 "--hparams", getattr(args, "hparams", "amazon")]
+        limit = max(15.0, 2.0 * budget_s)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-point", str(ncpu), str(budget_s * 0.3)] + flags,
+                               capture_output=True, text=True, timeout=limit, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+            add(ncpu, rec["steps"], rec["seconds"])
+        except subprocess.TimeoutExpired:
+            points.append(dict(threads=ncpu, items_per_s=None, steps=0, seconds=limit))
+            notes.append(f"{ncpu} threads (all cores): not finished within {limit:.0f} s (1 warm-up + 1 step)")
+        except Exception as e:  # noqa: BLE001  the all-core point is a report, not a requirement
+            notes.append(f"{ncpu} threads (all cores): failed ({type(e).__name__})")
+    return dict(value=best[0], unit="items/s", cores=best[1], kind="port", cpu_model=_cpu_model(), host_cores=ncpu, points=points,
                 sample=f"full train steps (fwd+bwd+AdamW) of the oracle's torch-CPU restatement at B={args.batch}, "
-                       f"{'tagged' if args.tagged else 'untagged'}, 2 warm-up steps then a bounded sample per thread count: "
-                       + "; ".join(notes))
+                       f"{'tagged' if args.tagged else 'untagged'}, {getattr(args, 'hparams', 'amazon')} hyper-parameters, warm-up then a bounded "
+                       "sample per thread count: " + "; ".join(notes))
+
+
+def kmeans_init_times(device, budget_s=4.0):
+    """BASELINE config 5 / SURVEY 8(d): the codebook start-up -- k-means on 20,000 x 32 residual-shaped rows to K = 256 and K = 1024
+    (reference init/kmeans.py:34-77, Lloyd to convergence) -- on the GPU kernels, and the CPU restatement (oracle/kmeans_oracle.py) for a
+    bounded number of Lloyd iterations beside it."""
+    import numpy as np
+    from hidvae_amd.init.kmeans import Kmeans
+    from oracle import kmeans_oracle as KO
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    x_cpu = torch.randn(20000, 32, generator=g) * 0.35
+    x = x_cpu.to(device)
+    out = []
+    for K in (256, 1024):
+        init = np.random.RandomState(7).choice(20000, K, replace=False)
+        Kmeans(k=K, max_iters=2, init_indices=init).run(x)  # warm-up (kernel load)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        km = Kmeans(k=K, init_indices=init)
+        km.run(x)
+        torch.cuda.synchronize()
+        gpu_s = time.perf_counter() - t0
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+        t0, it = time.perf_counter(), 0
+        c = x_cpu[torch.as_tensor(init)].clone()
+        while it < 3 and (it == 0 or time.perf_counter() - t0 < budget_s / 2):
+            c, _ = KO.lloyd_iteration(x_cpu, c, reseed=lambda cl: 0)
+            it += 1
+        cpu_it = (time.perf_counter() - t0) / it
+        out.append(dict(N=20000, D=32, K=K, gpu_seconds=gpu_s, gpu_iterations=km.n_iter, gpu_seconds_per_iteration=gpu_s / max(1, km.n_iter),
+                        cpu_seconds_per_iteration=cpu_it, cpu_iterations_timed=it, cpu_threads=min(8, os.cpu_count() or 8),
+                        cpu_seconds_same_iterations=cpu_it * km.n_iter))
+    return out
 
 
 def run_workload(args, device, rank, world, dist):
@@ -500,6 +590,8 @@ def launch_ranks(n, argv, child=None, env=None, time_limit=None):
 
 
 def main():
+    if "--cpu-point" in sys.argv:
+        return _cpu_point_child(sys.argv)
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: become one.  (device_count() may call hipGetDeviceCount here; that is harmless because this process only spawns
@@ -550,7 +642,7 @@ def main():
         vdt, _, vinfo = run_workload(vargs, device, rank, world, dist)
         ex = dict(value=vargs.batch * vargs.steps / vdt, unit="items/s", ms_per_step=vdt / vargs.steps * 1e3, steps=vargs.steps,
                   batch=vargs.batch, hip_graph=vinfo["hip_graph"], windows_ms_per_step=vinfo["windows_ms_per_step"], workload=label)
-        if vinfo["hip_graph"] and args.kernels and dist is None and vargs.batch <= 2048:
+        if vinfo["hip_graph"] and args.kernels and dist is None and vargs.batch <= 4096:
             vrows, _ = step_timeline(vinfo["stepper"], vinfo["pool_batch"], device)
             vtable, vtop, _ = summarize_timeline(vrows)
             ex["launches"] = len(vrows)
@@ -567,11 +659,23 @@ def main():
         other_extra, other_args = variant(oa, "untagged core step: encoder, L-level RQ, decoder, reconstruction + commitment losses (no tag heads)" if args.tagged
                                           else "same shapes + tag heads (projector, InfoNCE, predictor, focal+mixup), amazon gin hyper-parameters")
         if args.cpu_seconds > 0:
-            other_extra["cpu_baseline"] = cpu_baseline(other_args, max(4.0, args.cpu_seconds / 2))
+            other_extra["cpu_baseline"] = cpu_baseline(other_args, max(4.0, args.cpu_seconds / 2), all_cores=False)
     large_extra = None
     if single and args.also_large and args.kernels:
         la = argparse.Namespace(**{**vars(args), "tagged": 0, "batch": args.also_large, "steps": max(20, args.steps // 5), "warmup": 5, "pool": 2})
         large_extra, _ = variant(la, f"untagged core step at batch {args.also_large} (the per-GPU shard of BASELINE config 4): the throughput-bound regime")
+
+    config_extras = {}
+    if single and args.also_configs and args.kernels:
+        c3 = argparse.Namespace(**{**vars(args), "tagged": 1, "batch": 2048, "hparams": "kuairand", "levels": 3, "codes": 256,
+                                   "steps": max(20, args.steps // 4), "warmup": 5, "pool": 4})
+        config_extras["config3_step"], _ = variant(c3, "BASELINE config 3: KuaiRand-shaped tagged step (configs/h_rqvae_kuairand.gin hyper-parameters), "
+                                                       "768-d + tag embeddings, 3x256, batch 2048")
+        c5 = argparse.Namespace(**{**vars(args), "tagged": 0, "batch": 4096, "levels": 4, "codes": 1024, "steps": max(20, args.steps // 4),
+                                   "warmup": 5, "pool": 2})
+        config_extras["config5_step"], _ = variant(c5, "BASELINE config 5: 4 levels x 1024 codes, batch 4096 per GPU, untagged core step (streamed RQ: the "
+                                                       "codebooks do not fit LDS)")
+        config_extras["kmeans_init"] = kmeans_init_times(device)
 
     if rank == 0:
         if not args.kernels:  # profiling run of the step only (rocprofv3 timelines): no roofline object
@@ -615,6 +719,7 @@ def main():
             most = max(r.get("flops", 0.0) for r in fam_rows)
             big = max((r for r in fam_rows if r.get("flops", 0.0) >= 0.999 * most), key=lambda r: r["us"])
             same = warm is not None and abs(warm.get("flops", -1.0) - big.get("flops", 0.0)) <= 1e-6 * max(1.0, big.get("flops", 0.0))
+            roof["traffic"] = warm.get("traffic") if same else None  # PMC bytes per launch of the family's largest launch (profiles/*_pmc_hbm_traffic.csv)
             roof["largest_launch"] = dict(MxNxK=[big.get("M"), big.get("N"), big.get("K")], us=big["us"],
                                           achieved=big.get("flops", 0.0) / big["us"] * 1e-6, frac=big.get("flops", 0.0) / big["us"] * 1e-6 / MFMA_F32_PEAK_TF,
                                           traffic=warm.get("traffic") if same else None, us_warm=warm.get("us") if same else None)
@@ -633,6 +738,7 @@ def main():
                                    f" train step = fwd+bwd+{'RCCL all-reduce+' if world > 1 else ''}AdamW(cosine)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                        "graph_queues": os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES"),
+                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"),
                        "collectives_in_graph": bool(getattr(info["stepper"], "in_graph", False))},
             "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"], "us_per_launch": roof["us"]}
                         | {k: roof[k] for k in ("share_of_step", "us_warm", "frac_warm", "largest_launch", "whole_step") if k in roof},
@@ -645,6 +751,7 @@ def main():
             line["untagged_core_step" if args.tagged else "tagged_step"] = other_extra
         if large_extra is not None:
             line["large_batch_step"] = large_extra
+        line.update(config_extras)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         degraded = bool(args.graph) and not use_graph  # the step could not be captured and ran eagerly (host-bound, ~6x slower)

@@ -159,3 +159,17 @@ def test_oracle_matches_reference_plain_rqvae(name):
     assert abs(float(out["reconstruction_loss"].mean()) - float(fx["reconstruction_loss"])) <= 1e-5 * abs(float(fx["reconstruction_loss"]))
     assert abs(float(out["rqvae_loss"].mean()) - float(fx["rqvae_loss"])) <= 1e-5 * abs(float(fx["rqvae_loss"]))
     assert abs(float(out["p_unique_ids"]) - float(fx["p_unique_ids"])) < 1e-7
+
+
+@pytest.mark.parametrize("name", [n for n in H.case_names("kmeans") if "n20000" not in n])
+def test_kmeans_oracle_matches_the_reference(name):
+    """oracle/kmeans_oracle.py (the CPU baseline of bench.py's kmeans_init leg) against the reference's own Lloyd runs
+    (init/kmeans.py:34-77 via tests/golden/make_golden.py run_kmeans): same assignment, centroids to rounding"""
+    from oracle import fill, kmeans_oracle as KO
+    fx, desc = H.load(name)
+    x = torch.from_numpy(fill.gauss((desc["N"], desc["D"]), desc["seed"]))
+    init = fill.perm(desc["N"], desc["seed"] + 1)[:desc["K"]]
+    c, a, iters = KO.run(x, desc["K"], init)
+    assert iters >= 1
+    assert np.array_equal(a.numpy().astype(np.int32), fx["assignment"])
+    assert np.abs(c.numpy() - fx["centroids"]).max() <= 1e-6 * max(1.0, float(np.abs(fx["centroids"]).max()))
