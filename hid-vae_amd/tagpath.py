@@ -675,11 +675,20 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
                 st.wait_stream(branch[1])
     fwd_done = []
     if early_bwd:
-        # Every level on a side stream of its own, the caller's stream keeps the decoder and the loss.  Forwards are issued in the
-        # reference's order (level by level, projector first: the random draws are numbered in that order), then every level's backward
-        # on the same stream.  (Dealing the 2 L units -- projector + alignment, predictor + loss -- over three streams by estimated
-        # duration, the caller's included, balanced the streams' end times but not the step: 1.39 vs 1.39 ms, B = 2048 2.36 vs 2.33.)
+        # Levels 1.. on side streams of their own; LEVEL 0 ON THE CALLER'S STREAM, in front of the decoder and the loss.  (Round 3 gave
+        # every level a side stream and left the caller's to the decoder and the loss.  In the replayed graph that is four busy branches
+        # on three hardware queues -- the count the step replays fastest with, __init__.py -- and the caller's branch was the one left
+        # waiting: tools/step_phases.py, profiles/r04_step_phases_tagged_3queues.log: decoder forward done at 947 us of a 1,182 us step,
+        # 130 us of decoder / loss / decoder-backward work left behind the heads.  With level 0 on the caller's stream there are three
+        # branches and each has a queue: 1.187 -> 1.153 ms.  Not kept: the decoder forward at the head of level 1's stream (1.198 ms: it
+        # delays that level); the loss launch on a level stream (hipGraph instantiation segfaults on that topology); four graph queues
+        # (1.252 ms: the decoder does run early then, at 189 us, but the loss launch still only gets its queue at 967 us).)
+        # Forwards are issued in the reference's order (level by level, projector first: the random draws are numbered in that order),
+        # then every level's backward on the same stream.  (Dealing the 2 L units -- projector + alignment, predictor + loss -- over three
+        # streams by estimated duration, the caller's included, balanced the streams' end times but not the step: 1.39 vs 1.39 ms.)
         plan = {(k, i): i + 1 for i in range(L) for k in ("pred", "align")}
+        if L >= 2 and os.environ.get("HIDVAE_L0_ON_CALLER", "1") != "0":
+            plan[("pred", 0)] = plan[("align", 0)] = 0
         side = _tag_streams(emb_cat.device, L + 1)
         lanes = [None] + list(side[1:])
         for st in lanes[1:]:
@@ -715,7 +724,7 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
         for st in lanes[1:]:  # the caller's loss launch waits for the units' FORWARD only
             ev = torch.cuda.Event()
             ev.record(st)
-            fwd_done.append(ev)
+            fwd_done.append((st, ev))
         _LN_DEFER[0] = True  # (the LayerNorms' affine gradients are finished by ONE launch, in HeadsGradPort.collect)
         bwd_done = [None] * L
         level_done = getattr(model, "_level_done_hook", None)  # the training loop's: this level's parameters may take their optimizer update
@@ -741,9 +750,12 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
         port.leaves, port.streams, port.done = list(views), lanes[1:], bwd_done
         out = tuple(aligns) + tuple(preds) + tuple(accs)
 
-        def join():
-            for ev in fwd_done:
-                main.wait_event(ev)
+        def join(target=None):  # target: the stream that is to consume the scalars (default: the caller's)
+            for st, ev in fwd_done:
+                if target is None:
+                    main.wait_event(ev)
+                elif st is not target:  # (a stream is ordered behind its own work already; a wait on its own event would be a duplicate edge of the captured graph)
+                    target.wait_event(ev)
 
         if defer_join:
             return out, join
