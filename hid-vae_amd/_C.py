@@ -66,11 +66,11 @@ _SIGNATURES = {
     "hidvae_tag_loss_fwd": [_vp, _i64, _i64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_tag_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "hidvae_kmeans_iter": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    "hidvae_gumbel_rows_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _f, _vp, _vp],
-    "hidvae_gumbel_loss": [_vp, _vp, _i64, _f, _vp, _vp],
-    "hidvae_gumbel_gemb": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp],
+    "hidvae_gumbel_rows_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _f, _vp, _i, _i, _vp],
+    "hidvae_gumbel_loss": [_vp, _vp, _i64, _f, _vp, _i, _vp],
+    "hidvae_gumbel_gemb": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i, _vp],
     "hidvae_gumbel_rows_bwd": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
-    "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _vp],
+    "hidvae_gumbel_finish": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _i64, _i, _vp],
     "hidvae_cat_recon_rows": [_vp, _i64, _vp, _i64, _i64, _i64, _i, _vp, _i64, _vp, _vp, _vp],
     "hidvae_loss_fwd": [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _f, _vp],
@@ -1031,7 +1031,7 @@ def infonce_dlogits_chunk(Sc, col0, tau, scale, lse, g):
     return Sc
 
 
-MIXUP_PLAN_MAX_B = 4096
+MIXUP_PLAN_MAX_B = 16384
 
 
 def mixup_plan(targets, uniforms, alpha, rng_state=None):
@@ -1083,22 +1083,24 @@ def kmeans_iter(x, centroids, assign, reseed_idx, new_centroids, shift_scratch, 
 
 
 # ------------------------------------------------------------------------------------------------ gumbel branch
-def gumbel_rows_fwd(S, x, cc, U, temperature):
+def gumbel_rows_fwd(S, x, cc, U, temperature, cosine=False):
     B, K = S.shape
     ids = torch.empty((B,), device=S.device, dtype=torch.int64)
-    _check(lib().hidvae_gumbel_rows_fwd(_p(S), _p(x), _p(cc), _p(U), B, K, float(temperature), _p(ids), _stream()), "hidvae_gumbel_rows_fwd")
+    _check(lib().hidvae_gumbel_rows_fwd(_p(S), _p(x), _p(cc), _p(U), B, K, float(temperature), _p(ids), int(x.shape[1]), int(bool(cosine)),
+                                        _stream()), "hidvae_gumbel_rows_fwd")
     return ids
 
 
 def gumbel_loss(x, emb, beta):
     loss = torch.empty((x.shape[0],), device=x.device, dtype=torch.float32)
-    _check(lib().hidvae_gumbel_loss(_p(x), _p(emb), x.shape[0], float(beta), _p(loss), _stream()), "hidvae_gumbel_loss")
+    _check(lib().hidvae_gumbel_loss(_p(x), _p(emb), x.shape[0], float(beta), _p(loss), int(x.shape[1]), _stream()), "hidvae_gumbel_loss")
     return loss
 
 
 def gumbel_gemb(g_out, g_l, x, emb):
     out = torch.empty_like(x)
-    _check(lib().hidvae_gumbel_gemb(_p(g_out), _p(g_l), _vec_stride(g_l), _p(x), _p(emb), x.shape[0], _p(out), _stream()), "hidvae_gumbel_gemb")
+    _check(lib().hidvae_gumbel_gemb(_p(g_out), _p(g_l), _vec_stride(g_l), _p(x), _p(emb), x.shape[0], _p(out), int(x.shape[1]), _stream()),
+           "hidvae_gumbel_gemb")
     return out
 
 
@@ -1111,7 +1113,7 @@ def gumbel_rows_bwd(P, gP, temperature):
 
 def gumbel_finish(g_x, x, emb, g_xx, g_l, beta, g_cb, cb, gS_colsum):
     _check(lib().hidvae_gumbel_finish(_p(g_x), _p(x), _p(emb), _p(g_xx), _p(g_l), _vec_stride(g_l), float(beta), x.shape[0], _p(g_cb), _p(cb),
-                                      _p(gS_colsum), cb.shape[0], _stream()), "hidvae_gumbel_finish")
+                                      _p(gS_colsum), cb.shape[0], int(x.shape[1]), _stream()), "hidvae_gumbel_finish")
 
 
 # ------------------------------------------------------------------------------------------------ grouped launches

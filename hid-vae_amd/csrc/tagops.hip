@@ -1384,7 +1384,7 @@ extern "C" int hidvae_infonce_dlogits(float *P, int64_t B, float tau, float scal
 // caller's generator (B keys + 64 spare draws per level for the rejection sampler), so graph replay semantics stay torch's.
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int MIX_MAXB = 4096, MIX_SPARE = 64;
+constexpr int MIX_MAXB = 16384, MIX_SPARE = 64;  // (rows: the sort's keys and row numbers live in LDS, 6 bytes per row)
 
 __device__ float mix_gamma(float shape, const float *u, int &k) {  // Gamma(shape, 1), shape > 0
     const float boost = shape < 1.0f ? powf(fmaxf(u[k++ % MIX_SPARE], 1e-30f), 1.0f / shape) : 1.0f;  // G(a) = G(a+1) U^(1/a)
@@ -1407,9 +1407,7 @@ constexpr unsigned MIX_SITE = 0x4d495800u;  // the mixup plan's randomness site 
 __global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets, int64_t B, int64_t ldt, const float *u, float alpha,
                                                           int64_t *partner, int64_t *inverse, float *lam,
                                                           const unsigned long long *rng_state) {
-    __shared__ float key[MIX_MAXB];
-    __shared__ int idx[MIX_MAXB];
-    __shared__ int inv[MIX_MAXB];
+    extern __shared__ __attribute__((aligned(16))) unsigned char mix_lds[];  // key float[n2], then idx unsigned short[n2]
     __shared__ int part[1024];
     __shared__ float spare[MIX_SPARE];
     const int lvl = blockIdx.x, tid = threadIdx.x;
@@ -1418,12 +1416,15 @@ __global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets
     if (tid < MIX_SPARE) spare[tid] = ul != nullptr ? ul[B + tid] : hv_rng_uniform(rng_state, MIX_SITE + (unsigned)lvl, (unsigned long long)(B + tid));
     int n2 = 1024;
     while (n2 < B) n2 <<= 1;
+    float *key = reinterpret_cast<float *>(mix_lds);
+    unsigned short *idx = reinterpret_cast<unsigned short *>(mix_lds + 4 * (size_t)n2);
+    int64_t *inv = inverse + (int64_t)lvl * B;  // (written in place: -1 everywhere first, the valid rows' entries after the barrier below)
     for (int i = tid; i < n2; i += 1024) {
         const bool valid = i < B && targets[(int64_t)i * ldt + lvl] >= 0;
         const float ui = !valid ? 0.0f : (ul != nullptr ? ul[i] : hv_rng_uniform(rng_state, MIX_SITE + (unsigned)lvl, (unsigned long long)i));
         key[i] = valid ? ui : (i < B ? 2.0f : 3.0f);  // valid rows first, then the invalid ones, then the padding
-        idx[i] = i;
-        inv[i] = -1;
+        idx[i] = (unsigned short)i;
+        if (i < B) inv[i] = -1;
     }
     __syncthreads();
     for (int k = 2; k <= n2; k <<= 1)
@@ -1460,12 +1461,10 @@ __global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets
         const int i = tid * per + r;
         if (i >= B) break;
         const bool valid = targets[(int64_t)i * ldt + lvl] >= 0;
-        const int pr = valid ? idx[rank] : -1;
+        const int pr = valid ? (int)idx[rank] : -1;
         partner[(int64_t)lvl * B + i] = pr;
         if (valid) { inv[pr] = i; rank++; }
     }
-    __syncthreads();
-    for (int i = tid; i < B; i += 1024) inverse[(int64_t)lvl * B + i] = inv[i];
     if (tid == 0) {
         int k = 0;
         const float x = mix_gamma(alpha, spare, k), y = mix_gamma(alpha, spare, k);
@@ -1480,7 +1479,12 @@ extern "C" int hidvae_mixup_plan(const int64_t *targets, int64_t B, int L, int64
     HV_REQUIRE(targets && (uniforms || rng_state) && partner && inverse && lam && B >= 1 && L >= 1 && ld_targets >= L && alpha > 0.0f,
                "mixup_plan: bad arguments");
     HV_REQUIRE(B <= MIX_MAXB, "mixup_plan: B=%lld rows do not fit the in-LDS sort (max %d)", (long long)B, MIX_MAXB);
-    hipLaunchKernelGGL(mixup_plan_kernel, dim3((unsigned)L), dim3(1024), 0, (hipStream_t)stream, targets, B, ld_targets, uniforms, alpha,
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&mixup_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       6 * MIX_MAXB);
+    HV_REQUIRE(attr == hipSuccess, "mixup_plan: could not size the LDS of mixup_plan_kernel");
+    size_t n2 = 1024;
+    while ((int64_t)n2 < B) n2 <<= 1;
+    hipLaunchKernelGGL(mixup_plan_kernel, dim3((unsigned)L), dim3(1024), 6 * n2, (hipStream_t)stream, targets, B, ld_targets, uniforms, alpha,
                        partner, inverse, lam, rng_state);
     HV_LAUNCH_CHECK("mixup_plan");
     return HIDVAE_OK;

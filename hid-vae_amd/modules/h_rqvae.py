@@ -301,8 +301,6 @@ class HRqVae(nn.Module, _HubMixin):
         """-> z, ids [B,L], emb_cat [B,L*D], emb_sum [B,D], qloss [B], res_cat"""
         self._maybe_kmeans(y, normalize_input)
         if self.training and self.codebook_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
-            if self.embed_dim != _C.EMBED_DIM:
-                raise NotImplementedError("GUMBEL_SOFTMAX training is built for embed_dim = 32 only (no shipped config trains in that mode)")
             from ..gumbel_path import gumbel_all_levels
             return gumbel_all_levels(self, y, normalize_input)
         return RQFn.apply(y.contiguous(), normalize_input, self._fused_mode(), self.training, self.commitment_weight,

@@ -37,9 +37,6 @@ class Quantize(nn.Module):
         super().__init__()
         if distance_mode not in (QuantizeDistance.L2, QuantizeDistance.COSINE):
             raise Exception("Unsupported Quantize distance mode.")  # quantize.py:121
-        if distance_mode == QuantizeDistance.COSINE and forward_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
-            raise NotImplementedError("QuantizeDistance.COSINE with GUMBEL_SOFTMAX: the Gumbel row kernels rank by the L2 distance only "
-                                      "(no reference config or caller selects the cosine distance; STE / ROTATION_TRICK / eval take it)")
         self.embed_dim, self.n_embed = embed_dim, n_embed
         self.embedding = nn.Embedding(n_embed, embed_dim)
         self.forward_mode, self.distance_mode = forward_mode, distance_mode
@@ -84,7 +81,8 @@ class Quantize(nn.Module):
         mode = self.forward_mode.value
         if self.training and mode == QuantizeForwardMode.GUMBEL_SOFTMAX.value:
             from ..gumbel_path import gumbel_level
-            return QuantizeOutput(*gumbel_level(self, x, temperature))
+            return QuantizeOutput(*gumbel_level(self, x, temperature, rand=getattr(self, "rand", None),
+                                                cosine=self.distance_mode == QuantizeDistance.COSINE))
         if self.distance_mode == QuantizeDistance.COSINE:  # -(x/|x| . c)/|c| ranks the codes (quantize.py:115-119); all else as L2
             mode = (mode, _C.DIST_COSINE)
         _, ids, emb_cat, _, qloss, _ = RQFn.apply(x.contiguous(), False, mode, self.training, self.quantize_loss.commitment_weight,

@@ -78,7 +78,7 @@ class DeviceRand:
         Random pairing of the VALID rows (target >= 0) among themselves, as loss.py:144 does on the compacted rows:
         partner[b] = row mixed into b, inverse[partner[b]] = b, -1 on invalid rows; lam ~ Beta(alpha, alpha) (device)."""
         B, L = targets.shape
-        if targets.is_cuda and B <= 4096 and targets.dtype == torch.int64 and targets.stride(1) == 1:
+        if targets.is_cuda and B <= 16384 and targets.dtype == torch.int64 and targets.stride(1) == 1:
             # one launch (csrc/tagops.hip mixup_plan_kernel), its uniforms drawn inside from the counter-based generator
             from . import _C
             partner, inverse, lam = _C.mixup_plan(targets, None, self.mixup_alpha, rng_state=self.state(device))

@@ -448,7 +448,7 @@ int hidvae_infonce_dlogits(float *P, int64_t B, float tau, float scale, const fl
 /* The mixup plan of one training step for all L levels (loss.py:139-147: perm = randperm(n_valid), lam ~ Beta(alpha, alpha)):
  * targets [B, ld>=L] int64 (-1 = invalid row); uniforms [L, B+64] in [0,1) from the caller's generator (B sort keys + 64 spare
  * draws for the gamma sampler, per level), or NULL with rng_state: then the kernel draws them itself (counter-based, see hidvae_rng_advance).  partner [L,B]: partner[l][b] = the row mixed into b, a uniformly random permutation
- * of level l's valid rows among themselves, -1 on invalid rows; inverse [L,B]: inverse[l][partner[l][b]] = b; lam [L].  B <= 4096. */
+ * of level l's valid rows among themselves, -1 on invalid rows; inverse [L,B]: inverse[l][partner[l][b]] = b; lam [L].  B <= 16384 (the sort keys and row numbers of a level live in LDS, 6 bytes per row). */
 int hidvae_mixup_plan(const int64_t *targets, int64_t B, int L, int64_t ld_targets, const float *uniforms, float alpha,
                       int64_t *partner, int64_t *inverse, float *lam, const unsigned long long *rng_state, void *stream);
 /* TagPredictionLoss (loss.py:107-265) with the model's layer_idx = 0 call.  target -1 = invalid row.
@@ -475,20 +475,23 @@ int hidvae_kmeans_iter(const float *x, int64_t N, const float *centroids, int64_
                        const int64_t *reseed_idx, float *new_centroids, float *shift_scratch, float *shift, int embed_dim, void *stream);
 
 /* ---- a6: GUMBEL_SOFTMAX training branch of one level (quantize.py:125-130, distributions/gumbel.py:8-18); row kernels
- * around the GEMMs (S = x cb^T, emb = P cb and their gradients run on hidvae_gemm_f32).  D = 32.
+ * around the GEMMs (S = x cb^T, emb = P cb and their gradients run on hidvae_gemm_f32).  Any embed_dim <= 64.
  * rows_fwd : S [B,K] in -> P = softmax((-(|x|^2+cc-2S) + G)/T) in place, G from the uniform draws U [B,K]; ids = argmin dist.
+ *            cosine != 0 (QuantizeDistance.COSINE, quantize.py:115-119): S arrives as x^ c^T of the NORMALISED operands, dist = -S
+ *            (x and cc are not read then and may be NULL).
  * loss     : loss[b] = (1+beta)|x-emb|^2.        gemb: g_emb = g_out + g_l[b*stride]*2(emb-x).
- * rows_bwd : gP [B,K] (= g_emb cb^T) -> g_S in place, g_xx[b] = d/d|x_b|^2.
+ * rows_bwd : gP [B,K] (= g_emb cb^T) -> g_S in place (for the L2 distance: d dist / d S = -2; halve it for the cosine form),
+ *            g_xx[b] = d/d|x_b|^2.
  * finish   : g_x += 2 x g_xx + g_l 2 beta (x-emb);  g_cb += 2 cb * (-colsum(g_S)/2). */
 int hidvae_gumbel_rows_fwd(float *S, const float *x, const float *cc, const float *U, int64_t B, int64_t K,
-                           float temperature, int64_t *ids, void *stream);
-int hidvae_gumbel_loss(const float *x, const float *emb, int64_t B, float beta, float *loss, void *stream);
+                           float temperature, int64_t *ids, int embed_dim, int cosine, void *stream);
+int hidvae_gumbel_loss(const float *x, const float *emb, int64_t B, float beta, float *loss, int embed_dim, void *stream);
 int hidvae_gumbel_gemb(const float *g_out, const float *g_l, int64_t gl_stride, const float *x, const float *emb, int64_t B,
-                       float *g_emb, void *stream);
+                       float *g_emb, int embed_dim, void *stream);
 int hidvae_gumbel_rows_bwd(const float *P, float *gP, int64_t B, int64_t K, float temperature, float *g_xx, void *stream);
 int hidvae_gumbel_finish(float *g_x, const float *x, const float *emb, const float *g_xx, const float *g_l,
                          int64_t gl_stride, float beta, int64_t B, float *g_cb, const float *cb, const float *gS_colsum,
-                         int64_t K, void *stream);
+                         int64_t K, int embed_dim, void *stream);
 
 /* distributions/gumbel.py:8-18 as stand-alone functions: G = -log(-log(U+eps)+eps) elementwise; out = softmax((logits+G(U))/T)
  * per row.  U: uniform draws in [0,1) from the caller's generator (the library holds no RNG state). */

@@ -67,8 +67,43 @@ def run(name, B, D, K, mode, training, normalize, beta=0.4, seed=70):
           f"ids differing from the L2 ranking: {(l2 != out.ids).float().mean():.2f}")
 
 
+def run_gumbel(name, B, D, K, normalize, beta=0.4, seed=90, temperature=0.2):
+    """GUMBEL_SOFTMAX training with the cosine ranking (quantize.py:115-119,125-130); torch.rand inside distributions/gumbel.py:10 is
+    routed to a formula so the draws can be replayed (fill.uniform(seed + 5))."""
+    x, E, g_out, g_loss = inputs(B, D, K, seed)
+    U = fill.uniform((B, K), seed + 5, 0.0, 1.0)
+    q = Quantize(embed_dim=D, n_embed=K, do_kmeans_init=False, codebook_normalize=normalize, sim_vq=False, commitment_weight=beta,
+                 forward_mode=QuantizeForwardMode.GUMBEL_SOFTMAX, distance_mode=QuantizeDistance.COSINE)
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(E))
+    q.train(True)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    saved = torch.rand
+    torch.rand = lambda shape, **kw: torch.from_numpy(U).reshape(tuple(shape))
+    try:
+        out = q(xt, temperature=temperature)
+    finally:
+        torch.rand = saved
+    ((out.embeddings * torch.from_numpy(g_out)).sum() + (out.loss * torch.from_numpy(g_loss)).sum()).backward()
+    with torch.no_grad():
+        cb = q.out_proj(q.embedding.weight)
+        xd = xt.detach()
+        d = -((xd / xd.norm(dim=1, keepdim=True)) @ cb.T / cb.T.norm(dim=0, keepdim=True))
+        top2 = torch.topk(d, 2, dim=1, largest=False).values
+    fx = {"embeddings": out.embeddings.detach().numpy(), "ids": out.ids.numpy().astype(np.int32), "loss": out.loss.detach().numpy(),
+          "grad_x": xt.grad.numpy(), "grad_E": q.embedding.weight.grad.numpy(), "margins": (top2[:, 1] - top2[:, 0]).numpy(),
+          "desc": json.dumps(dict(name=name, B=B, D=D, K=K, mode=1, training=True, normalize=normalize, beta=beta, seed=seed,
+                                  temperature=temperature, torch=torch.__version__))}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    print(f"{name:34s} loss.mean={fx['loss'].mean():.6f} min_margin={fx['margins'].min():.2e}")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--gumbel" in sys.argv:
+        run_gumbel("qgumbel_cosine_train_b80", 80, 32, 128, False)
+        run_gumbel("qgumbel_cosine_train_d64_norm_b48", 48, 64, 96, True, seed=91)
+        sys.exit(0)
     run("quantize_cosine_rot_train_b200", 200, 32, 256, 3, True, False)
     run("quantize_cosine_ste_train_d64_b96", 96, 64, 100, 2, True, False)
     run("quantize_cosine_rot_eval_norm_b64", 64, 32, 256, 3, False, True)

@@ -19,7 +19,9 @@ def case_names(kind="case"):
             out.append(n)
         elif kind == "quantize" and n.startswith("quantize"):
             out.append(n)
-        elif kind == "case" and not n.startswith(("kmeans", "train", "rqvae", "tokenizer", "quantize")):
+        elif kind == "qgumbel" and n.startswith("qgumbel"):
+            out.append(n)
+        elif kind == "case" and not n.startswith(("kmeans", "train", "rqvae", "tokenizer", "quantize", "qgumbel")):
             out.append(n)
         elif kind == "kmeans" and n.startswith("kmeans"):
             out.append(n)

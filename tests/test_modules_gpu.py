@@ -1,6 +1,8 @@
 """GPU: the reference's small modules as stand-alone callables on the HIP path -- ReconstructionLoss / QuantizeLoss
 (reference modules/loss.py:7-12, 36-44), SemanticIdUniquenessLoss called directly (h_rqvae.py:41-105), distributions/gumbel.py --
 each against the torch expression the reference evaluates, values and gradients."""
+import types
+
 import numpy as np
 import pytest
 import torch
@@ -291,5 +293,30 @@ def test_quantize_level_with_the_cosine_ranking_matches_the_reference(name):
     assert np.array_equal(ids.cpu().numpy(), want["ids"])
     assert np.array_equal(emb_cat.cpu().numpy(), want["emb_cat"])
     assert np.array_equal(qloss.cpu().numpy(), want["loss"])
-    with pytest.raises(NotImplementedError):
-        Quantize(embed_dim=32, n_embed=8, distance_mode=QuantizeDistance.COSINE)  # (GUMBEL_SOFTMAX is the ctor default)
+
+
+@pytest.mark.parametrize("name", H.case_names("qgumbel"))
+def test_quantize_level_gumbel_softmax_with_the_cosine_ranking_matches_the_reference(name):
+    """Quantize(GUMBEL_SOFTMAX -- the ctor default --, distance_mode=COSINE) in training (reference modules/quantize.py:115-119,125-130),
+    D = 32 and 64, with and without codebook normalisation, the Gumbel draws replayed from the fixture's formula: ids on the rows whose
+    top-2 gap is not a near-tie, embeddings / loss / both gradients against the reference's own run"""
+    from hidvae_amd.modules.quantize import Quantize, QuantizeDistance, QuantizeForwardMode
+    from oracle import fill
+    fx, d = H.load(name)
+    x, E, g_out, g_loss = H.quantize_inputs(d)
+    U = fill.uniform((d["B"], d["K"]), d["seed"] + 5, 0.0, 1.0)
+    q = Quantize(embed_dim=d["D"], n_embed=d["K"], do_kmeans_init=False, codebook_normalize=d["normalize"], commitment_weight=d["beta"],
+                 forward_mode=QuantizeForwardMode.GUMBEL_SOFTMAX, distance_mode=QuantizeDistance.COSINE).cuda()
+    q.rand = types.SimpleNamespace(gumbel_u=lambda shape, device: torch.from_numpy(U).to(device).reshape(tuple(shape)))
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(E))
+    q.train(True)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    out = q(xt, temperature=d["temperature"])
+    safe = fx["margins"] > 1e-6
+    assert np.array_equal(out.ids.cpu().numpy()[safe], fx["ids"].astype(np.int64)[safe])
+    assert H.rel_err(out.embeddings.detach().cpu().numpy(), fx["embeddings"]) <= 2e-5
+    assert H.rel_err(out.loss.detach().cpu().numpy(), fx["loss"]) <= 2e-5
+    ((out.embeddings * torch.from_numpy(g_out).cuda()).sum() + (out.loss * torch.from_numpy(g_loss).cuda()).sum()).backward()
+    assert H.close(xt.grad.cpu().numpy(), fx["grad_x"], 5e-5, 1e-6)
+    assert H.close(q.embedding.weight.grad.cpu().numpy(), fx["grad_E"], 5e-5, 1e-6)

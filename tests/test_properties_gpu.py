@@ -286,7 +286,7 @@ def test_mixup_plan_kernel_properties(C):
     themselves with the matching inverse, -1 on invalid rows, for ragged / maximal / single-row shapes; over many draws lam has the
     mean and variance of Beta(alpha, alpha) and the pairing is not biased towards any row."""
     g = torch.Generator(device="cuda").manual_seed(23)
-    for B, L in ((1, 1), (7, 3), (1000, 3), (1025, 2), (4096, 8)):
+    for B, L in ((1, 1), (7, 3), (1000, 3), (1025, 2), (4096, 8), (8192, 3), (16384, 2), (12345, 3)):
         t = torch.randint(0, 5, (B, L), device="cuda", generator=g)
         t[torch.rand(B, device="cuda", generator=g) < 0.3, 0] = -1
         if L > 1:
@@ -303,7 +303,13 @@ def test_mixup_plan_kernel_properties(C):
             assert (inv[p[valid]] == rows).all()
             assert 0.0 <= float(lam[l]) <= 1.0
         again = C.mixup_plan(t, u, 0.2)  # same uniforms, same plan
-        assert torch.equal(again[0], partner) and torch.equal(again[2], lam)
+        assert torch.equal(again[0], partner) and torch.equal(again[1], inverse) and torch.equal(again[2], lam)
+        if B > 1:  # the pairing is the valid rows sorted by (key, row): the definition, whatever the size
+            for l in range(L):
+                rows = torch.nonzero(t[:, l] >= 0).flatten()
+                if len(rows):
+                    order = rows[torch.argsort(u[l, rows] * 0 + u[l, rows], stable=True)]
+                    assert torch.equal(partner[l, rows], order)
     B, L, alpha = 64, 8, 0.2
     t = torch.zeros(B, L, dtype=torch.int64, device="cuda")
     lams, firsts = [], []
