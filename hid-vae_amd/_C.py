@@ -84,6 +84,7 @@ _SIGNATURES = {
     "hidvae_sqdiff_rows_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _f, _f, _vp, _vp, _vp],
     "hidvae_gumbel_noise": [_vp, _i64, _f, _vp, _vp],
     "hidvae_gumbel_softmax_rows": [_vp, _vp, _i64, _i64, _f, _vp, _vp],
+    "hidvae_softmax_argmax_rows": [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp],
     "hidvae_timestamp": [_vp, _vp],
     "hidvae_linear_bwd_group": [_vp, _i, _vp],
 }
@@ -1182,6 +1183,19 @@ def sqdiff_rows_bwd(g, a, b, scale_a, scale_b, want_a=True, want_b=True):
     _check(lib().hidvae_sqdiff_rows_bwd(_p(g), _vec_stride(g), _p(a), _row_stride(a, "a"), _p(b), _row_stride(b, "b"), M, N, float(scale_a),
                                         float(scale_b), _p(ga), _p(gb), _stream()), "hidvae_sqdiff_rows_bwd")
     return ga, gb
+
+
+def softmax_argmax_rows(logits, pred, conf, col):
+    """logits [B, C]; pred int64 [B, L], conf float32 [B, L]: column `col` of both receives the row's first arg max and its softmax
+    probability (HRqVae.predict_tags, one launch per level, no [B, C] softmax intermediate)"""
+    _f32(logits, "logits")
+    B, C = logits.shape
+    if pred.dtype != torch.int64 or conf.dtype != torch.float32 or pred.shape != conf.shape or pred.shape[0] != B or not pred.is_contiguous() \
+            or not conf.is_contiguous():
+        raise RuntimeError("softmax_argmax_rows: expected contiguous pred int64 [B, L] and conf float32 [B, L]")
+    L = pred.shape[1]
+    _check(lib().hidvae_softmax_argmax_rows(_p(logits), B, C, _row_stride(logits, "logits"), ctypes.c_void_p(pred.data_ptr() + 8 * col), L,
+                                            ctypes.c_void_p(conf.data_ptr() + 4 * col), L, _stream()), "hidvae_softmax_argmax_rows")
 
 
 def gumbel_noise(U, eps=1e-20):

@@ -109,3 +109,45 @@ extern "C" int hidvae_gumbel_softmax_rows(const float *logits, const float *U, i
     HV_LAUNCH_CHECK("gumbel_softmax_rows");
     return HIDVAE_OK;
 }
+
+// ---- HRqVae.predict_tags (reference modules/h_rqvae.py:716-722): per row, the arg max of the logits and its softmax probability --
+// conf = max softmax(logits) = 1 / sum_j exp(l_j - l_max), pred = the FIRST maximal column (torch.max's CPU tie rule, as the reference
+// runs it).  One wave per row; replaces torch.softmax(...).max(...) (two torch kernels and a [B, C] intermediate per level).
+namespace {
+__global__ __launch_bounds__(256) void softmax_argmax_rows_kernel(const float *logits, int64_t B, int64_t C, int64_t ld, int64_t *pred,
+                                                                  int64_t pred_stride, float *conf, int64_t conf_stride) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float *l = logits + row * ld;
+    float best = -INFINITY;
+    int64_t bi = 0;
+    for (int64_t c = lane; c < C; c += 64) {
+        const float v = l[c];
+        if (v > best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int64_t oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    float sum = 0.0f;
+    for (int64_t c = lane; c < C; c += 64) sum += expf(l[c] - best);
+    sum = hv_wave_sum(sum);
+    if (lane == 0) {
+        pred[row * pred_stride] = bi;
+        conf[row * conf_stride] = 1.0f / sum;
+    }
+}
+}  // namespace
+
+extern "C" int hidvae_softmax_argmax_rows(const float *logits, int64_t B, int64_t C, int64_t ld_logits, int64_t *pred, int64_t pred_stride,
+                                          float *conf, int64_t conf_stride, void *stream) {
+    HV_REQUIRE(logits && pred && conf && B >= 1 && C >= 1 && ld_logits >= C && pred_stride >= 1 && conf_stride >= 1,
+               "softmax_argmax_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_argmax_rows_kernel, dim3((unsigned)hv_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, logits, B, C, ld_logits,
+                       pred, pred_stride, conf, conf_stride);
+    HV_LAUNCH_CHECK("softmax_argmax_rows");
+    return HIDVAE_OK;
+}

@@ -469,14 +469,13 @@ class HRqVae(nn.Module, _HubMixin):
         z = self.encode(flat)
         out = self.get_semantic_ids(z, None, None, gumbel_t)
         emb_cat = out.embeddings.transpose(1, 2).reshape(z.shape[0], -1)
-        preds, confs = [], []
-        for i in range(self.n_layers):
+        n = z.shape[0]
+        preds = torch.empty((n, self.n_layers), dtype=torch.int64, device=z.device)
+        confs = torch.empty((n, self.n_layers), dtype=torch.float32, device=z.device)
+        for i in range(self.n_layers):  # the eval-mode launch chain of the heads, then ONE launch for arg max + its softmax probability
             logits = self.tag_predictors[i](emb_cat[:, : (i + 1) * self.embed_dim])
-            conf, pred = torch.softmax(logits, dim=-1).max(dim=-1)
-            preds.append(pred)
-            confs.append(conf)
+            _C.softmax_argmax_rows(logits.contiguous(), preds, confs, i)
         self.train(was_training)
         if x.dim() == 3:
-            preds = [p.reshape(shape[0], shape[1]) for p in preds]
-            confs = [c.reshape(shape[0], shape[1]) for c in confs]
-        return {"predictions": torch.stack(preds, dim=-1), "confidences": torch.stack(confs, dim=-1)}
+            preds, confs = preds.reshape(shape[0], shape[1], self.n_layers), confs.reshape(shape[0], shape[1], self.n_layers)
+        return {"predictions": preds, "confidences": confs}

@@ -498,6 +498,11 @@ int hidvae_gumbel_finish(float *g_x, const float *x, const float *emb, const flo
 int hidvae_gumbel_noise(const float *U, int64_t n, float eps, float *out, void *stream);
 int hidvae_gumbel_softmax_rows(const float *logits, const float *U, int64_t B, int64_t K, float temperature, float *out,
                                void *stream);
+/* HRqVae.predict_tags (h_rqvae.py:716-722: torch.softmax(logits, -1).max(-1)): per row of logits [B, ld >= C] the first maximal
+ * column -> pred[row * pred_stride] and its softmax probability 1 / sum_j exp(l_j - l_max) -> conf[row * conf_stride]; the strides
+ * let a level write its column of the stacked [B, L] outputs in place. */
+int hidvae_softmax_argmax_rows(const float *logits, int64_t B, int64_t C, int64_t ld_logits, int64_t *pred, int64_t pred_stride,
+                               float *conf, int64_t conf_stride, void *stream);
 
 /* ---- measurement aid: *slot = the device's constant-rate wall clock (wall_clock64: 100 MHz, 10 ns ticks), stored by a
  * one-wave kernel launched on `stream`.  Launched before and after another launch INSIDE a captured step it brackets that launch's

@@ -320,3 +320,22 @@ def test_quantize_level_gumbel_softmax_with_the_cosine_ranking_matches_the_refer
     ((out.embeddings * torch.from_numpy(g_out).cuda()).sum() + (out.loss * torch.from_numpy(g_loss).cuda()).sum()).backward()
     assert H.close(xt.grad.cpu().numpy(), fx["grad_x"], 5e-5, 1e-6)
     assert H.close(q.embedding.weight.grad.cpu().numpy(), fx["grad_E"], 5e-5, 1e-6)
+
+
+def test_softmax_argmax_rows_is_torchs_softmax_max():
+    """HRqVae.predict_tags' launch (reference h_rqvae.py:716-722: torch.softmax(logits, -1).max(-1)): first arg max per row and its
+    softmax probability, written into one column of the stacked [B, L] outputs; ragged widths, ties, one-column logits"""
+    from hidvae_amd import _C
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for B, C in ((1, 1), (5, 38), (333, 168), (1024, 348), (64, 1000)):
+        logits = torch.randn(B, C, device="cuda", generator=g) * 3
+        if C > 4:
+            logits[0, 3] = logits[0, 1] = logits[0].max() + 1.0  # a tie: the first maximal column wins
+        pred = torch.full((B, 3), -7, dtype=torch.int64, device="cuda")
+        conf = torch.full((B, 3), -7.0, device="cuda")
+        _C.softmax_argmax_rows(logits, pred, conf, 1)
+        want_c, _ = torch.softmax(logits.double(), dim=-1).max(dim=-1)
+        want_p = torch.from_numpy(np.argmax(logits.cpu().numpy(), axis=1))  # (numpy: first maximum)
+        assert torch.equal(pred[:, 1].cpu(), want_p)
+        assert torch.allclose(conf[:, 1].double(), want_c, rtol=2e-6, atol=1e-7)
+        assert (pred[:, 0] == -7).all() and (pred[:, 2] == -7).all() and (conf[:, 0] == -7).all() and (conf[:, 2] == -7).all()
