@@ -613,8 +613,16 @@ __device__ __forceinline__ void pf32_tile(const char *Ch, const char *Cl, const 
 // IDS (the corpus tokenisation of HSemanticIdTokenizer.precompute_corpus_ids, reference h_semids.py:109-195: only the ids leave the
 // launch): eval-mode search with NO output but ids -- no z / emb_cat / emb_sum / res_cat / loss stores and none of their arithmetic,
 // no winner-row fetch after the last level (nothing consumes that residual).  Same scores, same decisions: the same ids.
-template <int MODE, bool TRAIN, int NW, int NT, bool PIPE = false, bool IDS = false>  // NT: 32-code tiles per level when known at compile time (full unroll), else 0
+// SCAN2 (with PIPE): the two-stage scan.  The one-stage scan spends three vector instructions per score (index pack, med3, min) on every
+// one of the level's K scores -- the measured bound of this kernel (71 % of its cycles are vector-ALU issue).  But the index and the
+// runner-up are only needed where the minimum is: per 32-code tile the lane takes the tile's minimum with v_min3_f32 (two scores per
+// instruction), keeps the two smallest tile minima, and copies the tile's sixteen accumulators aside when the tile is the best so far
+// (one v_cndmask each): 28 instructions per tile instead of 50.  The kept tile then gets the exact index-carrying scan once per level,
+// and the level's second smallest score is the smaller of the kept tile's second smallest and the second smallest TILE minimum
+// (every other tile's minimum bounds its scores from below).  Same scores, same decision rule: the same ids and the same undecided list.
+template <int MODE, bool TRAIN, int NW, int NT, bool PIPE = false, bool IDS = false, bool SCAN2 = false>  // NT: 32-code tiles per level when known at compile time (full unroll), else 0
 __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
+    static_assert(!SCAN2 || PIPE, "the two-stage scan lives in the ping-pong form");
     static_assert(!IDS || !TRAIN, "the ids-only form is an eval-mode search");
     extern __shared__ __attribute__((aligned(16))) char pf_lds[];
     __shared__ unsigned ccmax_bits[HIDVAE_MAX_LEVELS];
@@ -688,7 +696,33 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[1], acc, 0, 0, 0);
                     acc2[sl] = acc;
                 };
+                float g1 = INFINITY, g2 = INFINITY;  // SCAN2: the two smallest tile minima
+                f32x16 keep;                           //        the accumulators of the tile that holds the smallest
+                if (SCAN2) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) keep[j] = INFINITY;
+                }
                 auto scan = [&](int tt, int sl) {
+                    if (SCAN2) {
+                        const f32x16 &ac = acc2[sl];
+                        // (plain fminf chains: the compiler emits v_min3_f32 on accumulator values AND pads the MFMA -> reader wait states;
+                        //  an asm v_min3 reading the accumulators straight after the MFMAs got stale values: 13 wrong ids in 210,000)
+                        float tm = __builtin_fminf(__builtin_fminf(ac[0], ac[1]), ac[2]);
+                        tm = __builtin_fminf(__builtin_fminf(tm, ac[3]), ac[4]);
+                        tm = __builtin_fminf(__builtin_fminf(tm, ac[5]), ac[6]);
+                        tm = __builtin_fminf(__builtin_fminf(tm, ac[7]), ac[8]);
+                        tm = __builtin_fminf(__builtin_fminf(tm, ac[9]), ac[10]);
+                        tm = __builtin_fminf(__builtin_fminf(tm, ac[11]), ac[12]);
+                        tm = __builtin_fminf(__builtin_fminf(tm, ac[13]), ac[14]);
+                        tm = __builtin_fminf(tm, ac[15]);
+                        const bool better = tm < g1;  // (strict: the first of equal tiles stays -- and equal minima make the item undecided anyway)
+                        g2 = __builtin_amdgcn_fmed3f(g1, g2, tm);
+                        g1 = __builtin_fminf(g1, tm);
+                        tbest = better ? 32 * tt : tbest;
+#pragma unroll
+                        for (int j = 0; j < 16; j++) keep[j] = better ? ac[j] : keep[j];
+                        return;
+                    }
                     const float before = best1;
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
@@ -707,9 +741,18 @@ __global__ __launch_bounds__(64 * NW) void rq_forward_pf32_kernel(FwdArgs a) {
 #pragma unroll
                         for (int i = 0; i < 6; i++) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA of the next tile ...
-                            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // ... eight scan operations of this one under it
+                            __builtin_amdgcn_sched_group_barrier(0x002, SCAN2 ? 5 : 8, 0);  // ... a share of this one's scan operations under it
                         }
                     }
+                }
+                if (SCAN2) {  // the kept tile: the index-carrying scan, once
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const float sc = __uint_as_float((__float_as_uint(keep[j]) & 0xfffffff0u) | (unsigned)j);
+                        best2 = __builtin_amdgcn_fmed3f(best1, best2, sc);
+                        best1 = vmin_f32(best1, sc);
+                    }
+                    best2 = vmin_f32(best2, g2);
                 }
             } else if (NT > 0) {
 #pragma unroll
@@ -1435,7 +1478,7 @@ extern "C" int hidvae_rq_forward(const float *y, int64_t B, int normalize_input,
         const int pgrid = (int)(nt < 256 ? nt : 256);
 #define HV_PF32_GO(M, T, W, NTI, PP, II)                                                                                       \
     {                                                                                                                          \
-        auto kern = rq_forward_pf32_kernel<M, T, W, NTI, PP, II>;                                                              \
+        auto kern = rq_forward_pf32_kernel<M, T, W, NTI, PP, II, PP>;  /* the two-stage scan wherever the tiles ping-pong */    \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf32_bytes); \
         hipLaunchKernelGGL(kern, dim3(pgrid), dim3(64 * W), pf32_bytes, s, p);                                                 \
     }
