@@ -201,6 +201,14 @@ def kernel_rooflines(args, m, device):
                 us=t, flops=fl3)
     (head if args.tagged else dec)["entry"] = "hidvae_linear_bwd"  # the stand-alone figure quoted beside the in-step family of the headline
     out += [dec, head]
+    # the same layer at config 3's batch: from B = 2048 on hidvae_linear_bwd runs on the LDS-DMA ring kernel (csrc/gemm_ring.hip)
+    B2 = 2048
+    gt2, xt2, yt2 = torch.randn(B2, 691, device=device), torch.randn(B2, 768, device=device), torch.rand(B2, 768, device=device)
+    t = time_kernel(lambda: _C.linear_bwd(gt2, xt2, wt, True, _C.EPI_DRELU, yt2, bias=True, dx_scale=1.6), side=lane)
+    fl4 = 4.0 * B2 * 691 * 768
+    out.append(dict(kernel="gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 2048 (LDS-DMA ring, four-wave workgroups, evenly dealt k-steps): "
+                           "dW, gated dX, db in one launch", bound="mfma", achieved=fl4 / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                    frac=fl4 / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None, us=t, flops=fl4))
     # the same layer in the throughput regime (LDS-tiled kernel; corpus tokenisation and large-batch training run here)
     bigm = 1 << 16
     xb, ob, ab = torch.randn(bigm, 768, device=device), torch.empty(bigm, 512, device=device), torch.empty(bigm, 512, device=device)

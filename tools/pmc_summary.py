@@ -18,7 +18,7 @@ QUOTED = [
     ("rq_forward at 1,048,576 items", "rq_forward_pf32_kernel<3, true", None),
     ("gemm_f32_kernel<2,2,NT> encoder layer 0 at 65,536 rows", "gemm_f32_kernel<2, 2, 0>", None),
     ("gemm_mid_sk_kernel decoder layer 3 backward", "gemm_mid_sk_kernel<4, 2>", 229376),   # 96 + 128 tiles (no bias here), 1024 threads each
-    ("gemm_mid_sk_kernel even ranges (B=8192, 256x512 layer)", "gemm_mid_sk_kernel<4, 2>", 262144),
+    ("gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 2048", "gemm_ring_bwd_kernel", None),
     ("gemm_mid_sk_kernel tag-head layer backward 691 x 768", "gemm_mid_sk_kernel<4, 2>", 258048),  # equal ranges over 252 sixteen-wave workgroups
     ("gemm_mid_sk_kernel<2,2> tag-head layer backward 691 x 768 (co-resident form)", "gemm_mid_sk_kernel<2, 2>", None),  # whole tiles, eight-wave workgroups
     ("rq_forward_kernel streamed code-split (4x1024, B=4096)", "rq_forward_kernel<3, true, false, true, 4, true>", None),

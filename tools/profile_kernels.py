@@ -47,7 +47,6 @@ for _ in range(10):
     _C.linear_bwd(gd, xd, wd3, True, _C.EPI_DSILU, pd)
     _C.rq_forward(y5, cb5, cc5, True, 3, True, 0.4)
     _C.gemm(_C.GEMM_NT, x8, w0, out=o8, epilogue=_C.EPI_SILU, aux=a8)       # fp32 LDS-tiled at B = 8192
-    _C.linear_bwd(g8, o8, w1, True, _C.EPI_DSILU, a8)                       # gemm_mid_sk_kernel with even k-step ranges (B = 8192)
 xb = torch.randn(1 << 16, 768, device=dev)
 ob, ab = torch.empty(1 << 16, 512, device=dev), torch.empty(1 << 16, 512, device=dev)
 # round 3: the tag heads' level-2 shapes (the widest Linear backward, LayerNorm both ways, the gate) and the ids-only corpus search
@@ -70,6 +69,11 @@ with torch.cuda.stream(side):
     for _ in range(10):
         _C.linear_bwd(gt, xt, wt, True, _C.EPI_DRELU, yt, bias=True, dx_scale=1.6)
 torch.cuda.current_stream().wait_stream(side)
+# round 4: from B = 2048 on the Linear backward runs on the LDS-DMA ring kernel (gemm_ring.hip): the heads' widest layer at config 3's batch
+B2 = 2048
+gt2, xt2, yt2 = torch.randn(B2, 691, device=dev), torch.randn(B2, 768, device=dev), torch.rand(B2, 768, device=dev)
+for _ in range(10):
+    _C.linear_bwd(gt2, xt2, wt, True, _C.EPI_DRELU, yt2, bias=True, dx_scale=1.6)   # 2048 x 691 x 768: gemm_ring_bwd_kernel
 for _ in range(5):
     _C.rq_forward(y_big, cb, cc, True, 3, True, 0.4)
     _C.rq_ids(y_big, cb, cc, True)                                     # the tokenizer's corpus pass: only the ids leave the launch
