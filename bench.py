@@ -370,6 +370,29 @@ def _cpu_model():
     return "unknown"
 
 
+def _usable_cores():
+    """Cores this process may actually run on: the smaller of the affinity mask and the cgroup CPU quota (a GPU box shows all of the
+    host's logical CPUs in os.cpu_count() while granting a share of them; threads beyond the share only queue)."""
+    n = os.cpu_count() or 8
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def _cpu_point_child(argv):
     """`python bench.py --cpu-point THREADS BUDGET <workload flags>`: one thread-count point of the CPU baseline in a process of its own (no
     GPU use), so the parent can bound it -- all cores of a 100+-core host take ~20 s per step on these small-op graphs"""
@@ -388,7 +411,8 @@ def cpu_baseline(args, budget_s, all_cores=True):
     section 2 holds the true reference code's numbers at 8) and all cores.  Small-op PyTorch does not scale with cores, so the BEST
     point is `value`; the all-core point runs in a child process under a time limit."""
     import subprocess
-    ncpu = os.cpu_count() or 8
+    host = os.cpu_count() or 8
+    ncpu = _usable_cores()
     points, notes, best = [], [], None
 
     def add(th, steps, dt, note=""):
@@ -414,10 +438,10 @@ def cpu_baseline(args, budget_s, all_cores=True):
             add(ncpu, rec["steps"], rec["seconds"])
         except subprocess.TimeoutExpired:
             points.append(dict(threads=ncpu, items_per_s=None, steps=0, seconds=limit))
-            notes.append(f"{ncpu} threads (all cores): not finished within {limit:.0f} s (1 warm-up + 1 step)")
+            notes.append(f"{ncpu} threads (all usable cores of {host}): not finished within {limit:.0f} s (1 warm-up + 1 step)")
         except Exception as e:  # noqa: BLE001  the all-core point is a report, not a requirement
             notes.append(f"{ncpu} threads (all cores): failed ({type(e).__name__})")
-    return dict(value=best[0], unit="items/s", cores=best[1], kind="port", cpu_model=_cpu_model(), host_cores=ncpu, points=points,
+    return dict(value=best[0], unit="items/s", cores=best[1], kind="port", cpu_model=_cpu_model(), host_cores=host, usable_cores=ncpu, points=points,
                 sample=f"full train steps (fwd+bwd+AdamW) of the oracle's torch-CPU restatement at B={args.batch}, "
                        f"{'tagged' if args.tagged else 'untagged'}, {getattr(args, 'hparams', 'amazon')} hyper-parameters, warm-up then a bounded "
                        "sample per thread count: " + "; ".join(notes))
@@ -747,7 +771,9 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                        "graph_queues": os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES"),
                        "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"),
-                       "collectives_in_graph": bool(getattr(info["stepper"], "in_graph", False))},
+                       "collectives_in_graph": bool(getattr(info["stepper"], "in_graph", False)),
+                       "dp_comm": (None if info["stepper"].dp is None else
+                                   "own RCCL communicator (hidvae_amd.rccl)" if getattr(info["stepper"].dp, "_comm", None) else "torch.distributed")},
             "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": roof["kernel"], "us_per_launch": roof["us"]}
                         | {k: roof[k] for k in ("share_of_step", "us_warm", "frac_warm", "largest_launch", "whole_step") if k in roof},
             "windows_ms_per_step": info["windows_ms_per_step"],

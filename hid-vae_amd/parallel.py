@@ -1,5 +1,6 @@
 """Data parallelism for the tokenizer step: one process per GPU, replicas of the model, per-rank item shards, ONE RCCL
-all-reduce of a flat fp32 gradient buffer per optimizer step (torch.distributed backend "nccl" == RCCL on ROCm).
+all-reduce of a flat fp32 gradient buffer per optimizer step, on the package's own RCCL communicator (rccl.py; bootstrapped over the
+torch.distributed group, which also carries the start-up broadcasts and is the fallback for the exchange).
 
 The reference gets the same semantics from accelerate -> DistributedDataParallel (reference train_hidvae.py:186-189,
 630-632, 709): replicated parameters broadcast from rank 0, gradients averaged over ranks before optimizer.step().
@@ -9,6 +10,9 @@ rank 0 and is broadcast (the reference runs it per rank after DDP wrapping, so i
 BatchNorm statistics, InfoNCE negatives and p_unique_ids stay rank-local, as under DDP.
 
 Nothing here touches a HIP kernel, so the logic is exercised on CPU with the gloo backend (tests/test_dp_cpu.py)."""
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -120,13 +124,35 @@ class DataParallel:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.always = False  # rehearsal switch: issue the collective even in a one-rank group (bench.py --dist 1)
+        self._comm = None    # rccl.Communicator once the first exchange asked for it; False: refused, torch.distributed carries it
+
+    def communicator(self):
+        """The package's own RCCL communicator for the gradient exchange (rccl.py: plain stream operations, no watchdog), created by
+        the first exchange -- a collective call, every rank reaches it in the same step -- or None: host-side backends (gloo: the CPU
+        tests), HIDVAE_DP_COMM=torch, or a communicator that could not be built (reported once; torch.distributed then carries the
+        exchange, between graphs)."""
+        if self._comm is None:
+            self._comm = False
+            want = os.environ.get("HIDVAE_DP_COMM", "rccl")
+            if want != "torch" and dist.is_initialized() and self.buf.flat.is_cuda and dist.get_backend(self.group) == "nccl":
+                try:
+                    from .rccl import Communicator
+                    c = Communicator(self.group, self.buf.flat.device)
+                    c.warm_up()
+                    self._comm = c
+                except Exception as e:  # noqa: BLE001  any failure here has a working fallback
+                    print(f"[hidvae] own RCCL communicator unavailable ({type(e).__name__}: {str(e).splitlines()[0]}); the gradient "
+                          "exchange stays on torch.distributed, between graphs", file=sys.stderr)
+        return self._comm or None
 
     def capturable(self):
-        """may the gradient exchange be captured into a HIP graph?  RCCL collectives are stream operations (yes); gloo's run on the
-        host (no).  A one-rank group that issues no collective at all (`always` unset) has nothing to capture."""
+        """may the gradient exchange be captured into a HIP graph?  Only on the package's own communicator.  torch.distributed's "nccl"
+        collectives are stream operations too, but capturing one pulls the process group's internal stream into the capture, and its
+        watchdog thread's next completion poll of ANY earlier eager collective then aborts the process (rccl.py); gloo's run on the
+        host.  A one-rank group that issues no collective at all (`always` unset) has nothing to capture."""
         if not dist.is_initialized() or (self.world == 1 and not self.always):
             return False
-        return dist.get_backend(self.group) == "nccl"
+        return self.communicator() is not None
 
     def broadcast_parameters(self, src=0):
         """DDP-style start: every replica takes rank `src`'s parameters and buffers."""
@@ -146,6 +172,12 @@ class DataParallel:
         self.buf.seal()
         if self.world == 1 and not self.always:
             return 1.0, None
+        c = self.communicator()
+        if c is not None:
+            if async_op:
+                return 1.0 / self.world, c.all_reduce_sum_async_(self.buf.flat)
+            c.all_reduce_sum_(self.buf.flat)
+            return 1.0 / self.world, None
         work = dist.all_reduce(self.buf.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return 1.0 / self.world, work
 
@@ -155,6 +187,9 @@ class DataParallel:
         backend's own stream, i.e. beside what the caller queues next; work.wait() makes the current stream wait for it."""
         if (self.world == 1 and not self.always) or hi <= lo:
             return None
+        c = self.communicator()
+        if c is not None:
+            return c.all_reduce_sum_async_(self.buf.flat[lo:hi])
         return dist.all_reduce(self.buf.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def shard_seed(self, base_seed=0):

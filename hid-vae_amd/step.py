@@ -195,6 +195,9 @@ class GraphedTrainStep:
         from .tagpath import join_tag_streams
         join_side()
         join_tag_streams(self.static[0].x.device)
+        comm = getattr(self.dp, "_comm", None) if self.dp is not None else None
+        if comm:  # the own communicator's stream carries the asynchronous bucket exchanges
+            torch.cuda.current_stream().wait_stream(comm.stream)
 
     def _reset_after_failed_capture(self):
         """a capture that raised part-way leaves host-side bookkeeping of a step that never ran: undo it before anything steps again"""

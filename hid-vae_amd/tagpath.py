@@ -699,7 +699,8 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
             main.wait_stream(side[1])
             for st in side[2:]:
                 st.wait_stream(side[1])
-        scal = {}
+        scal, proj_cut = {}, {}
+        split_align = os.environ.get("HIDVAE_ALIGN_SPLIT", "1") != "0"
         for i in range(L):
             for kind in ("align", "pred"):
                 st = lanes[plan[(kind, i)]]
@@ -711,6 +712,12 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
                         else:
                             with _sites(rand, i, "align"):
                                 proj = tag_projector_forward(model.tag_projectors[i], te[:, i * E:(i + 1) * E], training, rand)
+                        if split_align and proj.requires_grad:
+                            # the projector's backward produces parameter gradients only: cut the tape in front of it, so the level's
+                            # gradient hand-over (HeadsGradPort) is signalled BEFORE it is issued
+                            cut = proj.detach().requires_grad_()
+                            proj_cut[i] = (proj, cut)
+                            proj = cut
                         scal[(kind, i)] = (model.tag_alignment_loss(views[2 * i], proj, i),)
                         _C.phase_mark(f"fwd:level {i} projector+infonce done")
                     else:
@@ -729,6 +736,8 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
         bwd_done = [None] * L
         level_done = getattr(model, "_level_done_hook", None)  # the training loop's: this level's parameters may take their optimizer update
         try:
+            # (not kept: level 0's projector + alignment unit as a guest on another level's lane, behind its host, to shorten the
+            #  caller's lane by ~180 us: 1.235-1.273 ms against 1.156 -- profiles/r04_align0_lane_ab.log)
             for i in range(L):
                 for kind in ("pred", "align"):
                     st = lanes[plan[(kind, i)]]
@@ -736,12 +745,21 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
                     #  caller's stream does not wait for a side stream's backward before HeadsGradPort.collect)
                     with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
                         torch.autograd.backward([scal[(kind, i)][0]], [seed_a if kind == "align" else seed_p])
-                        if kind == "align" and level_done is not None and st is not None:
-                            ev = torch.cuda.Event()  # the gradient hand-over waits for the backward only ...
+                        if kind == "align" and st is not None and level_done is not None:
+                            # (without the hook -- data parallel, gradient accumulation -- the hand-over joins the whole lane: the
+                            #  exchange of the heads' gradients follows it)
+                            ev = torch.cuda.Event()  # the gradient hand-over waits for the backward into emb_cat only ...
                             ev.record(st)
                             bwd_done[i] = ev
-                            flush_layernorm_finals(only_stream=st)  # ... then the level's LayerNorms finish their affine gradients
-                            level_done(i)  # and its parameters take their update, beside the rest of the backward
+                        if kind == "align" and i in proj_cut:  # ... then the projector's backward,
+                            head, cut = proj_cut.pop(i)
+                            g_cut, cut.grad = cut.grad, None
+                            if g_cut is not None:
+                                torch.autograd.backward([head], [g_cut])
+                        if kind == "align" and st is not None and level_done is not None:
+                            flush_layernorm_finals(only_stream=st)  # the lane's LayerNorms finish their affine gradients there
+                            level_done(i)  # and the level's parameters take their update, beside the rest of the backward
+            for i in range(L):
                 aligns.append(scal[("align", i)][0].detach())
                 preds.append(scal[("pred", i)][0].detach())
                 accs.append(scal[("pred", i)][1])

@@ -84,6 +84,9 @@ def _run(tagged, dp_mode, steps=6, B=128, in_graph=True, fail_first_capture=Fals
     rows = []
     for it in range(steps):
         rows.append(st([_batch(cfg, B, 500 + it, tagged)]).clone())
+    if multi:  # the exchange ran on the package's own communicator (hidvae_amd.rccl), not on the process group's
+        from hidvae_amd.rccl import Communicator
+        assert isinstance(dp.communicator(), Communicator) and dp.capturable()
     between = multi and (not in_graph or fail_first_capture)
     assert st.graphs is not None and len(st.graphs) == (3 if between else 1)
     assert st.in_graph == (multi and not between)
@@ -181,6 +184,57 @@ def test_event_query_from_another_thread_breaks_a_global_capture_and_not_a_threa
     """the mechanism behind GraphedTrainStep._capture_mode (no process group involved: deterministic, one run)"""
     import torch.multiprocessing as mp
     mp.spawn(_event_query_worker, nprocs=1, join=True)
+
+
+def _joined_stream_query_worker(rank):
+    """Why the process group's collectives are never captured (hidvae_amd/rccl.py): an event recorded EAGERLY on a stream, long
+    complete, cannot be queried any more once that stream has joined a capture -- whatever the capture mode, whichever thread asks.
+    ProcessGroupNCCL's internal stream joins the capture with the first captured collective; its watchdog's poll of an earlier eager
+    collective is exactly this query."""
+    import threading
+    torch.cuda.set_device(0)
+    x = torch.zeros(1 << 16, device="cuda")
+    s, c = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    with torch.cuda.stream(s):
+        x.add_(1.0)
+        ev.record(s)  # an "eager collective" of a warm-up step on the group's internal stream
+    torch.cuda.synchronize()
+    assert ev.query()
+    seen = {}
+
+    def poll(tag):
+        try:
+            seen[tag] = ev.query()
+        except Exception as e:  # noqa: BLE001
+            seen[tag] = f"{type(e).__name__}: {str(e).splitlines()[0]}"
+
+    g = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.stream(c), torch.cuda.graph(g, stream=c, capture_error_mode="thread_local"):
+            x.mul_(2.0)
+            t = threading.Thread(target=poll, args=("before the stream joins",))
+            t.start(), t.join()
+            fork = torch.cuda.Event()
+            fork.record(c)
+            s.wait_event(fork)  # the first captured collective: the internal stream joins the capture
+            with torch.cuda.stream(s):
+                x.add_(3.0)
+            t = threading.Thread(target=poll, args=("after the stream joined",))
+            t.start(), t.join()
+            c.wait_stream(s)
+    except RuntimeError as e:  # (the refused query may also leave the capture unable to end: not what is tested here)
+        seen["capture"] = str(e).splitlines()[0]
+    print(f"[joined-stream query] {seen}", flush=True)
+    assert seen["before the stream joins"] is True, seen
+    assert isinstance(seen["after the stream joined"], str) and "captur" in seen["after the stream joined"], seen
+
+
+@pytest.mark.timeout(300)
+def test_event_of_a_stream_that_joined_a_capture_cannot_be_queried():
+    """the second way a process group's watchdog kills a captured data-parallel step (deterministic, no process group involved)"""
+    import torch.multiprocessing as mp
+    mp.spawn(_joined_stream_query_worker, nprocs=1, join=True)
 
 
 def _rank_worker(rank, world, port, out_dir, steps, B, tagged=False):
