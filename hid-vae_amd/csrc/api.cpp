@@ -51,7 +51,7 @@ extern "C" int hidvae_query_workspace(int op, const int64_t *d, int n, int64_t *
     case HIDVAE_WS_LAYERNORM_PARAM_GRAD: if (need(2)) fl = 2 * cdiv(d[0], 128) * d[1]; break;          // M, N
     case HIDVAE_WS_LAYERNORM_BWD_ALL: if (need(2)) fl = 2 * cdiv(d[0], 4) * d[1]; break;               // M, N
     case HIDVAE_WS_BATCHNORM_FWD: if (need(2)) fl = 3 * cdiv(d[0], 64) * d[1]; break;                  // M, N
-    case HIDVAE_WS_BATCHNORM_BWD: if (need(2)) fl = 2 * cdiv(d[0], 64) * d[1]; break;                  // M, N
+    case HIDVAE_WS_BATCHNORM_BWD: if (need(2)) fl = 2 * cdiv(d[0], 32) * d[1]; break;                  // M, N
     case HIDVAE_WS_ID_CENSUS: if (need(1)) { *bytes = (4 * d[0] + 3) * 8; return HIDVAE_OK; } break;   // B   (int64 slots, zero-filled once)
     case HIDVAE_WS_RQ_FORWARD: if (need(3)) fl = d[0] >= 65536 ? d[0] + 4 : 0; break;                       // B, L, K  (counter + item list)
     case HIDVAE_WS_KMEANS: if (need(2)) fl = d[1]; break;                                               // N, K

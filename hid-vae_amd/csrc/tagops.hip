@@ -742,23 +742,41 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *x, int64_t l
 
 // backward: partial (sum gh*xhat, sum gh) per (64 columns x 64 rows), then every workgroup adds the chunks of its columns in
 // ascending order and writes gx for 16 rows
+constexpr int BN2_BWD_ROWS = 32;  // rows per partial chunk of the backward: every load of a thread's 8 rows is in flight at once (64-row
+                                  // chunks walked four rows at a time: 14.2 us in the step at 1024 x 512)
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *gy, const float *x, int64_t ldx, const float *gamma,
                                                              const float *beta, const float *save_mean, const float *save_rstd,
                                                              int64_t M, int64_t N, int relu, const float *mask, float scale,
                                                              float *part, const float *yout) {
     __shared__ float red[2][4][64];
+    constexpr int R = BN2_BWD_ROWS / 4;
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * 64 + c;
-    const int64_t m0 = (int64_t)blockIdx.y * BN2_ROWS;
+    const int64_t m0 = (int64_t)blockIdx.y * BN2_BWD_ROWS;
     float sg = 0.0f, sb = 0.0f;
     if (n < N) {
-        const float mu = save_mean[n], rs = save_rstd[n], ga = gamma[n], be = beta[n];
-#pragma unroll 4
-        for (int j = 0; j < BN2_ROWS / 4; j++) {
+        float xv[R], gv[R], ov[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
             const int64_t m = m0 + rl + 4 * j;
-            if (m < M) {
-                const float xh = (x[m * ldx + n] - mu) * rs;
-                const float g = bn_gate(gy[m * N + n], xh, ga, be, relu, mask, yout, m * N + n, scale);
+            const bool ok = m < M;
+            xv[j] = ok ? x[m * ldx + n] : 0.0f;
+            gv[j] = ok ? gy[m * N + n] : 0.0f;
+            ov[j] = 0.0f;
+            if (ok && yout != nullptr) ov[j] = yout[m * N + n];
+            else if (ok && mask != nullptr) ov[j] = mask[m * N + n];
+        }
+        const float mu = save_mean[n], rs = save_rstd[n], ga = gamma[n], be = beta[n];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (m0 + rl + 4 * j < M) {
+                const float xh = (xv[j] - mu) * rs;
+                float g = gv[j];  // bn_gate on the values already loaded
+                if (yout != nullptr) g = relu ? (ov[j] > 0.0f ? g * scale : 0.0f) : g;
+                else {
+                    if (mask != nullptr) g = g * (ov[j] * scale);
+                    if (relu && !(xh * ga + be > 0.0f)) g = 0.0f;
+                }
                 sg += g * xh;
                 sb += g;
             }
@@ -1077,6 +1095,192 @@ __global__ __launch_bounds__(256) void tag_loss_rows_kernel(TagLossArgs a, float
     if (lane == 0) { a.row_loss[row] = loss; a.row_hit[row] = (bi == cls) ? 1.0f : 0.0f; }
 }
 
+// The same row with its C <= 64 * NV logits held in REGISTERS: lane l owns classes l, l + 64, ...  The kernel above walks the row in
+// ~10 dependent passes through memory (the mixed row goes to scratch and comes back, dz is zeroed, read and rewritten: 12 us in the
+// step for 1024 x 348); here every pass is register arithmetic in the SAME per-lane order of the same operations, so the results are
+// bit-identical, and memory is touched once per operand.
+template <int NV>
+__device__ __forceinline__ float focal_row_reg(const float (&z)[NV], int64_t C, int64_t cls, float smooth, float gamma, float alpha, int lane,
+                                               float mx, float sum, float coef, float (&dz)[NV], bool want_dz) {
+    float pt = 0.0f, ce = 0.0f;
+    const float lsum = logf(sum);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int64_t k = lane + 64 * j;
+        if (k < C) {
+            const float oh = (k == cls ? 1.0f - smooth : 0.0f) + smooth / (float)C;
+            const float logp = (z[j] - mx) - lsum;
+            pt += oh * expf(logp);
+            ce -= oh * logp;
+        }
+    }
+    pt = hv_wave_sum(pt);
+    ce = hv_wave_sum(ce);
+    const float om = 1.0f - pt;
+    const float w = alpha * powf(om, gamma);
+    if (want_dz) {
+        const float dw = -alpha * gamma * powf(om, gamma - 1.0f);
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int64_t k = lane + 64 * j;
+            if (k < C) {
+                const float oh = (k == cls ? 1.0f - smooth : 0.0f) + smooth / (float)C;
+                const float p = expf((z[j] - mx) - lsum);
+                dz[j] += coef * (dw * (p * (oh - pt)) * ce + w * (p - oh));
+            }
+        }
+    }
+    return w * ce;
+}
+
+template <int NV>
+__device__ __forceinline__ float ce_row_reg(const float (&z)[NV], int64_t C, int64_t cls, float ls, int lane, float mx, float sum, float coef,
+                                            float (&dz)[NV], bool want_dz) {
+    const float lsum = logf(sum);
+    float nll = 0.0f, all = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int64_t k = lane + 64 * j;
+        if (k < C) {
+            const float logp = (z[j] - mx) - lsum;
+            if (k == cls) nll = -logp;
+            all -= logp;
+        }
+    }
+    nll = hv_wave_sum(nll);
+    all = hv_wave_sum(all);
+    if (want_dz) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int64_t k = lane + 64 * j;
+            if (k < C) {
+                const float p = expf((z[j] - mx) - lsum);
+                const float oh = (k == cls ? 1.0f - ls : 0.0f) + ls / (float)C;
+                dz[j] += coef * (p - oh);
+            }
+        }
+    }
+    return (1.0f - ls) * nll + ls * (all / (float)C);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void tag_loss_rows_reg_kernel(TagLossArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.B) return;
+    const int64_t cls = a.target[row];
+    const int64_t C = a.C;
+    const bool want_dz = a.dmix != nullptr;
+    if (cls < 0) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int64_t k = lane + 64 * j;
+            if (k < C) {
+                if (want_dz) a.dmix[row * C + k] = 0.0f;
+                if (a.dkl != nullptr) a.dkl[row * C + k] = 0.0f;
+            }
+        }
+        if (lane == 0) { a.row_loss[row] = 0.0f; a.row_hit[row] = 0.0f; }
+        return;
+    }
+    const int64_t pr = a.partner != nullptr ? a.partner[row] : -1;
+    const bool mixed = pr >= 0;
+    const float lam = mixed ? *a.lam_dev : 1.0f;
+    const int64_t cls2 = mixed ? a.target[pr] : 0;
+    float z0[NV], zp[NV], z[NV], dz[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int64_t k = lane + 64 * j;
+        z0[j] = k < C ? a.logits[row * C + k] : 0.0f;
+        zp[j] = (mixed && k < C) ? a.logits[pr * C + k] : 0.0f;
+        dz[j] = 0.0f;
+    }
+    // accuracy on the un-mixed logits (first maximum, like torch.argmax)
+    float bm = -INFINITY;
+    int64_t bi = 0;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int64_t k = lane + 64 * j;
+        if (k < C && z0[j] > bm) { bm = z0[j]; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(bm, o);
+        const int64_t oi = __shfl_xor(bi, o);
+        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        z[j] = mixed ? lam * z0[j] + (1.0f - lam) * zp[j] : z0[j];  // loss.py:150
+        if (lane + 64 * j < C) mx = fmaxf(mx, z[j]);
+    }
+    mx = hv_wave_max(mx);
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+        if (lane + 64 * j < C) sum += expf(z[j] - mx);
+    sum = hv_wave_sum(sum);
+    float loss;
+    if (a.focal) {
+        loss = focal_row_reg<NV>(z, C, cls, a.smooth, a.gamma, a.alpha, lane, mx, sum, lam, dz, want_dz);
+        if (mixed) loss = lam * loss + (1.0f - lam) * focal_row_reg<NV>(z, C, cls2, a.smooth, a.gamma, a.alpha, lane, mx, sum, 1.0f - lam, dz, want_dz);
+    } else {
+        loss = ce_row_reg<NV>(z, C, cls, a.ce_ls, lane, mx, sum, lam, dz, want_dz);
+        if (mixed) loss = lam * loss + (1.0f - lam) * ce_row_reg<NV>(z, C, cls2, a.ce_ls, lane, mx, sum, 1.0f - lam, dz, want_dz);
+        float m0 = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+            if (lane + 64 * j < C) m0 = fmaxf(m0, z0[j]);
+        m0 = hv_wave_max(m0);
+        float s0 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+            if (lane + 64 * j < C) s0 += expf(z0[j] - m0);
+        s0 = hv_wave_sum(s0);
+        const float u = 1.0f / (float)C, logu = logf(u);
+        float kl = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+            if (lane + 64 * j < C) {
+                const float p = expf(z0[j] - m0) / s0;
+                kl += u * (logu - logf(p + 1e-8f));
+            }
+        kl = hv_wave_sum(kl);
+        loss += 0.05f * kl;
+        if (a.dkl != nullptr) {
+            float wsum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+                if (lane + 64 * j < C) { const float p = expf(z0[j] - m0) / s0; wsum += p / (p + 1e-8f); }
+            wsum = hv_wave_sum(wsum);
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                const int64_t k = lane + 64 * j;
+                if (k < C) {
+                    const float p = expf(z0[j] - m0) / s0;
+                    a.dkl[row * C + k] = 0.05f * (-u) * (p / (p + 1e-8f) - p * wsum);
+                }
+            }
+        }
+    } 
+    if (want_dz) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int64_t k = lane + 64 * j;
+            if (k < C) a.dmix[row * C + k] = dz[j];
+        }
+    }
+    if (a.focal && a.dkl != nullptr) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int64_t k = lane + 64 * j;
+            if (k < C) a.dkl[row * C + k] = 0.0f;
+        }
+    }
+    if (lane == 0) { a.row_loss[row] = loss; a.row_hit[row] = (bi == cls) ? 1.0f : 0.0f; }
+}
+
 // loss = sum(row_loss)/n_valid, acc = sum(row_hit)/n_valid (0,0 if no valid row: loss.py:123-125); single workgroup
 __global__ __launch_bounds__(256) void tag_loss_reduce_kernel(const float *row_loss, const float *row_hit, const int64_t *target,
                                                               int64_t B, float *loss, float *acc, float *n_valid_out) {
@@ -1309,7 +1513,7 @@ extern "C" int hidvae_batchnorm_bwd(const float *gy, const float *x, int64_t ldx
     HV_REQUIRE(!(keep_mask && y_out), "batchnorm_bwd: the gate comes from the keep-mask OR from the forward output, not both");
     if (workspace != nullptr) {  // row-parallel form
         hipStream_t s = (hipStream_t)stream;
-        const int64_t chunks = hv_cdiv(M, BN2_ROWS);
+        const int64_t chunks = hv_cdiv(M, BN2_BWD_ROWS);
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((unsigned)hv_cdiv(N, 64), (unsigned)chunks), dim3(256), 0, s, gy, x, ldx, gamma, beta,
                            save_mean, save_rstd, M, N, relu, keep_mask, keep_scale, workspace, y_out);
         HV_LAUNCH_CHECK("batchnorm_bwd partial");
@@ -1521,7 +1725,14 @@ extern "C" int hidvae_tag_loss_fwd(const float *logits, int64_t B, int64_t C, co
     HV_REQUIRE(partner == nullptr || lam_dev != nullptr, "tag_loss_fwd: mixup needs lam");
     TagLossArgs a{logits, B, C, target, partner, lam_dev, focal, gamma, alpha, smooth, ce_label_smoothing, row_loss, row_hit, dmix, dkl};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(tag_loss_rows_kernel, dim3((unsigned)hv_cdiv(B, 4)), dim3(256), 0, s, a, zbuf);
+    const dim3 grid((unsigned)hv_cdiv(B, 4)), block(256);
+    if (C <= 64) hipLaunchKernelGGL(tag_loss_rows_reg_kernel<1>, grid, block, 0, s, a);
+    else if (C <= 128) hipLaunchKernelGGL(tag_loss_rows_reg_kernel<2>, grid, block, 0, s, a);
+    else if (C <= 192) hipLaunchKernelGGL(tag_loss_rows_reg_kernel<3>, grid, block, 0, s, a);
+    else if (C <= 256) hipLaunchKernelGGL(tag_loss_rows_reg_kernel<4>, grid, block, 0, s, a);
+    else if (C <= 384) hipLaunchKernelGGL(tag_loss_rows_reg_kernel<6>, grid, block, 0, s, a);
+    else if (C <= 512) hipLaunchKernelGGL(tag_loss_rows_reg_kernel<8>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(tag_loss_rows_kernel, grid, block, 0, s, a, zbuf);  // wider rows: through the scratch rows
     HV_LAUNCH_CHECK("tag_loss_rows");
     hipLaunchKernelGGL(tag_loss_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, row_hit, target, B, loss, acc, n_valid);
     HV_LAUNCH_CHECK("tag_loss_reduce");
