@@ -103,6 +103,17 @@ class ResidentItemData:
                                   seq_mask=mask, tags_emb=self.tags_emb[idx], tags_indices=self.tags_indices[idx])
         return SeqBatch(user_ids=-torch.ones_like(ids), ids=ids, ids_fut=-torch.ones_like(ids), x=x, x_fut=empty, seq_mask=mask)
 
+    def gather_into(self, idx, out):
+        """rows `idx` (index tensor) written into the tensors of `out` (x, and tags_emb / tags_indices when present there): the batch
+        lands where its consumer reads it -- GraphedTrainStep.input_buffers() -- instead of in a fresh tensor that is copied once more.
+        -> out"""
+        idx = idx.to(self.x.device)
+        torch.index_select(self.x, 0, idx, out=out.x)
+        if self.has_tags and getattr(out, "tags_emb", None) is not None:
+            torch.index_select(self.tags_emb, 0, idx, out=out.tags_emb)
+            torch.index_select(self.tags_indices, 0, idx, out=out.tags_indices)
+        return out
+
     def subset(self, mask):
         return ResidentItemData(self.x[mask], self.tags_emb[mask] if self.has_tags else None,
                                 self.tags_indices[mask] if self.has_tags else None)
@@ -138,11 +149,14 @@ class RandomBatches:
         self.gen = torch.Generator(device=data.x.device).manual_seed(seed)
         self._perm, self._pos = None, 0
 
-    def next(self):
+    def next(self, out=None):
+        """the next batch; out: tensors to write it into (GraphedTrainStep.input_buffers(j)) when their shapes fit, else a fresh batch"""
         n = len(self.data)
         if self._perm is None or self._pos + self.batch_size > n:
             self._perm = torch.randperm(n, device=self.data.x.device, generator=self.gen)
             self._pos = 0
         idx = self._perm[self._pos:self._pos + min(self.batch_size, n)]
         self._pos += self.batch_size
+        if out is not None and out.x.shape[0] == idx.shape[0]:
+            return self.data.gather_into(idx, out)
         return self.data[idx]

@@ -232,7 +232,8 @@ def train(iterations=50000, batch_size=64, learning_rate=0.0001, weight_decay=0.
             if dp is not None:  # rank 0's codebooks win (the reference lets them diverge)
                 dp.broadcast_codebooks([layer.embedding.weight for layer in model.layers], 0)
             log.info("K-means initialization complete")
-        micro = [sampler.next() for _ in range(ga)]
+        # (once the step object exists the batches are gathered straight into its input buffers: no per-step copy)
+        micro = [sampler.next(out=stepper.input_buffers(j) if stepper is not None else None) for j in range(ga)]
         if stepper is None:  # built on the first regular step: its static buffers take the batch shapes
             stepper = GraphedTrainStep(model, opt, micro, dp=dp, gumbel_t=t, enabled=use_hip_graph)
         row = stepper(micro)  # device [6]: total loss, mean recon, mean rqvae, tag align, tag pred, tag accuracy

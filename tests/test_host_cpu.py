@@ -245,3 +245,20 @@ def test_optimizer_tensor_ranges_for_an_early_update():
     assert opt.tensor_ranges_of([ps[3], frozen]) == [(3, 4)]           # a frozen parameter is not an optimized tensor: ignored
     assert opt.tensor_ranges_of([torch.nn.Parameter(torch.zeros(1))]) is None   # a stranger: no early update for that set
     assert opt.step_early([(0, 2)]) is False                            # nothing prepared (and CPU tensors): it must decline, not raise
+
+
+def test_random_batches_gathered_into_given_buffers_equal_fresh_batches():
+    """RandomBatches.next(out=...) (the training loop hands it GraphedTrainStep.input_buffers()): the same rows as next(), written in place"""
+    import types
+    from hidvae_amd.data.items import RandomBatches, ResidentItemData
+    g = torch.Generator().manual_seed(3)
+    data = ResidentItemData(torch.randn(50, 8, generator=g), torch.randn(50, 3, 8, generator=g), torch.randint(0, 9, (50, 3), generator=g))
+    a, b = RandomBatches(data, 16, seed=5), RandomBatches(data, 16, seed=5)
+    out = types.SimpleNamespace(x=torch.empty(16, 8), tags_emb=torch.empty(16, 3, 8), tags_indices=torch.empty(16, 3, dtype=torch.long))
+    px = out.x.data_ptr()
+    for _ in range(7):  # crosses a re-permutation (50 items, 16 per batch)
+        fresh, given = a.next(), b.next(out=out)
+        assert given is out and out.x.data_ptr() == px
+        assert torch.equal(fresh.x, out.x) and torch.equal(fresh.tags_emb, out.tags_emb) and torch.equal(fresh.tags_indices, out.tags_indices)
+    short = types.SimpleNamespace(x=torch.empty(8, 8))  # buffers of another batch size are left alone
+    assert b.next(out=short) is not short
