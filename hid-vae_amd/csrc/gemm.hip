@@ -1817,8 +1817,10 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
     constexpr int mid_minq = 6;  // shortest range worth a workgroup (steps)
     if (balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, dX != nullptr) &&
         fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && (dX == nullptr || fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw))) {
-        // from B = 2048 on: the LDS-DMA ring kernel (gemm_ring.hip) -- measured in the step, see its header; below, the kernels here
-        if (B >= 2048) {
+        // the LDS-DMA ring kernel (gemm_ring.hip) wherever it takes the problem; the kernels below are what runs when it declines.
+        // (First shipped from B = 2048 on, where it won stand-alone; in the step it also wins at B = 1024: tagged 1.156 -> 1.088 ms
+        // together with the lower threshold of rules.h -- profiles/r04_ring_threshold_ab.log.)
+        {
             const int rc = hv_ring_linear_bwd(g, ldg, x, ldx, W, ldw, B, n_out, n_in, dW, lddw, accumulate_dw, dX, lddx, dx_epilogue, aux, ldaux,
                                               dx_scale, db, accumulate_db, workspace, 512, (hipStream_t)stream);
             if (rc != 1) return rc;
