@@ -156,7 +156,7 @@ def time_kernel(fn, launches=20, reps=20, side=None):
 
 def kernel_rooflines(args, m, device):
     """Live per-kernel timings on the bench shapes.
-    * gemm_tile16_kernel / gemm_direct_kernel / gemm_mid_sk_kernel (fp32 MFMA roofline, 157.3 TFLOP/s): the largest GEMMs of the step;
+    * gemm_tile16_kernel / gemm_direct_kernel / gemm_ring_bwd_kernel (fp32 MFMA roofline, 157.3 TFLOP/s): the largest GEMMs of the step;
     * rq_forward_kernel (HBM roofline, 8 TB/s): ALGORITHMIC bytes per item exactly as SURVEY.md 8(d) counts them for the tagged
       variant: read z 128 B, write ids 8L, per-level emb_out 128L, loss 4 = 540 B at L=3 (+ the codebooks 4*L*K*32 once per
       launch).  The launch also writes emb_sum and z (128 B each, consumed by the decoder and the backward): `bytes_moved`
@@ -185,23 +185,23 @@ def kernel_rooflines(args, m, device):
     pre = torch.randn(B, 512, device=device)
     t = time_kernel(lambda: _C.linear_bwd(gd, xd, wd, True, _C.EPI_DSILU, pre))
     fl2 = 4.0 * B * 768 * 512
-    dec = dict(kernel="gemm_mid_sk_kernel decoder layer 3 backward: dW [768,512] = g^T x and dX = (g W) * silu'(pre) in one launch (LDS-shared 64x64 tiles, one per workgroup)",
+    dec = dict(kernel="gemm_ring_bwd_kernel decoder layer 3 backward: dW [768,512] = g^T x and dX = (g W) * silu'(pre) in one launch (LDS-DMA ring, 64x64 tiles, evenly dealt k-steps)",
                bound="mfma", achieved=fl2 / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl2 / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
                us=t, flops=fl2)
     # the tag heads' widest Linear backward (level 2's residual blocks, 691 <-> 768): dW + dX (through the ReLU -> Dropout gate of the layer
     # below, read off its output) + db in one launch
     gt, xt, wt, yt = torch.randn(B, 691, device=device), torch.randn(B, 768, device=device), torch.randn(691, 768, device=device) * 0.03, torch.rand(B, 768, device=device)
     lane = torch.cuda.Stream(device=device)
-    _C.register_ws_lane(lane)  # (as the level streams are: the launch takes its co-resident form, eight-wave workgroups two per CU)
+    _C.register_ws_lane(lane)  # (as the level streams are: a lane with a workspace of its own)
     t = time_kernel(lambda: _C.linear_bwd(gt, xt, wt, True, _C.EPI_DRELU, yt, bias=True, dx_scale=1.6), side=lane)
     fl3 = 4.0 * B * 691 * 768
-    head = dict(kernel="gemm_mid_sk_kernel<2,2> tag-head layer backward 691 x 768 (co-resident form): dW = g^T x, dX = (g W) gated by the layer below, db "
-                       "(LDS-shared 64x64 tiles, eight-wave workgroups as on the level streams)",
+    head = dict(kernel="gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 1024: dW = g^T x, dX = (g W) gated by the layer below, db "
+                       "(LDS-DMA ring, four-wave workgroups two per CU, evenly dealt k-steps)",
                 bound="mfma", achieved=fl3 / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl3 / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
                 us=t, flops=fl3)
     (head if args.tagged else dec)["entry"] = "hidvae_linear_bwd"  # the stand-alone figure quoted beside the in-step family of the headline
     out += [dec, head]
-    # the same layer at config 3's batch: from B = 2048 on hidvae_linear_bwd runs on the LDS-DMA ring kernel (csrc/gemm_ring.hip)
+    # the same layer at config 3's batch
     B2 = 2048
     gt2, xt2, yt2 = torch.randn(B2, 691, device=device), torch.randn(B2, 768, device=device), torch.rand(B2, 768, device=device)
     t = time_kernel(lambda: _C.linear_bwd(gt2, xt2, wt, True, _C.EPI_DRELU, yt2, bias=True, dx_scale=1.6), side=lane)
@@ -308,7 +308,7 @@ def summarize_timeline(rows):
 
 def describe_launch(r):
     what = {"hidvae_gemm_f32": "forward Linear layers: gemm_tile16 / gemm_directL16 / gemm_direct16 kernels, fp32 MFMA, one exact ORDER-G chain per output",
-            "hidvae_linear_bwd": "one-launch Linear backward dW = g^T x + dX = g W (+ db): gemm_mid_sk (widest layer) / gemm_pair16 / gemm_pair32 kernels, fp32 MFMA",
+            "hidvae_linear_bwd": "one-launch Linear backward dW = g^T x + dX = g W (+ db): gemm_ring_bwd_kernel (LDS-DMA ring, layers from 0.2 GFLOP) / gemm_pair16 (narrow layers), fp32 MFMA",
             "hidvae_bottleneck_fwd": "fused middle launch: encoder[-2:] + L-level RQ + decoder[:2], fp32 MFMA"}.get(r["entry"], "")
     shapes = "; ".join(f"{m}x{n}x{k}" for m, n, k in r.get("shapes", [])[:8])
     return f"{r['entry']} x{r['launches']} launches per step ({what}{'; MxNxK: ' + shapes if shapes else ''})"

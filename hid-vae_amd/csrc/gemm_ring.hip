@@ -1,5 +1,5 @@
-// Linear backward (dW = g^T x, dX = epi(g W), db = colsum(g)) on an LDS-DMA ring: the mid-size layers of the tag heads and of the
-// encoder / decoder (reference modules/h_rqvae.py:132-188,322-331; modules/encoder.py:23-36) at B >= 2048.
+// Linear backward (dW = g^T x, dX = epi(g W), db = colsum(g)) on an LDS-DMA ring: every layer of the tag heads and of the encoder /
+// decoder (reference modules/h_rqvae.py:132-188,322-331; modules/encoder.py:23-36) from 0.2 GFLOP on (rules.h), at every batch size.
 //
 // What differs from gemm_mid_sk_kernel (gemm.hip), which stages every operand global -> VGPR -> ds_write, runs sixteen (eight) waves per
 // 64x64 tile in four (two) k-groups whose partial tiles meet in LDS at every segment end, and restarts its pipeline at every segment:
@@ -15,14 +15,16 @@
 //   * the loader state (buffer descriptors, per-lane offsets, the cursor) lives in registers and is rebuilt only at a tile change:
 //     indexing the argument struct by a run-time product index turns every field into a scalar load from the argument segment, eight
 //     dependent ones per step (the first build: 1.7 us per step of nothing but that).
-// Measured (scratch/r4): alone, 10-25 % faster than gemm_mid_sk_kernel from B = 1024 up (2048 x 768 x 691: 55.6 vs
-// 64.0 us = 0.50 of the fp32 MFMA peak; 4096 x 768 x 512: 71.8 vs 80.6 = 0.57; 8192 x 512 x 256: 51.9 vs 60.8); inside the step it pays
-// from B = 2048 (tagged step 2.008 -> 1.881 ms, the B = 8192 shard 0.870 -> 0.830 ms) and ties at B = 1024, where the round-3 kernel
-// stays.  Variants that were built, tested and NOT kept (sources: scratch/r4/gemm_ring_v3c.hip.txt): a chunk-major step list (L2 hits
-// 39 % -> 81 %, fabric traffic 114 -> 27 MB per launch) with pieces parked in slabs and a second, combining launch -- slower in the
-// step for the second launch's gap; two dedicated loader waves beside four MFMA waves -- no change: what does not overlap is not the
-// DMA instructions' issue (ablation: MFMAs + LDS reads alone 17.4 us above the launch's fixed 8 us = the matrix pipe's floor at the
-// ~2.0 GHz the chip holds; DMAs alone 9.7 us; together 23.6).
+// Measured (scratch/r4): alone, 10-25 % faster than gemm_mid_sk_kernel on most shapes from B = 1024 up (1024 x 691 x 768:
+// 31.6 vs 37.5 us; 2048 x 768 x 691: 55.6 vs 64.0 us = 0.50 of the fp32 MFMA peak; 4096 x 768 x 512: 71.8 vs 80.6 = 0.57; 8192 x 512 x 256:
+// 51.9 vs 60.8; slower on 1024 x 768 x 512: 27.4 vs 22.9).  Inside the step it first replaced gemm_mid_sk_kernel from B = 2048 (tagged step
+// 2.008 -> 1.881 ms, the B = 8192 shard 0.870 -> 0.830 ms) and tied at B = 1024; what moved the B = 1024 step was giving it the layers
+// of 0.2-0.9 GFLOP that the per-wave pair kernels had (those run 1.5-2x slower in the three-lane step than alone): 1.156 -> 1.088 ms
+// (profiles/r04_ring_threshold_ab.log).  Variants that were built, tested and NOT kept (sources: scratch/r4/gemm_ring_v3c.hip.txt): a
+// chunk-major step list (L2 hits 39 % -> 81 %, fabric traffic 114 -> 27 MB per launch) with pieces parked in slabs and a second,
+// combining launch -- slower in the step for the second launch's gap; two dedicated loader waves beside four MFMA waves -- no change:
+// what does not overlap is not the DMA instructions' issue (ablation: MFMAs + LDS reads alone 17.4 us above the launch's fixed 8 us =
+// the matrix pipe's floor at the ~2.0 GHz the chip holds; DMAs alone 9.7 us; together 23.6).
 // LDS images (a stage = 16 KB = operand A, then operand B):
 //   k-major operand (g and x of dW; W of dX), element (k, c) at P[k * ld + c]:   [32 k][64 c] floats, filled by 8 pieces of 4 k-rows;
 //       the MFMA fragment of k-pair j is the dword at row 2j + h: 32 consecutive dwords per half-wave, conflict-free ds_read_b32;

@@ -17,10 +17,10 @@ QUOTED = [
     ("rq_forward_kernel (fused L-level VQ, code-split variant)", "rq_forward_kernel<3, true, true, true", None),
     ("rq_forward at 1,048,576 items", "rq_forward_pf32_kernel<3, true", None),
     ("gemm_f32_kernel<2,2,NT> encoder layer 0 at 65,536 rows", "gemm_f32_kernel<2, 2, 0>", None),
-    ("gemm_mid_sk_kernel decoder layer 3 backward", "gemm_mid_sk_kernel<4, 2>", 229376),   # 96 + 128 tiles (no bias here), 1024 threads each
-    ("gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 2048", "gemm_ring_bwd_kernel", None),
-    ("gemm_mid_sk_kernel tag-head layer backward 691 x 768", "gemm_mid_sk_kernel<4, 2>", 258048),  # equal ranges over 252 sixteen-wave workgroups
-    ("gemm_mid_sk_kernel<2,2> tag-head layer backward 691 x 768 (co-resident form)", "gemm_mid_sk_kernel<2, 2>", None),  # whole tiles, eight-wave workgroups
+    # three launches of the ring kernel, told apart by their grids (workgroups x 256 threads; gemm_ring.hip: G = min(512, S / 8) ranges)
+    ("gemm_ring_bwd_kernel decoder layer 3 backward", "gemm_ring_bwd_kernel", 131072),                        # 1024 x 768 x 512, no bias
+    ("gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 1024", "gemm_ring_bwd_kernel", 129280),   # 505 ranges of 17 steps
+    ("gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 2048", "gemm_ring_bwd_kernel", 128768),   # 503 ranges of 34 steps
     ("rq_forward_kernel streamed code-split (4x1024, B=4096)", "rq_forward_kernel<3, true, false, true, 4, true>", None),
     ("rq_forward ids-only at 1,048,576 items", "rq_forward_pf32_kernel<2, false, 16, 8, true, true>", None),
 ]

@@ -33,7 +33,7 @@ for _ in range(10):
     _C.gemm(_C.GEMM_TN, g, x, out=gw, split_k=0)
     _C.linear_bwd(g1, o0, w1, True, _C.EPI_DSILU, pre)  # the paired dW + dX launch of encoder layer 1
     _C.rq_forward(y_small, cb, cc, True, 3, True, 0.4)
-# round 2: the launch family that leads the step (hidvae_linear_bwd, gemm_mid_sk on the decoder's last layer), the streamed
+# round 2: the launch family that leads the step (hidvae_linear_bwd on the decoder's last layer), the streamed
 # code-split RQ kernel of config 5 (4 x 1024 codes, B = 4096)
 wd3 = torch.randn(768, 512, device=dev) * 0.03
 gd, xd, pd = torch.randn(B, 768, device=dev), torch.randn(B, 512, device=dev), torch.randn(B, 512, device=dev)
@@ -61,15 +61,7 @@ for _ in range(10):
     _C.layernorm_bwd_partial(xt, xt, gam, bet, ml, rl, True, yl, 1.0, 0.0)
     hh, sv = _C.gate_fwd(xc, *gW, True)
     _C.gate_bwd(hh, xc, gW[0], gW[2], gW[4], True, sv)
-# the same widest backward launch in the form it takes on the tag heads' level streams (co_resident: eight-wave workgroups, two per CU)
-side = torch.cuda.Stream()
-_C.register_ws_lane(side)
-side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    for _ in range(10):
-        _C.linear_bwd(gt, xt, wt, True, _C.EPI_DRELU, yt, bias=True, dx_scale=1.6)
-torch.cuda.current_stream().wait_stream(side)
-# round 4: from B = 2048 on the Linear backward runs on the LDS-DMA ring kernel (gemm_ring.hip): the heads' widest layer at config 3's batch
+# round 4: every Linear backward from 0.2 GFLOP on runs on the LDS-DMA ring kernel (gemm_ring.hip); the heads' widest layer at config 3's batch
 B2 = 2048
 gt2, xt2, yt2 = torch.randn(B2, 691, device=dev), torch.randn(B2, 768, device=dev), torch.rand(B2, 768, device=dev)
 for _ in range(10):
