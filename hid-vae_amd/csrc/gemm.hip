@@ -1651,7 +1651,9 @@ inline bool group_gemm_sub(GroupSub &s, int layout, const GemmArgs &g) {
     const bool f16 = use_direct16(g.M, g.N, g.K);
     s.kind = f16 ? 0 : 1;
     int sp = f16 ? pick_split16(g.M, g.N, g.K, 0) : pick_split32(g.M, g.N, g.K, 0);
-    constexpr int cap = 4;  // in-workgroup K split of a grouped sub-problem (measured: 1 -> 63 us, 2 -> 58 us, 4 -> 52 us for the three levels' widest layer)
+    // in-workgroup K split of a grouped sub-problem (measured: 1 -> 63 us, 2 -> 58 us, 4 -> 52 us for the three levels' widest layer);
+    // a handful of tiles with a long K (the attention gate's weight gradients: 2-8 tiles, K = batch) takes all eight waves
+    const int cap = hv_cdiv(g.M, 16) * hv_cdiv(g.N, 16) <= 16 ? GROUP_WAVES : 4;
     if (sp > GROUP_WAVES) sp = GROUP_WAVES;
     while (sp > cap && sp > 1) sp /= 2;
     s.split = sp;
