@@ -27,6 +27,7 @@ _SIGNATURES = {
     "hidvae_linear_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _f, _vp, _i, _vp, _i, _vp],
     "hidvae_layernorm_bwd_partial": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_layernorm_param_final_many": [_vp, _i, _vp],
+    "hidvae_predictor_fwd": [_vp, _i64, _i64, _vp, _i, _vp, _vp],
     "hidvae_gate_fwd": [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_gate_bwd": [_vp, _i64, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
@@ -938,6 +939,55 @@ def layernorm_param_final_many(problems):
     for q, (part, M, N, gg, gb, acc) in zip(arr, problems):
         q.partials, q.M, q.N, q.ggamma, q.gbeta, q.accumulate = part.data_ptr(), int(M), int(N), gg.data_ptr(), gb.data_ptr(), int(bool(acc))
     _check(lib().hidvae_layernorm_param_final_many(ctypes.cast(arr, _vp), len(problems), _stream()), "hidvae_layernorm_param_final_many")
+
+
+class PredUnit(ctypes.Structure):  # hidvae_pred_unit
+    _fields_ = [("W", _vp), ("bias", _vp), ("gamma", _vp), ("beta", _vp), ("N", _i), ("K", _i),
+                ("act1", _i), ("act2", _i), ("residual", _i), ("carry", _i),
+                ("drop_site1", ctypes.c_uint), ("drop_threshold1", ctypes.c_uint), ("drop_site2", ctypes.c_uint), ("drop_threshold2", ctypes.c_uint),
+                ("drop_scale1", ctypes.c_float), ("drop_scale2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("lin", _vp), ("y", _vp), ("mean", _vp), ("rstd", _vp)]
+
+
+PRED_WMAX, PRED_MAX_UNITS = 256, 10
+
+
+def predictor_fwd(h, units):
+    """TagPredictor behind its gate in one row-local launch.  units: list of dicts with lin (nn.Linear), norm (nn.LayerNorm or None),
+    act1 / act2 (bool), drop1 / drop2 ((DropSpec, scale) or None), residual, carry.  -> per unit dict(lin=..., y=..., mean=..., rstd=...)
+    with y / mean / rstd None for units without a LayerNorm."""
+    _f32(h, "h")
+    B = h.shape[0]
+    dev = h.device
+    arr = (PredUnit * len(units))()
+    outs, state = [], None
+    for q, u in zip(arr, units):
+        lin, norm = u["lin"], u.get("norm")
+        N, K = lin.out_features, lin.in_features
+        o = dict(lin=torch.empty((B, N), device=dev, dtype=torch.float32), y=None, mean=None, rstd=None)
+        q.W, q.bias = lin.weight.data_ptr(), (lin.bias.data_ptr() if lin.bias is not None else None)
+        q.N, q.K = N, K
+        q.act1, q.act2, q.residual, q.carry = int(bool(u.get("act1"))), int(bool(u.get("act2"))), int(bool(u.get("residual"))), int(bool(u.get("carry")))
+        q.eps = 1e-5
+        if norm is not None:
+            o["y"] = torch.empty((B, N), device=dev, dtype=torch.float32)
+            o["mean"], o["rstd"] = torch.empty((B,), device=dev, dtype=torch.float32), torch.empty((B,), device=dev, dtype=torch.float32)
+            q.gamma, q.beta, q.eps = norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps)
+            q.y, q.mean, q.rstd = o["y"].data_ptr(), o["mean"].data_ptr(), o["rstd"].data_ptr()
+        q.lin = o["lin"].data_ptr()
+        for k, (fs, ft, fc) in (("drop1", ("drop_site1", "drop_threshold1", "drop_scale1")), ("drop2", ("drop_site2", "drop_threshold2", "drop_scale2"))):
+            d = u.get(k)
+            if d is not None and d[0] is not None:
+                spec, scale = d
+                if not isinstance(spec, DropSpec):
+                    raise RuntimeError("predictor_fwd: dropout is decided inside the launch (a DropSpec), not from a keep-mask tensor")
+                setattr(q, fs, spec.site), setattr(q, ft, spec.threshold), setattr(q, fc, float(scale))
+                state = spec.state
+            else:
+                setattr(q, fc, 1.0)
+        outs.append(o)
+    _check(lib().hidvae_predictor_fwd(_p(h), _row_stride(h, "h"), B, ctypes.cast(arr, _vp), len(units), _p(state), _stream()), "hidvae_predictor_fwd")
+    return outs
 
 
 def gate_fwd(x, W0, b0, W2, b2, W4, b4, normalize, eps=1e-12):

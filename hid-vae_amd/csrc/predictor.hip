@@ -1,0 +1,247 @@
+// TagPredictor forward behind its attention gate (reference modules/h_rqvae.py:132-188: feature_extractor, two residual blocks,
+// classifier) as ONE row-local launch for levels whose layers are at most PRED_WMAX wide.
+//
+// Why: at B = 1024 a narrow level's predictor is 14 launches of 0.03-0.24 GFLOP each (Linear, LayerNorm, Linear, ...), every one at
+// the latency floor, on the lane of the step that is the longest -- and nothing in it crosses rows: Linear, LayerNorm,
+// ReLU, Dropout and the residual adds are all per item.  A workgroup takes 16 items through all units: activations stay in LDS as MFMA
+// B-fragment images ([k / 16][64 lanes] float4, lane = (item, k-quad): bottleneck_fwd_kernel's layout, rq.hip), weights stream from
+// L2 as A fragments, eight waves share a unit's output tiles.  Every tensor the separate launches save for the backward (a Linear's
+// output, a LayerNorm's input / mean / rstd / output) is written exactly as they would write it, so the backward is unchanged
+// (tagpath.py hands these tensors to the same autograd Functions instead of letting them launch).
+//
+// Arithmetic: Linear = fp32 MFMA 16x16x4 over ascending k + bias; LayerNorm = two-pass (mean, then sum of squared deviations) with
+// the row's partial sums added lane-quad -> wave -> workgroup in a fixed order; dropout = the counter-based generator of common.h on
+// element index row * N + col of the unit's site (the same decision the separate launches take).  Not bit-identical to the separate
+// LayerNorm kernels (another summation order): compared with them to 1e-5 in tests/test_modules_gpu.py.
+#include "common.h"
+
+namespace {
+
+constexpr int PRED_WMAX = 256;   // widest layer (features per item kept in LDS)
+constexpr int PRED_WAVES = 8;
+constexpr int PRED_MAX_UNITS = 10;
+constexpr int PRED_IMG = (PRED_WMAX / 16) * 64;  // float4 per activation image
+
+struct PredUnit {
+    const float *W, *bias;        // [N, K] row-major, [N]
+    const float *gamma, *beta;    // LayerNorm affine or nullptr (no LayerNorm in this unit)
+    int N, K;
+    int act1;                     // ReLU -> Dropout(site1) right after the Linear (before a LayerNorm, or as the unit's end)
+    int act2;                     // ReLU -> Dropout(site2) after the LayerNorm
+    int residual;                 // + the carried residual after the LayerNorm; the result becomes the new carried residual
+    int carry;                    // this unit's output becomes the carried residual (feature_extractor)
+    unsigned site1, thr1, site2, thr2;
+    float scale1, scale2, eps;
+    float *lin;                   // [B, N] Linear output (+ bias), after act1 if act1: what LinearFn / LayerNormFn save as their x
+    float *y;                     // [B, N] output of the unit (== lin when there is no LayerNorm: then nullptr)
+    float *mean, *rstd;           // [B]
+};
+
+struct PredArgs {
+    const float *h;               // [B, K0] input (the gate's output), row stride ldh
+    int64_t B, ldh;
+    int n;
+    const unsigned long long *rng;  // generator state or nullptr (no dropout anywhere)
+    PredUnit u[PRED_MAX_UNITS];
+};
+
+__device__ __forceinline__ float4 ld4_guard(const float *row, int k, int K, bool row_ok) {
+    // four consecutive k of a weight row; elements past K (or a row past N) read as zero.  Rows are only dword-aligned (K = 230, 115)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!row_ok) return v;
+    if (k + 3 < K) {
+        v.x = row[k]; v.y = row[k + 1]; v.z = row[k + 2]; v.w = row[k + 3];
+    } else {
+        if (k < K) v.x = row[k];
+        if (k + 1 < K) v.y = row[k + 1];
+        if (k + 2 < K) v.z = row[k + 2];
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs a) {
+    __shared__ float4 img[3][PRED_IMG];                 // activation images: input / output of the running unit, the carried residual
+    __shared__ float red[2][PRED_WAVES][16];            // per-wave row partials (sum, then squared deviations)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int it = lane & 15, q = lane >> 4;
+    const int64_t item = (int64_t)blockIdx.x * 16 + it;
+    const bool in_range = item < a.B;
+    const int64_t src = in_range ? item : a.B - 1;
+    // the input rows as k-block images
+    {
+        const int K0 = a.u[0].K, nkb = (K0 + 15) / 16;
+        for (int idx = threadIdx.x; idx < nkb * 64; idx += 64 * PRED_WAVES) {
+            const int kb = idx >> 6, l = idx & 63;
+            const int64_t row = (int64_t)blockIdx.x * 16 + (l & 15);
+            const float *p = a.h + (row < a.B ? row : a.B - 1) * a.ldh;
+            img[0][idx] = ld4_guard(p, 16 * kb + 4 * (l >> 4), K0, true);
+        }
+    }
+    __syncthreads();
+    int cur = 0, res = 2;  // img[cur]: the unit's input; img[cur ^ 1]: its output; img[res]: the carried residual
+    for (int ui = 0; ui < a.n; ui++) {
+        const PredUnit &u = a.u[ui];
+        const int N = u.N, K = u.K, ntile = (N + 15) / 16, nkb = (K + 15) / 16;
+        const float4 *Hin = img[cur];
+        float4 *Hout = img[cur ^ 1];
+        // ---- Linear: output tiles dealt to the waves round-robin (at most 2 per wave at N <= 256).  A wave's weight rows for BOTH its
+        // tiles are fetched up front (<= 32 sixteen-byte buffer loads in flight: one round trip to L2 per unit instead of one per
+        // k-block -- the first version of this kernel, 134 us); rows are only dword-aligned (K = 230, 115), the tail of a row's last
+        // load reads into the next row (or, past the end of W, zeros): those k meet activation entries that are exactly zero
+        float4 val[2];
+        float psum = 0.0f;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(u.W), 0, (int)(4 * (int64_t)N * K), 0x00020000);
+        f32x4 wv[2][PRED_WMAX / 16];
+        const int t0 = wave, t1 = wave + PRED_WAVES;
+        const bool has0 = t0 < ntile, has1 = t1 < ntile;
+        {
+            const int r0 = 16 * t0 + it, r1 = 16 * t1 + it;
+            const int o0 = 4 * ((r0 < N ? r0 : 0) * K + 4 * q), o1 = 4 * ((r1 < N ? r1 : 0) * K + 4 * q);
+#pragma unroll
+            for (int kb = 0; kb < PRED_WMAX / 16; kb++) {
+                if (kb < nkb && has0) wv[0][kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, o0 + 64 * kb, 0, 0));
+                if (kb < nkb && has1) wv[1][kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, o1 + 64 * kb, 0, 0));
+            }
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < PRED_WMAX / 16; kb++) {
+            if (kb < nkb) {
+                const float4 b = Hin[kb * 64 + lane];
+                if (has0) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][kb][0], b.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][kb][1], b.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][kb][2], b.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][kb][3], b.w, acc0, 0, 0, 0);
+                }
+                if (has1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][kb][0], b.x, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][kb][1], b.y, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][kb][2], b.z, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][kb][3], b.w, acc1, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int t = wave + PRED_WAVES * s;
+            val[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= ntile) continue;
+            const f32x4 acc = s ? acc1 : acc0;
+            // lane (it, q) holds features 16 t + 4 q + e of item `it`
+            float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int col = 16 * t + 4 * q + e;
+                float x = col < N ? v[e] + (u.bias != nullptr ? u.bias[col] : 0.0f) : 0.0f;
+                if (u.act1 && col < N) {
+                    x = fmaxf(x, 0.0f);
+                    if (u.thr1 != 0u) {
+                        const HvDrop d{a.rng, u.site1, u.thr1};
+                        x = hv_drop_keep(d, (unsigned long long)(item * N + col)) ? x * u.scale1 : 0.0f;
+                    }
+                }
+                v[e] = x;
+                if (in_range && col < N) u.lin[item * N + col] = x;
+                psum += x;
+            }
+            val[s] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (u.gamma != nullptr) {
+            // ---- LayerNorm over the item's N features: quad lanes -> wave -> workgroup, fixed order
+            psum += __shfl_xor(psum, 16);
+            psum += __shfl_xor(psum, 32);
+            if (q == 0) red[0][wave][it] = psum;
+            __syncthreads();
+            float tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < PRED_WAVES; w++) tot += red[0][w][it];
+            const float mu = tot / (float)N;
+            float pdev = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int t = wave + PRED_WAVES * s;
+                if (t >= ntile) continue;
+                const float v[4] = {val[s].x, val[s].y, val[s].z, val[s].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (16 * t + 4 * q + e < N) { const float d = v[e] - mu; pdev += d * d; }
+            }
+            pdev += __shfl_xor(pdev, 16);
+            pdev += __shfl_xor(pdev, 32);
+            if (q == 0) red[1][wave][it] = pdev;
+            __syncthreads();
+            float dev = 0.0f;
+#pragma unroll
+            for (int w = 0; w < PRED_WAVES; w++) dev += red[1][w][it];
+            const float rs = 1.0f / sqrtf(dev / (float)N + u.eps);
+            if (in_range && wave == 0 && q == 0) { u.mean[item] = mu; u.rstd[item] = rs; }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int t = wave + PRED_WAVES * s;
+                if (t >= ntile) continue;
+                float v[4] = {val[s].x, val[s].y, val[s].z, val[s].w};
+                const float4 r4 = u.residual ? img[res][t * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int col = 16 * t + 4 * q + e;
+                    float o = 0.0f;
+                    if (col < N) {
+                        o = (v[e] - mu) * rs * u.gamma[col] + u.beta[col];
+                        if (u.act2) {
+                            o = fmaxf(o, 0.0f);
+                            if (u.thr2 != 0u) {
+                                const HvDrop d{a.rng, u.site2, u.thr2};
+                                o = hv_drop_keep(d, (unsigned long long)(item * N + col)) ? o * u.scale2 : 0.0f;
+                            }
+                        }
+                        if (u.residual) o = o + rr[e];
+                        if (in_range) u.y[item * N + col] = o;
+                    }
+                    v[e] = o;
+                }
+                val[s] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int t = wave + PRED_WAVES * s;
+            if (t >= ntile) continue;
+            Hout[t * 64 + lane] = val[s];
+            if (u.residual || u.carry) img[res][t * 64 + lane] = val[s];
+        }
+        // (tiles past ntile of the NEXT unit's k range must read as zero: a narrower output leaves stale blocks behind)
+        const int nkb_next = ui + 1 < a.n ? (a.u[ui + 1].K + 15) / 16 : 0;
+        for (int t = ntile + wave; t < nkb_next; t += PRED_WAVES) Hout[t * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+}  // namespace
+
+extern "C" int hidvae_predictor_fwd(const float *h, int64_t ldh, int64_t B, const hidvae_pred_unit *units, int n_units,
+                                    const unsigned long long *rng_state, void *stream) {
+    HV_REQUIRE(h && units && B >= 1 && n_units >= 1 && n_units <= PRED_MAX_UNITS, "predictor_fwd: bad arguments");
+    PredArgs a{};
+    a.h = h; a.B = B; a.ldh = ldh; a.n = n_units; a.rng = rng_state;
+    for (int i = 0; i < n_units; i++) {
+        const hidvae_pred_unit &s = units[i];
+        HV_REQUIRE(s.W && s.lin && s.N >= 1 && s.N <= PRED_WMAX && s.K >= 1 && s.K <= PRED_WMAX, "predictor_fwd: unit %d: widths %d x %d (at most %d)",
+                   i, s.N, s.K, PRED_WMAX);
+        HV_REQUIRE(i == 0 ? ldh >= s.K : s.K == units[i - 1].N, "predictor_fwd: unit %d does not continue unit %d", i, i - 1);
+        HV_REQUIRE(s.gamma == nullptr || (s.beta && s.y && s.mean && s.rstd), "predictor_fwd: unit %d: LayerNorm outputs missing", i);
+        HV_REQUIRE(s.gamma != nullptr || (!s.act2 && !s.residual), "predictor_fwd: unit %d: act2 / residual need the LayerNorm", i);
+        HV_REQUIRE((s.drop_threshold1 == 0u && s.drop_threshold2 == 0u) || rng_state != nullptr, "predictor_fwd: unit %d: dropout needs the generator state", i);
+        PredUnit &u = a.u[i];
+        u.W = s.W; u.bias = s.bias; u.gamma = s.gamma; u.beta = s.beta; u.N = s.N; u.K = s.K;
+        u.act1 = s.act1; u.act2 = s.act2; u.residual = s.residual; u.carry = s.carry;
+        u.site1 = s.drop_site1; u.thr1 = s.drop_threshold1; u.scale1 = s.drop_scale1;
+        u.site2 = s.drop_site2; u.thr2 = s.drop_threshold2; u.scale2 = s.drop_scale2;
+        u.eps = s.eps; u.lin = s.lin; u.y = s.y; u.mean = s.mean; u.rstd = s.rstd;
+    }
+    hipLaunchKernelGGL(predictor_fwd_kernel, dim3((unsigned)hv_cdiv(B, 16)), dim3(64 * PRED_WAVES), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("predictor_fwd");
+    return HIDVAE_OK;
+}

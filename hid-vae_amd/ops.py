@@ -497,13 +497,20 @@ class LinearFn(Function):
                     gradient leaves this launch already through that gate, (g W) * (x > 0 ? s : 0)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, keep_mask=None, keep_scale=1.0, act_bwd_done=False, dx_gate=None):
+    def forward(ctx, x, w, b, act, keep_mask=None, keep_scale=1.0, act_bwd_done=False, dx_gate=None, computed=None):
+        """computed: this layer's output, already produced by a fused launch (tagpath: hidvae_predictor_fwd) -- nothing is launched here,
+        the node only takes its place on the tape"""
         ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad)
         pre = None
-        if need and act in (_C.EPI_SILU, _C.EPI_GELU):
-            pre = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32)
-        y = _C.gemm(_C.GEMM_NT, x, w, bias=b, epilogue=act, aux=pre, mask=keep_mask, mask_scale=keep_scale, split_k=0)
+        if computed is not None:
+            if act in (_C.EPI_SILU, _C.EPI_GELU) or tuple(computed.shape) != (x.shape[0], w.shape[0]):
+                raise RuntimeError("LinearFn: a precomputed output needs a ReLU / identity layer of the same shape")
+            y = computed
+        else:
+            if need and act in (_C.EPI_SILU, _C.EPI_GELU):
+                pre = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32)
+            y = _C.gemm(_C.GEMM_NT, x, w, bias=b, epilogue=act, aux=pre, mask=keep_mask, mask_scale=keep_scale, split_k=0)
         ctx.act, ctx.keep_scale = act, keep_scale
         ctx.has_bias = b is not None
         ctx.w_param, ctx.b_param = w, b  # (the objects themselves: a flat-gradient slot hangs off the Parameter)
@@ -522,7 +529,7 @@ class LinearFn(Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None,) * 8
+            return (None,) * 9
         x, w, ref, keep_mask = ctx.saved_tensors
         g = g.contiguous()
         if not ctx.act_bwd_done and (ctx.act != _C.EPI_NONE or keep_mask is not None):
@@ -540,4 +547,4 @@ class LinearFn(Function):
             gb = None
         if dst is not None:
             gw = None
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None

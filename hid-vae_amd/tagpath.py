@@ -208,9 +208,12 @@ class LayerNormFn(Function):
     LayerNorm as its only consumer, and gx is returned already taken through that gate (that Linear is built with act_bwd_done)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, mask, mask_scale, residual, in_relu_scale=0.0, res_link=None, extra_grad=None):
+    def forward(ctx, x, gamma, beta, eps, relu, mask, mask_scale, residual, in_relu_scale=0.0, res_link=None, extra_grad=None, computed=None):
         ctx.set_materialize_grads(False)
-        y, mean, rstd = _C.layernorm_fwd(x, gamma, beta, eps, relu, mask, mask_scale, residual)
+        if computed is not None:  # (y, mean, rstd) already produced by a fused launch (hidvae_predictor_fwd): nothing is launched here
+            y, mean, rstd = computed
+        else:
+            y, mean, rstd = _C.layernorm_fwd(x, gamma, beta, eps, relu, mask, mask_scale, residual)
         ctx.save_for_backward(x, gamma, beta, mean, rstd, y if relu else None)
         ctx.cfg = (relu, float(mask_scale) if mask is not None else 1.0, residual is not None, float(in_relu_scale))
         ctx.gamma_param, ctx.beta_param = gamma, beta
@@ -220,7 +223,7 @@ class LayerNormFn(Function):
     @staticmethod
     def backward(ctx, gy):
         if gy is None:
-            return (None,) * 11
+            return (None,) * 12
         x, gamma, beta, mean, rstd, y = ctx.saved_tensors
         relu, scale, has_res, in_relu_scale = ctx.cfg
         gy = gy.contiguous()
@@ -246,7 +249,7 @@ class LayerNormFn(Function):
                 gx = _C.act_bwd(gx, x, _C.EPI_RELU, x, in_relu_scale)
             if gdst is not None:
                 gg = gb = None
-            return gx, gg, gb, None, None, None, None, res_grad, None, None, None
+            return gx, gg, gb, None, None, None, None, res_grad, None, None, None, None
         if link is not None and gy2 is not None:
             gx, part, link.g = _C.layernorm_bwd_partial(gy, x, gamma, beta, mean, rstd, relu, y, scale, in_relu_scale,
                                                         need_gx=ctx.needs_input_grad[0], gy2=gy2, want_sum=True)
@@ -259,7 +262,7 @@ class LayerNormFn(Function):
             from torch.autograd import Variable
             Variable._execution_engine.queue_callback(flush_layernorm_finals)
         _LN_PENDING.append((torch.cuda.current_stream(), part, x.shape[0], x.shape[1], ctx.gamma_param, ctx.beta_param))
-        return gx, None, None, None, None, None, None, res_grad, None, None, None
+        return gx, None, None, None, None, None, None, res_grad, None, None, None, None
 
 
 class GateFn(Function):
@@ -425,8 +428,8 @@ class TagPredLossFn(Function):
 
 
 # ------------------------------------------------------------------------------------------------ compositions
-def _lin(x, m, act=_C.EPI_NONE, mask=None, scale=1.0, act_bwd_done=False, dx_gate=None):
-    return LinearFn.apply(x, m.weight, m.bias, act, mask, scale, act_bwd_done, dx_gate)
+def _lin(x, m, act=_C.EPI_NONE, mask=None, scale=1.0, act_bwd_done=False, dx_gate=None, computed=None):
+    return LinearFn.apply(x, m.weight, m.bias, act, mask, scale, act_bwd_done, dx_gate, computed)
 
 
 def _mask(rand, shape, p, device, training):
@@ -459,6 +462,69 @@ def tag_projector_forward(seq, t, training, rand):
     return h
 
 
+def _predictor_fusable(pred, x, rand):
+    """the one-launch forward (hidvae_predictor_fwd) takes a predictor in training with every hop a LayerNorm, dropout decided in the
+    launch, and no layer wider than 256"""
+    if os.environ.get("HIDVAE_FUSED_PREDICTOR", "1") == "0" or not (pred.training and torch.is_grad_enabled()) or x.dim() != 2:
+        return False
+    E = x.shape[1]
+    if E % 4 != 0 or E > 128 or x.shape[0] < 16:
+        return False
+    fe, blocks, cl = pred.feature_extractor, (pred.residual_block1, pred.residual_block2), pred.classifier
+    if not (isinstance(fe[1], nn.LayerNorm) and isinstance(cl[1], nn.LayerNorm)
+            and all(isinstance(rb[1], nn.LayerNorm) and isinstance(rb[7], nn.LayerNorm) for rb in blocks)):
+        return False
+    lins = [fe[0], cl[0], cl[4], cl[7]] + [rb[k] for rb in blocks for k in (0, 4)]
+    if max(max(m.out_features, m.in_features) for m in lins) > _C.PRED_WMAX or any(m.bias is None for m in lins):
+        return False
+    return pred.dropout_p == 0.0 or hasattr(rand, "state")  # (a provider of mask TENSORS -- the parity tests' injected masks -- keeps the launches apart)
+
+
+def _tag_predictor_forward_fused(pred, x, rand):
+    """tag_predictor_forward with everything behind the gate computed by ONE launch; the autograd tape is then laid by the same
+    Functions as on the unfused path, each handed its output instead of launching (so the backward is the unfused backward)."""
+    training, p = pred.training, pred.dropout_p
+    att = pred.attention
+    h = GateFn.apply(x, att[0].weight, att[0].bias, att[2].weight, att[2].bias, att[4].weight, att[4].bias, bool(pred.apply_norm))
+    fe, blocks, cl = pred.feature_extractor, (pred.residual_block1, pred.residual_block2), pred.classifier
+    B, dev = x.shape[0], x.device
+    # the dropout sites in the order the unfused path requests them
+    m_fe = _mask(rand, (B, fe[0].out_features), p, dev, training)
+    m_rb = []
+    for rb in blocks:
+        m_rb.append((_mask(rand, (B, rb[0].out_features), p, dev, training), _mask(rand, (B, rb[4].out_features), p, dev, training)))
+    m_c0 = _mask(rand, (B, cl[0].out_features), p, dev, training)
+    m_c4 = _mask(rand, (B, cl[4].out_features), p * 0.5, dev, training)
+    units = [dict(lin=fe[0], norm=fe[1], act2=True, drop2=m_fe, carry=True)]
+    for rb, (m0, m4) in zip(blocks, m_rb):
+        units.append(dict(lin=rb[0], norm=rb[1], act2=True, drop2=m0))
+        units.append(dict(lin=rb[4], norm=rb[7], act1=True, drop1=m4, residual=True))
+    units += [dict(lin=cl[0], norm=cl[1], act2=True, drop2=m_c0), dict(lin=cl[4], norm=None, act1=True, drop1=m_c4), dict(lin=cl[7], norm=None)]
+    o = _C.predictor_fwd(h.detach(), units)
+    # ---- the tape: tag_predictor_forward's chain, node for node
+    link = ResidualLink()
+    k = 0
+    f = LayerNormFn.apply(_lin(h, fe[0], computed=o[k]["lin"]), fe[1].weight, fe[1].bias, fe[1].eps, True, m_fe[0], m_fe[1], None, 0.0, None, link,
+                          (o[k]["y"], o[k]["mean"], o[k]["rstd"]))
+    k += 1
+    for n, (rb, (m0, m4)) in enumerate(zip(blocks, m_rb)):
+        r = LayerNormFn.apply(_lin(f, rb[0], computed=o[k]["lin"]), rb[1].weight, rb[1].bias, rb[1].eps, True, m0[0], m0[1], None, 0.0, None, None,
+                              (o[k]["y"], o[k]["mean"], o[k]["rstd"]))
+        k += 1
+        r = _lin(r, rb[4], _C.EPI_RELU, m4[0], m4[1], act_bwd_done=True, computed=o[k]["lin"])
+        nxt = ResidualLink() if n + 1 < len(blocks) else None
+        f = LayerNormFn.apply(r, rb[7].weight, rb[7].bias, rb[7].eps, False, None, 1.0, f.detach(), m4[1], link, nxt,
+                              (o[k]["y"], o[k]["mean"], o[k]["rstd"]))
+        link = nxt
+        k += 1
+    c = LayerNormFn.apply(_lin(f, cl[0], computed=o[k]["lin"]), cl[1].weight, cl[1].bias, cl[1].eps, True, m_c0[0], m_c0[1], None, 0.0, None, None,
+                          (o[k]["y"], o[k]["mean"], o[k]["rstd"]))
+    k += 1
+    c = _lin(c, cl[4], _C.EPI_RELU, m_c4[0], m_c4[1], act_bwd_done=True, computed=o[k]["lin"])
+    k += 1
+    return _lin(c, cl[7], dx_gate=m_c4[1], computed=o[k]["lin"])
+
+
 def tag_predictor_forward(pred, x, x_gate=None, rand=None):
     """pred: modules.h_rqvae.TagPredictor; x: [batch, embed_dim] (x_gate: accepted for older callers, the same data as x).
     Launches per call, forward: the gate 1, then GEMM (+ LayerNorm) per layer; backward: every activation / dropout gate rides in the
@@ -469,6 +535,8 @@ def tag_predictor_forward(pred, x, x_gate=None, rand=None):
     training = pred.training
     if x.dim() != 2:
         raise RuntimeError("TagPredictor expects [batch, embed_dim]")
+    if _predictor_fusable(pred, x, rand):
+        return _tag_predictor_forward_fused(pred, x, rand)
     att = pred.attention
     E = x.shape[1]
     if E % 4 == 0 and E <= 128:

@@ -402,6 +402,24 @@ int hidvae_layernorm_bwd_partial(const float *gy, const float *x, const float *g
                                  const float *rstd, int64_t M, int64_t N, int relu, const float *y_out, float keep_scale,
                                  float in_relu_scale, const float *gy2, float *gsum, float *gx, float *partials, void *stream);
 int hidvae_layernorm_param_final_many(const hidvae_ln_final *problems_host, int n, void *stream);
+/* TagPredictor behind its attention gate (h_rqvae.py:132-188: feature_extractor, residual blocks, classifier) as ONE row-local
+ * forward launch for levels whose layers are at most 256 wide.  A unit is  Linear(+bias) [-> ReLU -> Dropout(1)] [-> LayerNorm
+ * [-> ReLU -> Dropout(2)] [+ carried residual]];  unit i reads unit i-1's output (unit 0 reads h [B, K] at row stride ldh).  `lin`
+ * receives what the separate launches would save as the LayerNorm's input / the Linear's output (after ReLU -> Dropout(1) if act1),
+ * `y`, `mean`, `rstd` the LayerNorm's outputs -- so hidvae_linear_bwd / hidvae_layernorm_bwd_partial run the backward unchanged.
+ * carry: the unit's output becomes the carried residual; residual: the carried residual is added after the LayerNorm and the sum
+ * becomes the new carried residual.  Dropout decisions: the counter-based generator on element index row * N + col of the given site
+ * (threshold 0: no dropout), exactly as hidvae_gemm_f32 / hidvae_layernorm_fwd take them. */
+typedef struct {
+    const float *W, *bias, *gamma, *beta;
+    int N, K;
+    int act1, act2, residual, carry;
+    unsigned drop_site1, drop_threshold1, drop_site2, drop_threshold2;
+    float drop_scale1, drop_scale2, eps;
+    float *lin, *y, *mean, *rstd;
+} hidvae_pred_unit;
+int hidvae_predictor_fwd(const float *h, int64_t ldh, int64_t B, const hidvae_pred_unit *units_host, int n_units,
+                         const unsigned long long *rng_state, void *stream);
 /* The attention gate of TagPredictor (h_rqvae.py:128-139, :196-206) as ONE row-local launch each way (E = 32 (i+1) <= 128, a multiple of 4):
  *   a1 = relu(x W0^T + b0) [B,E/4], a2 = gelu(pre2 = a1 W2^T + b2) [B,E/2], a3 = sigmoid(a2 W4^T + b4) [B,E],
  *   h = x * a3, divided by max(|h|, eps) per row when normalize (nrm receives |h|)

@@ -52,7 +52,7 @@ def test_query_workspace_is_host_only_and_matches_the_documented_formulas():
     assert q(_C.WS_COLSUM, 1000, 48) == 16 * 48 * 4
     assert q(_C.WS_CODEBOOK_GRAD, 2048, 3, 256) == 0 and q(_C.WS_CODEBOOK_GRAD, 8192, 3, 256) == 3 * 256 * 4 * 32 * 4
     assert q(_C.WS_LAYERNORM_BWD_ALL, 1024, 230) == 2 * 256 * 230 * 4
-    assert q(_C.WS_BATCHNORM_FWD, 1024, 512) == 3 * 16 * 512 * 4 and q(_C.WS_BATCHNORM_BWD, 1024, 512) == 2 * 16 * 512 * 4
+    assert q(_C.WS_BATCHNORM_FWD, 1024, 512) == 3 * 16 * 512 * 4 and q(_C.WS_BATCHNORM_BWD, 1024, 512) == 2 * 32 * 512 * 4  # (64- / 32-row chunks)
     assert q(_C.WS_ID_CENSUS, 1024) == (4 * 1024 + 3) * 8
     assert q(_C.WS_TAG_LOSS, 128, 38) == (2 * 128 + 128 * 38) * 4
     with pytest.raises(RuntimeError):

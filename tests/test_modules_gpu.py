@@ -339,3 +339,49 @@ def test_softmax_argmax_rows_is_torchs_softmax_max():
         assert torch.equal(pred[:, 1].cpu(), want_p)
         assert torch.allclose(conf[:, 1].double(), want_c, rtol=2e-6, atol=1e-7)
         assert (pred[:, 0] == -7).all() and (pred[:, 2] == -7).all() and (conf[:, 0] == -7).all() and (conf[:, 2] == -7).all()
+
+
+@pytest.mark.parametrize("E,H,C,layer_idx,B,p", [(32, 256, 38, 0, 1024, 0.4), (64, 128, 17, 1, 100, 0.25), (96, 250, 348, 2, 37, 0.0)])
+def test_one_launch_predictor_forward_matches_the_separate_launches(E, H, C, layer_idx, B, p):
+    """hidvae_predictor_fwd (TagPredictor behind its gate as ONE row-local launch, reference h_rqvae.py:132-188) against the launch
+    sequence it replaces, under the SAME in-kernel dropout decisions: the logits, the input gradient and every parameter gradient
+    (the backward is the same Functions either way; only what they were handed differs in summation order of the LayerNorms)."""
+    import os
+    from hidvae_amd.modules.h_rqvae import TagPredictor
+    from hidvae_amd.rand import DeviceRand
+    from hidvae_amd.tagpath import tag_predictor_forward, flush_layernorm_finals
+    torch.manual_seed(E * 1000 + H)
+    pred = TagPredictor(E, C, hidden_dim=H, dropout_rate=p, use_batch_norm=True, layer_idx=layer_idx).cuda().train()
+    with torch.no_grad():
+        for q in pred.parameters():
+            if q.dim() == 1:
+                q.add_(torch.randn_like(q) * 0.1)  # (biases / affine parameters off their initial 0 / 1)
+    g = torch.Generator().manual_seed(B + C)
+    cat = torch.randn(B, 128, generator=g).cuda()
+    gout = torch.randn(B, C, generator=g).cuda()
+
+    def run(fused):
+        os.environ["HIDVAE_FUSED_PREDICTOR"] = "1" if fused else "0"
+        try:
+            for q in pred.parameters():
+                q.grad = None
+            rand = DeviceRand(seed=77)
+            rand.begin_step(cat.device)
+            x = cat[:, :E].detach().requires_grad_()
+            logits = tag_predictor_forward(pred, x, None, rand)
+            logits.backward(gout)
+            flush_layernorm_finals()
+            torch.cuda.synchronize()
+            return logits.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in pred.named_parameters()}
+        finally:
+            os.environ.pop("HIDVAE_FUSED_PREDICTOR", None)
+
+    lf, gxf, gpf = run(True)
+    lu, gxu, gpu = run(False)
+    rel = lambda a, b: float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
+    assert rel(lf, lu) <= 1e-5, rel(lf, lu)
+    assert rel(gxf, gxu) <= 2e-5, rel(gxf, gxu)
+    for n in gpu:
+        assert rel(gpf[n], gpu[n]) <= 3e-5 * max(1.0, (B / 256) ** 0.5), (n, rel(gpf[n], gpu[n]))
+    if p > 0:  # the two runs really dropped the same units: an activation that is exactly zero in one is zero in the other
+        assert float((lf - lu).abs().max()) < 1e-3
