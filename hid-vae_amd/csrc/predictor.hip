@@ -59,10 +59,26 @@ __device__ __forceinline__ float4 ld4_guard(const float *row, int k, int K, bool
     return v;
 }
 
+// four consecutive features of one item: one sixteen-byte buffer store where all four exist (rows are only dword-aligned: N = 230;
+// the buffer form takes that), element-wise at the ragged end of a row
+__device__ __forceinline__ void pred_store4(float *base, int64_t item, int N, int col, const float (&v)[4], bool in_range, int64_t B) {
+    if (!in_range || col >= N) return;
+    if (col + 3 < N) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(4 * B * N), 0x00020000);
+        const f32x4 w = {v[0], v[1], v[2], v[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), r, (int)(4 * (item * N + col)), 0, 0);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (col + e < N) base[item * N + col + e] = v[e];
+    }
+}
+
 __global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs a) {
     __shared__ float4 img[3][PRED_IMG];                 // activation images: input / output of the running unit, the carried residual
     __shared__ float red[2][PRED_WAVES][16];            // per-wave row partials (sum, then squared deviations)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (a scalar: what depends on it branches on the scalar unit)
     const int it = lane & 15, q = lane >> 4;
     const int64_t item = (int64_t)blockIdx.x * 16 + it;
     const bool in_range = item < a.B;
@@ -80,7 +96,7 @@ __global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs
     __syncthreads();
     int cur = 0, res = 2;  // img[cur]: the unit's input; img[cur ^ 1]: its output; img[res]: the carried residual
     for (int ui = 0; ui < a.n; ui++) {
-        const PredUnit &u = a.u[ui];
+        const PredUnit u = a.u[ui];  // (by value: one batch of scalar loads per unit, not one per use of a run-time-indexed argument field)
         const int N = u.N, K = u.K, ntile = (N + 15) / 16, nkb = (K + 15) / 16;
         const float4 *Hin = img[cur];
         float4 *Hout = img[cur ^ 1];
@@ -97,10 +113,28 @@ __global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs
         {
             const int r0 = 16 * t0 + it, r1 = 16 * t1 + it;
             const int o0 = 4 * ((r0 < N ? r0 : 0) * K + 4 * q), o1 = 4 * ((r1 < N ? r1 : 0) * K + 4 * q);
+            // (every load is issued, unconditionally and in order -- one that is not needed is aimed out of the buffer and returns zeros:
+            //  with the loads behind branches the compiler waited for ALL of them before the first MFMA)
 #pragma unroll
             for (int kb = 0; kb < PRED_WMAX / 16; kb++) {
-                if (kb < nkb && has0) wv[0][kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, o0 + 64 * kb, 0, 0));
-                if (kb < nkb && has1) wv[1][kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, o1 + 64 * kb, 0, 0));
+                wv[0][kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (kb < nkb && has0) ? o0 + 64 * kb : 0x7FFFFFF0, 0, 0));
+                wv[1][kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (kb < nkb && has1) ? o1 + 64 * kb : 0x7FFFFFF0, 0, 0));
+            }
+        }
+        // the unit's per-feature vectors for this lane's columns, fetched NOW (behind the weights, in front of the MFMAs): read at their
+        // point of use they were three more dependent round trips per unit
+        f32x4 bia[2], gam[2], bet[2];
+        {
+            const int nb = 4 * N;
+            const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(u.bias != nullptr ? u.bias : u.W), 0, u.bias != nullptr ? nb : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(u.gamma != nullptr ? u.gamma : u.W), 0, u.gamma != nullptr ? nb : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t re_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(u.gamma != nullptr ? u.beta : u.W), 0, u.gamma != nullptr ? nb : 0, 0x00020000);
+#pragma unroll
+            for (int s_ = 0; s_ < 2; s_++) {
+                const int off = 4 * (16 * (wave + PRED_WAVES * s_) + 4 * q);  // (columns past N, or a vector that is absent: zeros)
+                bia[s_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_, off, 0, 0));
+                gam[s_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg_, off, 0, 0));
+                bet[s_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(re_, off, 0, 0));
             }
         }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -133,7 +167,7 @@ __global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int col = 16 * t + 4 * q + e;
-                float x = col < N ? v[e] + (u.bias != nullptr ? u.bias[col] : 0.0f) : 0.0f;
+                float x = col < N ? v[e] + bia[s][e] : 0.0f;
                 if (u.act1 && col < N) {
                     x = fmaxf(x, 0.0f);
                     if (u.thr1 != 0u) {
@@ -142,10 +176,10 @@ __global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs
                     }
                 }
                 v[e] = x;
-                if (in_range && col < N) u.lin[item * N + col] = x;
                 psum += x;
             }
             val[s] = make_float4(v[0], v[1], v[2], v[3]);
+            pred_store4(u.lin, item, N, 16 * t + 4 * q, v, in_range, (int64_t)a.B);
         }
         if (u.gamma != nullptr) {
             // ---- LayerNorm over the item's N features: quad lanes -> wave -> workgroup, fixed order
@@ -188,7 +222,7 @@ __global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs
                     const int col = 16 * t + 4 * q + e;
                     float o = 0.0f;
                     if (col < N) {
-                        o = (v[e] - mu) * rs * u.gamma[col] + u.beta[col];
+                        o = (v[e] - mu) * rs * gam[s][e] + bet[s][e];
                         if (u.act2) {
                             o = fmaxf(o, 0.0f);
                             if (u.thr2 != 0u) {
@@ -197,11 +231,11 @@ __global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs
                             }
                         }
                         if (u.residual) o = o + rr[e];
-                        if (in_range) u.y[item * N + col] = o;
                     }
                     v[e] = o;
                 }
                 val[s] = make_float4(v[0], v[1], v[2], v[3]);
+                pred_store4(u.y, item, N, 16 * t + 4 * q, v, in_range, (int64_t)a.B);
             }
         }
 #pragma unroll
@@ -224,6 +258,7 @@ __global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs
 extern "C" int hidvae_predictor_fwd(const float *h, int64_t ldh, int64_t B, const hidvae_pred_unit *units, int n_units,
                                     const unsigned long long *rng_state, void *stream) {
     HV_REQUIRE(h && units && B >= 1 && n_units >= 1 && n_units <= PRED_MAX_UNITS, "predictor_fwd: bad arguments");
+    HV_REQUIRE(B <= (int64_t)1 << 20, "predictor_fwd: B=%lld (byte offsets are 32-bit)", (long long)B);
     PredArgs a{};
     a.h = h; a.B = B; a.ldh = ldh; a.n = n_units; a.rng = rng_state;
     for (int i = 0; i < n_units; i++) {
