@@ -28,6 +28,7 @@ _SIGNATURES = {
     "hidvae_layernorm_bwd_partial": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "hidvae_layernorm_param_final_many": [_vp, _i, _vp],
     "hidvae_predictor_fwd": [_vp, _i64, _i64, _vp, _i, _vp, _vp],
+    "hidvae_predictor_bwd": [_vp, _i64, _i64, _vp, _i, _vp, _i64, _vp],
     "hidvae_gate_fwd": [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_gate_bwd": [_vp, _i64, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_colsum": [_vp, _i64, _i64, _i64, _vp, _i, _vp, _vp],
@@ -946,7 +947,7 @@ class PredUnit(ctypes.Structure):  # hidvae_pred_unit
                 ("act1", _i), ("act2", _i), ("residual", _i), ("carry", _i),
                 ("drop_site1", ctypes.c_uint), ("drop_threshold1", ctypes.c_uint), ("drop_site2", ctypes.c_uint), ("drop_threshold2", ctypes.c_uint),
                 ("drop_scale1", ctypes.c_float), ("drop_scale2", ctypes.c_float), ("eps", ctypes.c_float),
-                ("lin", _vp), ("y", _vp), ("mean", _vp), ("rstd", _vp)]
+                ("lin", _vp), ("y", _vp), ("mean", _vp), ("rstd", _vp), ("g_lin", _vp), ("partials", _vp)]
 
 
 PRED_WMAX, PRED_MAX_UNITS = 256, 10
@@ -988,6 +989,33 @@ def predictor_fwd(h, units):
         outs.append(o)
     _check(lib().hidvae_predictor_fwd(_p(h), _row_stride(h, "h"), B, ctypes.cast(arr, _vp), len(units), _p(state), _stream()), "hidvae_predictor_fwd")
     return outs
+
+
+def predictor_bwd(g_out, units, outs, E):
+    """the input-gradient chain of predictor_fwd's units in one launch.  units / outs: as given to / returned by predictor_fwd.
+    -> (g_h [B, E], per unit dict(g_lin=[B, N], partials=[ceil(B/4), 2, N] or None))"""
+    _f32(g_out, "g_out")
+    B = g_out.shape[0]
+    dev = g_out.device
+    arr = (PredUnit * len(units))()
+    res = []
+    for q, u, o in zip(arr, units, outs):
+        lin, norm = u["lin"], u.get("norm")
+        N, K = lin.out_features, lin.in_features
+        r = dict(g_lin=torch.empty((B, N), device=dev, dtype=torch.float32), partials=None)
+        q.W, q.N, q.K = lin.weight.data_ptr(), N, K
+        q.act1, q.act2, q.residual, q.carry = int(bool(u.get("act1"))), int(bool(u.get("act2"))), int(bool(u.get("residual"))), int(bool(u.get("carry")))
+        q.drop_scale1 = float(u["drop1"][1]) if u.get("drop1") is not None else 1.0
+        q.drop_scale2 = float(u["drop2"][1]) if u.get("drop2") is not None else 1.0
+        q.lin, q.g_lin = o["lin"].data_ptr(), r["g_lin"].data_ptr()
+        if norm is not None:
+            r["partials"] = torch.empty(((B + 3) // 4, 2, N), device=dev, dtype=torch.float32)
+            q.gamma, q.y, q.mean, q.rstd, q.partials = norm.weight.data_ptr(), o["y"].data_ptr(), o["mean"].data_ptr(), o["rstd"].data_ptr(), r["partials"].data_ptr()
+        res.append(r)
+    g_h = torch.empty((B, E), device=dev, dtype=torch.float32)
+    _check(lib().hidvae_predictor_bwd(_p(g_out), _row_stride(g_out, "g_out"), B, ctypes.cast(arr, _vp), len(units), _p(g_h), E, _stream()),
+           "hidvae_predictor_bwd")
+    return g_h, res
 
 
 def gate_fwd(x, W0, b0, W2, b2, W4, b4, normalize, eps=1e-12):

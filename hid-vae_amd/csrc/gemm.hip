@@ -1817,7 +1817,9 @@ static int linear_bwd_impl(const float *g, int64_t ldg, const float *x, int64_t 
     // LDS-shared 64x64 tiles, evenly dealt (gemm_mid_sk_kernel<4, 2>: 16 waves = 2x2 quarters x 4 k-groups, register prefetch two steps
     // ahead; <2, 2>: 8 waves, for launches that share the chip with other streams' -- see co_resident below; not kept: four prefetch stages)
     constexpr int mid_minq = 6;  // shortest range worth a workgroup (steps)
-    if (balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, dX != nullptr) &&
+    // (the rule looks at the layer, not at whether this call wants dX: a weight-gradient-only call on a balanced shape -- the one-launch
+    //  predictor backward's, a projector's first layer -- takes the ring kernel too, and the workspace query says the same)
+    if (balanced_ok && workspace != nullptr && hv_lbwd_balanced(B, n_out, n_in, true) &&
         fits32bit(HIDVAE_GEMM_TN, n_out, n_in, B, ldg, ldx) && (dX == nullptr || fits32bit(HIDVAE_GEMM_NN, B, n_in, n_out, ldg, ldw))) {
         // the LDS-DMA ring kernel (gemm_ring.hip) wherever it takes the problem; the kernels below are what runs when it declines.
         // (First shipped from B = 2048 on, where it won stand-alone; in the step it also wins at B = 1024: tagged 1.156 -> 1.088 ms

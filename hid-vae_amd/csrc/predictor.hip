@@ -35,6 +35,8 @@ struct PredUnit {
     float *lin;                   // [B, N] Linear output (+ bias), after act1 if act1: what LinearFn / LayerNormFn save as their x
     float *y;                     // [B, N] output of the unit (== lin when there is no LayerNorm: then nullptr)
     float *mean, *rstd;           // [B]
+    float *g_lin;                 // backward: [B, N] gradient at the Linear's output (what its weight / bias gradients are formed from)
+    float *partials;              // backward: [ceil(B / 4)][2][N] LayerNorm affine-gradient partials (layout of hidvae_layernorm_bwd_partial)
 };
 
 struct PredArgs {
@@ -253,6 +255,192 @@ __global__ __launch_bounds__(64 * PRED_WAVES) void predictor_fwd_kernel(PredArgs
     }
 }
 
+// ---- backward: the input-gradient chain of the same units in reverse, one launch.  Per unit, with G the gradient of its output (from
+// the next unit's dX) and GR the gradient carried along the residual path:  g = G (+ GR at a residual / carry unit; a residual unit
+// hands g on as the new GR);  through ReLU -> Dropout(2) read off the saved output;  through the LayerNorm (two row sums; the affine
+// gradients' per-4-row partials go out in hidvae_layernorm_bwd_partial's layout);  through ReLU -> Dropout(1) read off the saved
+// Linear output;  g_lin = that, stored for the weight / bias gradients (one grouped launch behind this one);  dX = g_lin W on MFMA with
+// W read down its columns (four dword loads where the forward has one sixteen-byte load).
+__global__ __launch_bounds__(64 * PRED_WAVES) void predictor_bwd_kernel(PredArgs a, const float *g_out, int64_t ldg, float *g_h, int64_t ldgh) {
+    __shared__ float4 img[3][PRED_IMG];       // gradient images: of the running unit's output / input, and the carried residual's
+    __shared__ float red[2][PRED_WAVES][16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int it = lane & 15, q = lane >> 4;
+    const int64_t item = (int64_t)blockIdx.x * 16 + it;
+    const bool in_range = item < a.B;
+    const int64_t chunks = (a.B + 3) / 4;
+    {
+        const int NL = a.u[a.n - 1].N, nb = (NL + 15) / 16;
+        for (int idx = threadIdx.x; idx < PRED_IMG; idx += 64 * PRED_WAVES) {
+            const int kb = idx >> 6, l = idx & 63;
+            const int64_t row = (int64_t)blockIdx.x * 16 + (l & 15);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kb < nb && row < a.B) v = ld4_guard(g_out + row * ldg, 16 * kb + 4 * (l >> 4), NL, true);
+            img[0][idx] = v;
+            img[2][idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int ui = a.n - 1; ui >= 0; ui--) {
+        const PredUnit u = a.u[ui];
+        const int N = u.N, K = u.K, ntn = (N + 15) / 16, ntk = (K + 15) / 16;
+        float4 *G = img[cur];
+        float4 *Gp = img[cur ^ 1];
+        const bool has_ln = u.gamma != nullptr;
+        const int nbytes = 4 * (int)a.B * N;
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(u.lin, 0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(has_ln ? u.y : u.lin, 0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_ln ? u.gamma : u.W), 0, has_ln ? 4 * N : 0, 0x00020000);
+        // ---- phase A: everything elementwise / per row on the unit's N features
+        float g[2][4], xh[2][4], gy[2][4];
+        unsigned posmask[2] = {0u, 0u};  // bit e: the saved Linear output of column col0 + e is > 0 (the ReLU -> Dropout(1) gate)
+        float s1 = 0.0f, s2 = 0.0f;
+        float mu = 0.0f, rs = 0.0f;
+        if (has_ln) { mu = u.mean[in_range ? item : a.B - 1]; rs = u.rstd[in_range ? item : a.B - 1]; }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int t = wave + PRED_WAVES * s;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { g[s][e] = 0.0f; xh[s][e] = 0.0f; gy[s][e] = 0.0f; }
+            if (t >= ntn) continue;
+            const int col0 = 16 * t + 4 * q;
+            const int off = in_range ? 4 * ((int)item * N + col0) : 0x7FFFFFF0;
+            float4 gv = G[t * 64 + lane];
+            if (u.residual || u.carry) {
+                const float4 r4 = img[2][t * 64 + lane];
+                gv.x += r4.x; gv.y += r4.y; gv.z += r4.z; gv.w += r4.w;
+            }
+            if (u.residual) img[2][t * 64 + lane] = gv;  // (own slot: read above by this lane only)
+            const f32x4 l4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, off, 0, 0));
+            const f32x4 y4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
+            const f32x4 ga = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, 4 * col0, 0, 0));
+            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool ok = col0 + e < N;
+                float v = ok ? gg[e] : 0.0f;
+                if (u.act2) v = (ok && y4[e] > 0.0f) ? v * u.scale2 : 0.0f;
+                gy[s][e] = v;
+                if (ok && l4[e] > 0.0f) posmask[s] |= 1u << e;
+                if (has_ln) {
+                    const float x = ok ? (l4[e] - mu) * rs : 0.0f;
+                    const float dy = v * ga[e];
+                    xh[s][e] = x;
+                    g[s][e] = dy;
+                    s1 += dy;
+                    s2 += dy * x;
+                } else {
+                    g[s][e] = (u.act1 && !((posmask[s] >> e) & 1u)) ? 0.0f : (u.act1 ? v * u.scale1 : v);
+                }
+            }
+        }
+        if (has_ln) {
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            if (q == 0) { red[0][wave][it] = s1; red[1][wave][it] = s2; }
+            __syncthreads();
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < PRED_WAVES; w++) { t1 += red[0][w][it]; t2 += red[1][w][it]; }
+            t1 = t1 / (float)N;
+            t2 = t2 / (float)N;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int t = wave + PRED_WAVES * s;
+                if (t >= ntn) continue;
+                const int col0 = 16 * t + 4 * q;
+                float pg[4], pb[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    pg[e] = gy[s][e] * xh[s][e];  // d gamma, d beta terms of this row
+                    pb[e] = gy[s][e];
+                    float gx = col0 + e < N ? rs * ((g[s][e] - t1) - xh[s][e] * t2) : 0.0f;
+                    if (u.act1) gx = ((posmask[s] >> e) & 1u) ? gx * u.scale1 : 0.0f;
+                    g[s][e] = in_range ? gx : 0.0f;
+                    // the four rows of a chunk: lanes it ^ 1, it ^ 2
+                    pg[e] += __shfl_xor(pg[e], 1); pg[e] += __shfl_xor(pg[e], 2);
+                    pb[e] += __shfl_xor(pb[e], 1); pb[e] += __shfl_xor(pb[e], 2);
+                }
+                const int64_t chunk = (int64_t)blockIdx.x * 4 + (it >> 2);
+                if ((it & 3) == 0 && chunk < chunks && u.partials != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (col0 + e < N) {
+                            u.partials[(chunk * 2 + 0) * N + col0 + e] = pg[e];
+                            u.partials[(chunk * 2 + 1) * N + col0 + e] = pb[e];
+                        }
+                }
+            }
+        }
+        // g is now the gradient at the Linear's output: out to memory (weight / bias gradients) and into the image for the dX product
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int t = wave + PRED_WAVES * s;
+            if (t >= ntn) continue;
+            const float v[4] = {g[s][0], g[s][1], g[s][2], g[s][3]};
+            pred_store4(u.g_lin, item, N, 16 * t + 4 * q, v, in_range, (int64_t)a.B);
+            G[t * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+        // ---- phase B: dX [16 items, K] = g_lin [16, N] W [N, K]
+        {
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(u.W), 0, 4 * N * K, 0x00020000);
+            const int t0 = wave, t1 = wave + PRED_WAVES;
+            const bool has0 = t0 < ntk, has1 = t1 < ntk;
+            f32x4 wv[2][PRED_WMAX / 16];
+#pragma unroll
+            for (int nb = 0; nb < PRED_WMAX / 16; nb++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int n = 16 * nb + 4 * q + e;
+                    const int o0 = (nb < ntn && has0 && n < N) ? 4 * (n * K + 16 * t0 + it) : 0x7FFFFFF0;
+                    const int o1 = (nb < ntn && has1 && n < N) ? 4 * (n * K + 16 * t1 + it) : 0x7FFFFFF0;
+                    wv[0][nb][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, o0, 0, 0));
+                    wv[1][nb][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, o1, 0, 0));
+                }
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nb = 0; nb < PRED_WMAX / 16; nb++) {
+                if (nb < ntn) {
+                    const float4 b = G[nb * 64 + lane];
+                    if (has0) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][nb][0], b.x, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][nb][1], b.y, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][nb][2], b.z, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][nb][3], b.w, acc0, 0, 0, 0);
+                    }
+                    if (has1) {
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][nb][0], b.x, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][nb][1], b.y, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][nb][2], b.z, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][nb][3], b.w, acc1, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int t = wave + PRED_WAVES * s;
+                if (t >= ntk) continue;
+                const f32x4 acc = s ? acc1 : acc0;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = 16 * t + 4 * q + e < K ? acc[e] : 0.0f;
+                if (ui > 0) Gp[t * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+                else if (in_range) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (16 * t + 4 * q + e < K) g_h[item * ldgh + 16 * t + 4 * q + e] = v[e];
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 }  // namespace
 
 extern "C" int hidvae_predictor_fwd(const float *h, int64_t ldh, int64_t B, const hidvae_pred_unit *units, int n_units,
@@ -280,3 +468,28 @@ extern "C" int hidvae_predictor_fwd(const float *h, int64_t ldh, int64_t B, cons
     HV_LAUNCH_CHECK("predictor_fwd");
     return HIDVAE_OK;
 }
+
+extern "C" int hidvae_predictor_bwd(const float *g_out, int64_t ldg, int64_t B, const hidvae_pred_unit *units, int n_units, float *g_h,
+                                    int64_t ldgh, void *stream) {
+    HV_REQUIRE(g_out && units && g_h && B >= 1 && n_units >= 1 && n_units <= PRED_MAX_UNITS, "predictor_bwd: bad arguments");
+    HV_REQUIRE(B <= (int64_t)1 << 20, "predictor_bwd: B=%lld (byte offsets are 32-bit)", (long long)B);
+    PredArgs a{};
+    a.B = B; a.n = n_units;
+    for (int i = 0; i < n_units; i++) {
+        const hidvae_pred_unit &s = units[i];
+        HV_REQUIRE(s.W && s.lin && s.g_lin && s.N >= 1 && s.N <= PRED_WMAX && s.K >= 1 && s.K <= PRED_WMAX, "predictor_bwd: unit %d is malformed", i);
+        HV_REQUIRE(i == 0 || s.K == units[i - 1].N, "predictor_bwd: unit %d does not continue unit %d", i, i - 1);
+        HV_REQUIRE(s.gamma == nullptr || (s.y && s.mean && s.rstd && s.partials), "predictor_bwd: unit %d: LayerNorm tensors missing", i);
+        HV_REQUIRE(s.gamma != nullptr || (!s.act2 && !s.residual), "predictor_bwd: unit %d: act2 / residual need the LayerNorm", i);
+        PredUnit &u = a.u[i];
+        u.W = s.W; u.gamma = s.gamma; u.N = s.N; u.K = s.K;
+        u.act1 = s.act1; u.act2 = s.act2; u.residual = s.residual; u.carry = s.carry;
+        u.scale1 = s.drop_scale1; u.scale2 = s.drop_scale2;
+        u.lin = s.lin; u.y = s.y; u.mean = s.mean; u.rstd = s.rstd; u.g_lin = s.g_lin; u.partials = s.partials;
+    }
+    HV_REQUIRE(ldg >= units[n_units - 1].N && ldgh >= units[0].K, "predictor_bwd: leading dimension too small");
+    hipLaunchKernelGGL(predictor_bwd_kernel, dim3((unsigned)hv_cdiv(B, 16)), dim3(64 * PRED_WAVES), 0, (hipStream_t)stream, a, g_out, ldg, g_h, ldgh);
+    HV_LAUNCH_CHECK("predictor_bwd");
+    return HIDVAE_OK;
+}
+

@@ -480,6 +480,67 @@ def _predictor_fusable(pred, x, rand):
     return pred.dropout_p == 0.0 or hasattr(rand, "state")  # (a provider of mask TENSORS -- the parity tests' injected masks -- keeps the launches apart)
 
 
+class PredictorFn(Function):
+    """Everything of a narrow TagPredictor behind its gate as ONE node: forward = hidvae_predictor_fwd, backward = hidvae_predictor_bwd
+    (the whole input-gradient chain) + the eight weight / bias gradients from grouped launches + the LayerNorms' affine partials
+    queued for the step's one finishing launch.  inputs: h (the gate's output), the unit list, then every parameter in unit order
+    (weight, bias[, gamma, beta]) so autograd knows them; -> logits."""
+
+    @staticmethod
+    def forward(ctx, h, units, *params):
+        ctx.set_materialize_grads(False)
+        outs = _C.predictor_fwd(h, units)
+        logits = outs[-1]["lin"]
+        ctx.units, ctx.n_params = units, len(params)
+        ctx.outs = outs[:-1]  # (the last unit's tensor is this node's OUTPUT: saved below, not held as an attribute -- no reference cycle)
+        ctx.save_for_backward(h, logits)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * (2 + ctx.n_params)
+        from .ops import grad_sink
+        h, logits = ctx.saved_tensors
+        units = ctx.units
+        outs = ctx.outs + [dict(lin=logits, y=None, mean=None, rstd=None)]
+        g_h, res = _C.predictor_bwd(g.contiguous(), units, outs, h.shape[1])
+        problems, x_in = [], h
+        for u, o, r in zip(units, outs, res):
+            lin = u["lin"]
+            dst, acc = grad_sink(lin.weight)
+            bdst, bacc = grad_sink(lin.bias)
+            problems.append(dict(g=r["g_lin"], x=x_in, w=lin.weight, need_dx=False, dW=dst, accumulate=acc, bias=True, db=bdst, accumulate_db=bacc,
+                                 _sinks=(dst is not None, bdst is not None)))
+            x_in = o["y"] if u.get("norm") is not None else o["lin"]
+        # the wide layers' weight + bias gradients one ring-kernel launch each (hidvae_linear_bwd without dX), the narrow ones together in
+        # one grouped launch (all eight grouped: 136 us -- the grouped kernel is the per-wave design)
+        B = h.shape[0]
+        done, small = [None] * len(problems), []
+        for i, pr in enumerate(problems):
+            n_out, n_in = pr["w"].shape
+            if _C.workspace_bytes(_C.WS_LINEAR_BWD_ZEROED, B, n_out, n_in, 1) > 0:
+                dW, _, db = _C.linear_bwd(pr["g"], pr["x"], None, False, dW=pr["dW"], accumulate=pr["accumulate"], bias=True, db=pr["db"],
+                                          accumulate_db=pr["accumulate_db"])
+                done[i] = (dW, None, db)
+            else:
+                small.append(i)
+        for k in range(0, len(small), 6):
+            for i, r in zip(small[k:k + 6], _C.linear_bwd_group([problems[i] for i in small[k:k + 6]])):
+                done[i] = r
+        grads = []
+        for u, r, pr, (dW, _, db) in zip(units, res, problems, done):
+            grads += [None if pr["_sinks"][0] else dW, None if pr["_sinks"][1] else db]
+            norm = u.get("norm")
+            if norm is not None:
+                if not _LN_PENDING and not _LN_DEFER[0]:
+                    from torch.autograd import Variable
+                    Variable._execution_engine.queue_callback(flush_layernorm_finals)
+                _LN_PENDING.append((torch.cuda.current_stream(), r["partials"], h.shape[0], norm.weight.shape[0], norm.weight, norm.bias))
+                grads += [None, None]
+        return (g_h, None) + tuple(grads)
+
+
 def _tag_predictor_forward_fused(pred, x, rand):
     """tag_predictor_forward with everything behind the gate computed by ONE launch; the autograd tape is then laid by the same
     Functions as on the unfused path, each handed its output instead of launching (so the backward is the unfused backward)."""
@@ -500,6 +561,9 @@ def _tag_predictor_forward_fused(pred, x, rand):
         units.append(dict(lin=rb[0], norm=rb[1], act2=True, drop2=m0))
         units.append(dict(lin=rb[4], norm=rb[7], act1=True, drop1=m4, residual=True))
     units += [dict(lin=cl[0], norm=cl[1], act2=True, drop2=m_c0), dict(lin=cl[4], norm=None, act1=True, drop1=m_c4), dict(lin=cl[7], norm=None)]
+    if os.environ.get("HIDVAE_FUSED_PREDICTOR_BWD", "1") != "0":  # ... and its backward as one node too
+        params = [t for u in units for t in ([u["lin"].weight, u["lin"].bias] + ([u["norm"].weight, u["norm"].bias] if u.get("norm") is not None else []))]
+        return PredictorFn.apply(h, units, *params)
     o = _C.predictor_fwd(h.detach(), units)
     # ---- the tape: tag_predictor_forward's chain, node for node
     link = ResidualLink()

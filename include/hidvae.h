@@ -417,9 +417,15 @@ typedef struct {
     unsigned drop_site1, drop_threshold1, drop_site2, drop_threshold2;
     float drop_scale1, drop_scale2, eps;
     float *lin, *y, *mean, *rstd;
+    float *g_lin, *partials;   /* backward only: [B, N] gradient at the Linear's output; [ceil(B/4)][2][N] LayerNorm affine partials */
 } hidvae_pred_unit;
 int hidvae_predictor_fwd(const float *h, int64_t ldh, int64_t B, const hidvae_pred_unit *units_host, int n_units,
                          const unsigned long long *rng_state, void *stream);
+/* the input-gradient chain of the same units in reverse, one launch: g_out [B, N_last] -> g_h [B, K_0]; per unit g_lin (from which
+ * dW = g_lin^T in, db = colsum g_lin follow: hidvae_linear_bwd_group) and the LayerNorm partials (hidvae_layernorm_param_final_many
+ * finishes them).  The gates are read off the tensors the forward saved (y > 0, lin > 0): no keep decision is re-drawn. */
+int hidvae_predictor_bwd(const float *g_out, int64_t ldg, int64_t B, const hidvae_pred_unit *units_host, int n_units, float *g_h,
+                         int64_t ldgh, void *stream);
 /* The attention gate of TagPredictor (h_rqvae.py:128-139, :196-206) as ONE row-local launch each way (E = 32 (i+1) <= 128, a multiple of 4):
  *   a1 = relu(x W0^T + b0) [B,E/4], a2 = gelu(pre2 = a1 W2^T + b2) [B,E/2], a3 = sigmoid(a2 W4^T + b4) [B,E],
  *   h = x * a3, divided by max(|h|, eps) per row when normalize (nrm receives |h|)

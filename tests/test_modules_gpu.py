@@ -360,8 +360,9 @@ def test_one_launch_predictor_forward_matches_the_separate_launches(E, H, C, lay
     cat = torch.randn(B, 128, generator=g).cuda()
     gout = torch.randn(B, C, generator=g).cuda()
 
-    def run(fused):
+    def run(fused, bwd=True):
         os.environ["HIDVAE_FUSED_PREDICTOR"] = "1" if fused else "0"
+        os.environ["HIDVAE_FUSED_PREDICTOR_BWD"] = "1" if bwd else "0"
         try:
             for q in pred.parameters():
                 q.grad = None
@@ -375,13 +376,15 @@ def test_one_launch_predictor_forward_matches_the_separate_launches(E, H, C, lay
             return logits.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in pred.named_parameters()}
         finally:
             os.environ.pop("HIDVAE_FUSED_PREDICTOR", None)
+            os.environ.pop("HIDVAE_FUSED_PREDICTOR_BWD", None)
 
-    lf, gxf, gpf = run(True)
     lu, gxu, gpu = run(False)
     rel = lambda a, b: float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
-    assert rel(lf, lu) <= 1e-5, rel(lf, lu)
-    assert rel(gxf, gxu) <= 2e-5, rel(gxf, gxu)
-    for n in gpu:
-        assert rel(gpf[n], gpu[n]) <= 3e-5 * max(1.0, (B / 256) ** 0.5), (n, rel(gpf[n], gpu[n]))
+    for bwd in (False, True):  # the one-launch forward under the separate backward launches, then with the one-launch backward too
+        lf, gxf, gpf = run(True, bwd)
+        assert rel(lf, lu) <= 1e-5, (bwd, rel(lf, lu))
+        assert rel(gxf, gxu) <= 2e-5, (bwd, rel(gxf, gxu))
+        for n in gpu:
+            assert rel(gpf[n], gpu[n]) <= 3e-5 * max(1.0, (B / 256) ** 0.5), (bwd, n, rel(gpf[n], gpu[n]))
     if p > 0:  # the two runs really dropped the same units: an activation that is exactly zero in one is zero in the other
         assert float((lf - lu).abs().max()) < 1e-3
