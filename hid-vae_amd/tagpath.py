@@ -561,7 +561,13 @@ def _tag_predictor_forward_fused(pred, x, rand):
         units.append(dict(lin=rb[0], norm=rb[1], act2=True, drop2=m0))
         units.append(dict(lin=rb[4], norm=rb[7], act1=True, drop1=m4, residual=True))
     units += [dict(lin=cl[0], norm=cl[1], act2=True, drop2=m_c0), dict(lin=cl[4], norm=None, act1=True, drop1=m_c4), dict(lin=cl[7], norm=None)]
-    if os.environ.get("HIDVAE_FUSED_PREDICTOR_BWD", "1") != "0":  # ... and its backward as one node too
+    # ... and, on request, its backward as one node too (PredictorFn: hidvae_predictor_bwd + the wide layers' weight gradients on the ring
+    # kernel).  Off by default: it takes level 0's backward from 26 launches / 342 us of lane time to ~12 / ~190, but once the forward is
+    # one launch the caller's lane is no longer the longest -- the step ends with level 2's lane -- and the 64-workgroup kernel costs the
+    # other lanes what it saves: 1.053-1.066 vs 1.059-1.061 ms (profiles/r04_fused_predictor_bwd_ab.log; with all weight gradients of the
+    # level in ONE launch of a ring kernel generalised to a list of problems: 1.088 vs 1.078 on another box, and 1-2 % on every ring
+    # launch for the extra indirection -- not kept)
+    if os.environ.get("HIDVAE_FUSED_PREDICTOR_BWD", "0") == "1":
         params = [t for u in units for t in ([u["lin"].weight, u["lin"].bias] + ([u["norm"].weight, u["norm"].bias] if u.get("norm") is not None else []))]
         return PredictorFn.apply(h, units, *params)
     o = _C.predictor_fwd(h.detach(), units)
