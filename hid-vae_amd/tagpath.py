@@ -265,6 +265,10 @@ class LayerNormFn(Function):
         return gx, None, None, None, None, None, None, res_grad, None, None, None, None
 
 
+_PARAM_LATER = [None]  # a list while a level's early backward is being issued: launches that only produce PARAMETER gradients wait in it
+                       # until the level's gradient hand-over has been signalled (tag_heads_forward flushes it on the same stream)
+
+
 class GateFn(Function):
     """TagPredictor's attention gate (h_rqvae.py:128-139, :196-206) as one launch each way (_C.gate_fwd / _C.gate_bwd) plus one grouped
     launch for the three Linears' weight and bias gradients.  x: the level's concat-embedding view [B, E] (a column prefix of
@@ -289,12 +293,25 @@ class GateFn(Function):
         x, W0, W2, W4, a1, pre2, a2, a3, nrm = ctx.saved_tensors
         gx, g3, g2, g1 = _C.gate_bwd(gh.contiguous(), x, W0, W2, W4, ctx.normalize, (a1, pre2, a2, a3, nrm))
         probs, sunk = [], []
+        later = _PARAM_LATER[0]
         for g, inp, wp, bp in ((g1, x, ctx.params[0], ctx.params[1]), (g2, a1, ctx.params[2], ctx.params[3]), (g3, a2, ctx.params[4], ctx.params[5])):
-            dst, acc = grad_sink(wp)
-            bdst, bacc = grad_sink(bp)
+            if later is not None:
+                # deferred (below): the launch writes the parameters' gradient slots / .grad itself and autograd is handed nothing -- a
+                # tensor returned now and filled later would be CLONED by AccumulateGrad while still empty (it sees our reference to it)
+                dst, acc = _param_grad_slot(wp)
+                bdst, bacc = _param_grad_slot(bp)
+            else:
+                dst, acc = grad_sink(wp)
+                bdst, bacc = grad_sink(bp)
             probs.append(dict(g=g, x=inp, w=wp, need_dx=False, dW=dst, accumulate=acc, bias=True, db=bdst, accumulate_db=bacc))
             sunk.append((dst is not None, bdst is not None))
-        res = _C.linear_bwd_group(probs)
+        if later is not None:
+            # the three weight / bias gradients are not on the way to emb_cat: their (grouped) launch is issued behind the level's
+            # hand-over event (12.8 us of the widest level's lane in front of that event otherwise)
+            res = [(pr["dW"], None, pr["db"]) for pr in probs]
+            later.append(lambda probs=probs: _C.linear_bwd_group(probs))
+        else:
+            res = _C.linear_bwd_group(probs)
         out = [gx if ctx.need_x else None]
         for (dW, _, db), (ws, bs) in zip(res, sunk):
             out += [None if ws else dW, None if bs else db]
@@ -882,6 +899,10 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
                     # (called with the unit's stream current: the engine's end-of-pass synchronisation stays on that stream; the
                     #  caller's stream does not wait for a side stream's backward before HeadsGradPort.collect)
                     with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+                        if kind == "pred" and level_done is not None:
+                            # (only where the hand-over is an event of its own -- the per-level hook's case; without it the hand-over
+                            #  joins the whole lane and there is nothing to get out of its way)
+                            _PARAM_LATER[0] = []  # collected through this level's two units, issued after its hand-over below
                         torch.autograd.backward([scal[(kind, i)][0]], [seed_a if kind == "align" else seed_p])
                         if kind == "align" and st is not None and level_done is not None:
                             # (without the hook -- data parallel, gradient accumulation -- the hand-over joins the whole lane: the
@@ -889,7 +910,11 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
                             ev = torch.cuda.Event()  # the gradient hand-over waits for the backward into emb_cat only ...
                             ev.record(st)
                             bwd_done[i] = ev
-                        if kind == "align" and i in proj_cut:  # ... then the projector's backward,
+                        if kind == "align":  # ... then what only produces parameter gradients: the deferred launches,
+                            later, _PARAM_LATER[0] = _PARAM_LATER[0], None
+                            for fn in later or ():
+                                fn()
+                        if kind == "align" and i in proj_cut:  # the projector's backward,
                             head, cut = proj_cut.pop(i)
                             g_cut, cut.grad = cut.grad, None
                             if g_cut is not None:
@@ -903,6 +928,7 @@ def tag_heads_forward(model, emb_cat, tags_emb, tags_indices, defer_join=False, 
                 accs.append(scal[("pred", i)][1])
         finally:
             _LN_DEFER[0] = False
+            _PARAM_LATER[0] = None
         port.leaves, port.streams, port.done = list(views), lanes[1:], bwd_done
         out = tuple(aligns) + tuple(preds) + tuple(accs)
 
