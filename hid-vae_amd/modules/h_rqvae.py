@@ -9,6 +9,8 @@ The reference's quirks that change results are reproduced on purpose and cited w
 (Q3 transposed uniqueness call, Q4 double weights, Q5 layer_idx=0, Q6 rotation residuals)."""
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 from torch import Tensor, nn
 
@@ -379,7 +381,12 @@ class HRqVae(nn.Module, _HubMixin):
         else:
             self._heads_port = None
         early_projs = None
-        if early_heads:  # the projectors need only the batch: beside the encoder, on the level streams (tagpath.tag_projectors_early)
+        # the projectors need only the batch: they run on the level streams beside the front of the step (tagpath.tag_projectors_early) --
+        # from the fused middle launch on, not from the step's first launch: beside the encoder's two wide layers they slow those down
+        # (22 vs 13 us for the first), and the encoder is in front of EVERY lane; the middle launch runs on 64 CUs and leaves them room
+        # (tagged step 1.049-1.058 -> 1.029-1.044 ms, B = 2048 1.726 -> 1.695; HIDVAE_PROJ_AFTER_ENC=0: from the first launch on)
+        late_proj = self._bottleneck_ok(x) and os.environ.get("HIDVAE_PROJ_AFTER_ENC", "1") != "0"
+        if early_heads and not late_proj:
             from ..tagpath import tag_projectors_early
             early_projs = tag_projectors_early(self, tags_emb.float(), self._rand())
         y_dec = None
@@ -391,6 +398,9 @@ class HRqVae(nn.Module, _HubMixin):
             from ..ops import BottleneckFn, MLPBackFn, MLPFrontFn
             We, Wd = self.encoder.weights(), self.decoder.weights()
             pre1, h1 = MLPFrontFn.apply(x, *We[:-2])
+            if early_heads and late_proj:
+                from ..tagpath import tag_projectors_early
+                early_projs = tag_projectors_early(self, tags_emb.float(), self._rand())
             z, ids, emb_cat, emb_sum, qloss, pre_d1, d1, embs_norm, p_unique = BottleneckFn.apply(
                 pre1, h1, We[-2], We[-1], Wd[0], Wd[1], self.codebook_normalize, self._fused_mode(), self.commitment_weight,
                 self._normalize_flags(), self._prepared, (lambda: self._census("fused", x.shape[0], x.device)), self._heads_port,
