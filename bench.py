@@ -248,7 +248,7 @@ def kernel_rooflines(args, m, device):
     return out
 
 
-def step_timeline(stepper, pool_batch, device, replays=5):
+def step_timeline(stepper, pool_batch, device, replays=9):
     """In-step duration of every launch of the replayed train step.  HIP events cannot be recorded inside a captured graph on
     ROCm, so the step is re-captured with a device-timestamp launch (hidvae_timestamp: wall_clock64, 10 ns ticks) before and after
     every C-ABI launch, on that launch's own stream; bracket minus the empty bracket = the launch's duration plus one dependent-
@@ -270,11 +270,19 @@ def step_timeline(stepper, pool_batch, device, replays=5):
     finally:
         _C.stamps_end()
         stepper._fwd_bwd = inner
-    for i in range(replays):
+    # every launch's bracket is the MEDIAN over the replays: with three lanes sharing the chip a single replay's brackets swing by a
+    # factor of two from one replay to the next (a bracket also holds whatever the lane waited for inside it)
+    per_replay, empties = [], []
+    for i in range(max(1, replays)):
         stepper([pool_batch(1 + i)])
-    torch.cuda.synchronize()
-    rows, empty = stamps.rows_with_dims()
+        torch.cuda.synchronize()
+        r, e = stamps.rows_with_dims()
+        per_replay.append(r)
+        empties.append(e)
     stepper.graphs = graphs  # back to the un-stamped graph
+    mid = lambda v: sorted(v)[len(v) // 2]
+    rows = [(per_replay[0][k][0], mid([r[k][1] for r in per_replay]), per_replay[0][k][2]) for k in range(len(per_replay[0]))]
+    empty = mid(empties)
     out = []
     for name, us, dims in rows:
         r = dict(entry=name, us=us)
