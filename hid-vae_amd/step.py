@@ -66,7 +66,8 @@ class GraphedTrainStep:
             self.loss_grad_hint = float(torch.tensor(1.0, dtype=torch.float32) / self.ga) if self.ga > 1 else 1.0
             # ... and, with one micro-batch per step and no gradient exchange, a level's head parameters take their AdamW update on that
             # level's stream as soon as its backward is done (90 % of the tagged model's bytes leave the serial tail of the step)
-            if dp is None and self.ga == 1 and hasattr(opt, "step_early") and hasattr(model, "tag_predictors"):
+            if (dp is None and self.ga == 1 and hasattr(opt, "step_early") and hasattr(model, "tag_predictors")
+                    and os.environ.get("HIDVAE_EARLY_ADAMW", "1") != "0"):
                 ranges = [opt.tensor_ranges_of(list(model.tag_predictors[i].parameters()) + list(model.tag_projectors[i].parameters()))
                           for i in range(model.n_layers)]
                 if all(r is not None for r in ranges):
