@@ -37,6 +37,7 @@ _SIGNATURES = {
     "hidvae_bottleneck_fwd": [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp,
                               _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hidvae_rq_backward": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _i64, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _i, _vp],
+    "hidvae_rq_backward_slices": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i64, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _i64, _f, _vp, _i64, _vp, _vp, _i, _vp],
     "hidvae_uniq_loss": [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _i, _vp],
     "hidvae_total_loss": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "hidvae_total_loss_bwd": [_vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _i, _vp],
@@ -629,10 +630,26 @@ def bottleneck_fwd(h1, W2, W3, cb_eff, cc, normalize_input, mode, beta, Wd0, Wd1
 
 
 def rq_backward(y, z, cb_eff, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z_in, gq, gq_items):
+    """g_cat: the gradient of emb_cat [B, L*D], or a LIST of its prefix slices still to be summed (contiguous [B, w_s] tensors: what the
+    tag heads' early backward leaves behind) -- added up inside the launch at embed_dim 32, by hidvae_sum_prefix_slices first otherwise"""
     B = z.shape[0]
     L, K, D = cb_eff.shape
     g_y = torch.empty_like(z)
     dE = torch.empty((B, L * D), device=z.device, dtype=torch.float32)
+    if isinstance(g_cat, (list, tuple)):
+        live = [t for t in g_cat if t is not None]
+        if not live:
+            g_cat = None
+        elif D != EMBED_DIM or len(live) > 2 * MAX_LEVELS or any(not t.is_contiguous() or t.shape[1] % D for t in live):
+            g_cat = sum_prefix_slices(live, B, L * D)
+        else:
+            ptrs = (ctypes.c_void_p * len(live))(*[t.data_ptr() for t in live])
+            widths = (ctypes.c_int32 * len(live))(*[t.shape[1] for t in live])
+            _check(lib().hidvae_rq_backward_slices(_p(y), _p(z), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, int(mode), float(beta),
+                                                   _p(ids), ptrs, widths, len(live), _p(g_sum), _p(g_z_in),
+                                                   int(g_z_in.shape[0]) if g_z_in is not None else 0, float(gq), _p(gq_items),
+                                                   _vec_stride(gq_items), _p(g_y), _p(dE), int(D), _stream()), "hidvae_rq_backward_slices")
+            return g_y, dE
     ldg = _row_stride(g_cat, "g_cat") if g_cat is not None else 0
     _check(lib().hidvae_rq_backward(_p(y), _p(z), B, int(bool(normalize_input)), _p(cb_eff), _p(cc), L, K, int(mode), float(beta),
                                     _p(ids), _p(g_cat), ldg, _p(g_sum), _p(g_z_in),

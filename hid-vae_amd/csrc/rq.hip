@@ -1067,6 +1067,11 @@ struct BwdArgs {
     int64_t gq_stride;
     float *g_y;
     float *dE_rows;
+    // optional, instead of g_cat: the gradient of emb_cat as prefix slices still to be added up (hidvae_rq_backward_slices) -- slice s is a
+    // contiguous [B, width[s]] tensor holding the gradient of the first width[s] columns; summed here in slice order, from zero
+    int n_slices;
+    const float *slice[2 * HIDVAE_MAX_LEVELS];
+    int slice_w[2 * HIDVAE_MAX_LEVELS];
 };
 
 template <int MODE, int L>
@@ -1117,6 +1122,16 @@ __global__ __launch_bounds__(WG_THREADS) void rq_backward_kernel(BwdArgs a) {
         else {
 #pragma unroll
             for (int j = 0; j < 8; j++) go[j] = 0.0f;
+            if (a.n_slices > 0) {  // (the order and the starting zero of hidvae_sum_prefix_slices: the same bits)
+#pragma unroll
+                for (int s = 0; s < 2 * HIDVAE_MAX_LEVELS; s++)
+                    if (s < a.n_slices && i * D < a.slice_w[s]) {
+                        float t[8];
+                        load8(a.slice[s] + src * a.slice_w[s] + i * D + 8 * q, t);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) go[j] += t[j];
+                    }
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) go[j] = (go[j] + gs[j]) - R[j];  // o_i feeds sum, concat and -r_{i+1}
@@ -1577,6 +1592,31 @@ extern "C" int hidvae_rq_backward(const float *y, const float *z, int64_t B, int
     }
     HV_REQUIRE(g_cat == nullptr || (ld_gcat >= (int64_t)L * D && ld_gcat % 4 == 0), "rq_backward: ld_gcat=%lld", (long long)ld_gcat);
     BwdArgs a{y, z, B, normalize_input, cb_eff, cc, K, beta, ids, g_cat, ld_gcat, g_sum, g_z_in, g_z_rows, gq, gq_items, gq_stride, g_y, dE_rows};
+    const int grid = (int)hv_cdiv(B, ITEMS_PER_WG);
+    if (mode == HIDVAE_MODE_STE) return launch_bwd<HIDVAE_MODE_STE>(a, L, grid, (hipStream_t)stream);
+    return launch_bwd<HIDVAE_MODE_ROTATION>(a, L, grid, (hipStream_t)stream);
+}
+
+extern "C" int hidvae_rq_backward_slices(const float *y, const float *z, int64_t B, int normalize_input, const float *cb_eff, const float *cc,
+                                         int L, int64_t K, int mode, float beta, const int64_t *ids, const float *const *g_slices_host,
+                                         const int32_t *slice_width_host, int n_slices, const float *g_sum, const float *g_z_in,
+                                         int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows,
+                                         int embed_dim, void *stream) {
+    HV_REQUIRE(L >= 1 && L <= HIDVAE_MAX_LEVELS, "rq_backward_slices: n_layers=%d not in [1,%d]", L, HIDVAE_MAX_LEVELS);
+    HV_REQUIRE(B >= 1 && K >= 1 && z && cb_eff && cc && ids && g_y, "rq_backward_slices: bad arguments");
+    HV_REQUIRE(!normalize_input || y, "rq_backward_slices: normalize_input needs y");
+    HV_REQUIRE(mode == HIDVAE_MODE_STE || mode == HIDVAE_MODE_ROTATION, "rq_backward_slices: mode %d is not fused", mode);
+    HV_REQUIRE(embed_dim == D, "rq_backward_slices: embed_dim=%d (the width-independent kernels take the summed gradient: hidvae_sum_prefix_slices first)", embed_dim);
+    HV_REQUIRE(n_slices >= 1 && n_slices <= 2 * HIDVAE_MAX_LEVELS && g_slices_host && slice_width_host, "rq_backward_slices: %d slices (1..%d)", n_slices,
+               2 * HIDVAE_MAX_LEVELS);
+    BwdArgs a{y, z, B, normalize_input, cb_eff, cc, K, beta, ids, nullptr, 0, g_sum, g_z_in, g_z_rows, gq, gq_items, gq_stride, g_y, dE_rows};
+    a.n_slices = n_slices;
+    for (int s = 0; s < n_slices; s++) {
+        HV_REQUIRE(g_slices_host[s] != nullptr && slice_width_host[s] >= D && slice_width_host[s] <= L * D && slice_width_host[s] % D == 0,
+                   "rq_backward_slices: slice %d has width %d (a multiple of %d up to %d)", s, slice_width_host[s], D, L * D);
+        a.slice[s] = g_slices_host[s];
+        a.slice_w[s] = slice_width_host[s];
+    }
     const int grid = (int)hv_cdiv(B, ITEMS_PER_WG);
     if (mode == HIDVAE_MODE_STE) return launch_bwd<HIDVAE_MODE_STE>(a, L, grid, (hipStream_t)stream);
     return launch_bwd<HIDVAE_MODE_ROTATION>(a, L, grid, (hipStream_t)stream);

@@ -211,8 +211,9 @@ class BottleneckFn(Function):
             if dst is not None:
                 gWd0 = None
         if g_cat is None and ctx.port is not None:
-            g_cat = ctx.port.collect()
-        g_cat = g_cat.contiguous() if g_cat is not None else None
+            g_cat = ctx.port.collect(as_slices=True)  # (the heads' prefix slices: summed inside the quantiser's backward launch)
+        elif g_cat is not None:
+            g_cat = g_cat.contiguous()
         g_z = g_z.contiguous() if g_z is not None else None
         g_y, dE = _C.rq_backward(y, z, cb, cc, normalize_input, mode, beta, ids, g_cat, g_sum, g_z, 1.0 if g_q is not None else 0.0, g_q)
         sinks = [getattr(t, "_hv_view", None) for t in ctx.tables]

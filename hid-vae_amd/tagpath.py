@@ -54,7 +54,9 @@ class HeadsGradPort:
         self.shape = tuple(shape)
         self.leaves, self.streams, self.done = [], [], []
 
-    def collect(self):
+    def collect(self, as_slices=False):
+        """as_slices: -> the list of prefix slices themselves (the quantiser's backward adds them up inside its own launch:
+        _C.rq_backward) instead of their sum from a launch of its own"""
         main = torch.cuda.current_stream()
         capturing = torch.cuda.is_current_stream_capturing()
         for k, st in enumerate(self.streams):
@@ -80,6 +82,8 @@ class HeadsGradPort:
         if not live:
             return None
         _C.phase_mark("bwd:heads joined (port)")
+        if as_slices:
+            return live
         return _C.sum_prefix_slices(live, self.shape[0], self.shape[1])
 
 

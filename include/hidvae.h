@@ -217,6 +217,14 @@ int hidvae_rq_backward(const float *y, const float *z, int64_t B, int normalize_
                        int mode, float beta, const int64_t *ids,
                        const float *g_cat, int64_t ld_gcat, const float *g_sum, const float *g_z_in,
                        int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows, int embed_dim, void *stream);
+/* hidvae_rq_backward with the gradient of emb_cat handed over as the PREFIX SLICES the tag heads leave behind (slice s: a contiguous
+ * [B, width_s] tensor = the gradient of the first width_s columns, width_s a multiple of 32) instead of their sum: added up on the
+ * fly in slice order, from zero -- the bits of hidvae_sum_prefix_slices followed by hidvae_rq_backward, one launch less.  embed_dim 32. */
+int hidvae_rq_backward_slices(const float *y, const float *z, int64_t B, int normalize_input, const float *cb_eff, const float *cc,
+                              int L, int64_t K, int mode, float beta, const int64_t *ids, const float *const *g_slices_host,
+                              const int32_t *slice_width_host, int n_slices, const float *g_sum, const float *g_z_in,
+                              int64_t g_z_rows, float gq, const float *gq_items, int64_t gq_stride, float *g_y, float *dE_rows,
+                              int embed_dim, void *stream);
 
 /* gE[i][k][:] (+)= sum_{b: ids[b,i]==k} dE_rows[b, i*32:(i+1)*32], pushed through the row-normalise
  * Jacobian for levels with normalize[i] (E_host: raw tables, needed for |E_k|).  gE_host: L device ptrs.
