@@ -1727,6 +1727,17 @@ extern "C" int hidvae_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, cons
             // 24.9 -> 20.7 (64x64); with 1.5 rounds (1024x768x512 on 32x64 tiles) the finer-grained kernel below wins, 14.8 vs 16.3
             const int64_t t_small = hv_cdiv(M, 32) * hv_cdiv(N, 64), t_big = hv_cdiv(M, 64) * hv_cdiv(N, 64);
             const bool fit_small = t_small >= 192 && t_small <= 256, fit_big = t_big >= 224 && t_big <= 256;  // (192 64x64 tiles: no gain)
+            // the wide layers that may split K (the tag predictors of levels 1 / 2: 460 .. 768 wide) on the same kernel's 64x64 tiles.
+            // Stand-alone gemm_directL_kernel<NT, 4> (every wave its own operand strips, K over four waves) is as fast; inside the
+            // three-lane step it is not -- per-wave operand traffic is what the lanes compete for -- and the shared tiles take the
+            // tagged step from 1.045 to 1.032 ms at B = 1024, 1.702 to 1.690 at B = 2048 (profiles/r04_forward_shared_tiles_ab.log;
+            // not kept there: 32x64 tiles (equal), the 2x2-wave 32x32-MFMA tile kernel (+10 %), the same move for 224 .. 447 tiles
+            // or for the exact-chain layers outside the one-round window (no change))
+            if (layout == HIDVAE_GEMM_NT && split_k == 0 && K >= 256 && tiles32 >= 448) {
+                HV_REQUIRE((launch_tile16<4, 4>(g, s)) == 0, "gemm_f32: could not size the LDS of gemm_tile16_kernel");
+                HV_LAUNCH_CHECK("gemm_f32 tile16");
+                return HIDVAE_OK;
+            }
             if (layout == HIDVAE_GEMM_NT && split_k == 1 && K >= 256 && (fit_small || fit_big)) {
                 const int rc = !fit_small ? launch_tile16<4, 4>(g, s) : launch_tile16<2, 4>(g, s);
                 HV_REQUIRE(rc == 0, "gemm_f32: could not size the LDS of gemm_tile16_kernel");
