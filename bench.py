@@ -176,8 +176,8 @@ def kernel_rooflines(args, m, device):
                     us=t, flops=fl))
     g = torch.randn(B, 512, device=device)
     gw = torch.empty(512, 768, device=device)
-    t = time_kernel(lambda: _C.gemm(_C.GEMM_TN, g, x, out=gw, split_k=0))
-    out.append(dict(kernel="gemm_direct_kernel<TN,8,3> dW encoder layer 0: [512,B]x[B,768] (in-workgroup split-K)", bound="mfma",
+    t = time_kernel(lambda: _C.linear_bwd(g, x, None, False, dW=gw, bias=True))  # (the step's own launch: the first layer needs no dX)
+    out.append(dict(kernel="gemm_ring_bwd_kernel encoder layer 0 backward, weight gradient only: dW [512,768] = g^T x, db (LDS-DMA ring, evenly dealt k-steps)", bound="mfma",
                     achieved=fl / t * 1e-6, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=fl / t * 1e-6 / MFMA_F32_PEAK_TF, traffic=None,
                     us=t, flops=fl))
     wd = m.decoder.weights()[-1].detach()  # [768, 512]: the widest Linear backward of the step (decoder's last layer)

@@ -13,11 +13,11 @@ from collections import defaultdict
 # bench.py kernel-name prefix  <-  (substring of the profiled kernel name, grid size in work-items)
 QUOTED = [
     ("gemm_tile16_kernel encoder layer 0", "gemm_tile16_kernel<2, 4>", None),
-    ("gemm_direct_kernel<TN,8,3> dW encoder layer 0", "gemm_direct_kernel<2, 8, 3", None),
     ("rq_forward_kernel (fused L-level VQ, code-split variant)", "rq_forward_kernel<3, true, true, true", None),
     ("rq_forward at 1,048,576 items", "rq_forward_pf32_kernel<3, true", None),
     ("gemm_f32_kernel<2,2,NT> encoder layer 0 at 65,536 rows", "gemm_f32_kernel<2, 2, 0>", None),
-    # three launches of the ring kernel, told apart by their grids (workgroups x 256 threads; gemm_ring.hip: G = min(512, S / 8) ranges)
+    # four launches of the ring kernel, told apart by their grids (workgroups x 256 threads; gemm_ring.hip: G = min(512, S / 8) ranges)
+    ("gemm_ring_bwd_kernel encoder layer 0 backward, weight gradient only", "gemm_ring_bwd_kernel", 101376),  # 396 ranges of 8 steps
     ("gemm_ring_bwd_kernel decoder layer 3 backward", "gemm_ring_bwd_kernel", 131072),                        # 1024 x 768 x 512, no bias
     ("gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 1024", "gemm_ring_bwd_kernel", 129280),   # 505 ranges of 17 steps
     ("gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 2048", "gemm_ring_bwd_kernel", 128768),   # 503 ranges of 34 steps

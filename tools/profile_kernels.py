@@ -30,7 +30,7 @@ pre = torch.randn(B, 512, device=dev)
 g1 = torch.randn(B, 256, device=dev)
 for _ in range(10):
     _C.gemm(_C.GEMM_NT, x, w0, out=o0, epilogue=_C.EPI_SILU, aux=a0)
-    _C.gemm(_C.GEMM_TN, g, x, out=gw, split_k=0)
+    _C.linear_bwd(g, x, None, False, dW=gw, bias=True)  # encoder layer 0 backward as the step launches it: weight gradient + bias, no dX
     _C.linear_bwd(g1, o0, w1, True, _C.EPI_DSILU, pre)  # the paired dW + dX launch of encoder layer 1
     _C.rq_forward(y_small, cb, cc, True, 3, True, 0.4)
 # round 2: the launch family that leads the step (hidvae_linear_bwd on the decoder's last layer), the streamed

@@ -13,8 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step -- python3 $R/
 note "pass step done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_tagged -- python3 $R/bench.py --cpu-seconds 0 --steps 50 --warmup 5 --also-large 0 --also-other 0 --kernels 0 --windows 1 --tagged 1 > $OUT/step_tagged.log 2>&1
 note "pass step_tagged done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_config3 -- python3 $R/bench.py --cpu-seconds 0 --steps 50 --warmup 5 --also-large 0 --also-other 0 --kernels 0 --windows 1 --batch 2048 --tagged 1 > $OUT/step_config3.log 2>&1
-note "pass step_config3 (B=2048, tagged) done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_config3 -- python3 $R/bench.py --cpu-seconds 0 --steps 50 --warmup 5 --also-large 0 --also-other 0 --kernels 0 --windows 1 --batch 2048 --tagged 1 --hparams kuairand > $OUT/step_config3.log 2>&1
+note "pass step_config3 (B=2048, tagged, kuairand hyper-parameters) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_config5 -- python3 $R/bench.py --cpu-seconds 0 --steps 100 --warmup 10 --also-large 0 --also-other 0 --tagged 0 --kernels 0 --windows 1 --batch 4096 --levels 4 --codes 1024 > $OUT/step_config5.log 2>&1
 note "pass step_config5 (B=4096, 4x1024) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_config4 -- python3 $R/bench.py --cpu-seconds 0 --steps 100 --warmup 10 --also-large 0 --also-other 0 --tagged 0 --kernels 0 --windows 1 --batch 8192 > $OUT/step_config4.log 2>&1
