@@ -524,8 +524,17 @@ def run_workload(args, device, rank, world, dist):
         stepper.enabled, stepper.graphs, use_graph = False, None, False
         torch.cuda.synchronize()
 
+    # The timed step forms its batch as train_hidvae.train() does: the sampler's ids pick rows of the resident item tables (here: the
+    # synthetic pool as one table of pool * batch items, a fixed shuffle of it cut into batches) and ResidentItemData.gather_into
+    # writes them straight into the step's input buffers -- one hidvae_gather_rows launch, on the step's stream, inside the timed region
+    from hidvae_amd.data.items import ResidentItemData
+    table = ResidentItemData(pool_x.reshape(-1, pool_x.shape[-1]), pool_te.reshape(-1, *pool_te.shape[2:]) if args.tagged else None,
+                             pool_ti.reshape(-1, pool_ti.shape[-1]) if args.tagged else None)
+    shuffle = torch.randperm(len(table), generator=torch.Generator().manual_seed(99 + rank)).to(device)
+    ids = [shuffle[j * args.batch:(j + 1) * args.batch].contiguous() for j in range(args.pool)]
+
     def step(i):
-        stepper([pool_batch(i)])
+        stepper([table.gather_into(ids[i % args.pool], stepper.input_buffers())])
 
     for i in range(args.warmup):
         step(i)

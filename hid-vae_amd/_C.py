@@ -79,6 +79,7 @@ _SIGNATURES = {
     "hidvae_loss_bwd": [_vp, _vp, _vp, _i64, _i64, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _f, _vp],
     "hidvae_padded_to_jagged": [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp],
     "hidvae_jagged_to_padded": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
+    "hidvae_gather_rows": [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp],
     "hidvae_codebook_prepare_adamw": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _i, _vp],
     "hidvae_adamw_prepare": [_vp, _vp, _vp, _i, _f, _f, _f, _i64, _i64, _f, _vp, _vp],
     "hidvae_adamw_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _vp],
@@ -1332,3 +1333,33 @@ def jagged_to_padded(values, offsets, B, N):
     _check(lib().hidvae_jagged_to_padded(ctypes.c_void_p(values.data_ptr()), _p(offsets), _p(x), N * D * es, D * es, B, N, D * es, _stream()),
            "hidvae_jagged_to_padded")
     return x
+
+
+GATHER_MAX = 4
+
+
+def gather_rows(idx, tables, outs):
+    """outs[t][r] = tables[t][idx[r]] for every table, ONE launch (hidvae_gather_rows): a batch gathered from the resident item
+    tables straight into its destination (the step's input buffers).  idx: int64 device vector; tables / outs: contiguous device
+    tensors of matching dtype and row shape, outs[t] with len(idx) rows; element sizes in whole dwords per row."""
+    n = len(tables)
+    if not (1 <= n <= GATHER_MAX and len(outs) == n):
+        raise RuntimeError(f"gather_rows: {n} tables / {len(outs)} destinations (1 .. {GATHER_MAX}, equally many)")
+    if idx.dtype != torch.int64 or idx.dim() != 1 or not idx.is_contiguous() or not idx.is_cuda:
+        raise RuntimeError("gather_rows: idx must be a contiguous int64 device vector")
+    rows = idx.numel()
+    rb, sr = [], []
+    for t, o in zip(tables, outs):
+        if not (t.is_cuda and o.is_cuda and t.is_contiguous() and o.is_contiguous() and t.dtype == o.dtype and t.shape[1:] == o.shape[1:]
+                and o.shape[0] == rows and t.dim() >= 1):
+            raise RuntimeError(f"gather_rows: table {tuple(t.shape)} {t.dtype} -> destination {tuple(o.shape)} {o.dtype} for {rows} rows")
+        b = (t[0].numel() if t.dim() > 1 else 1) * t.element_size()
+        if b % 4:
+            raise RuntimeError(f"gather_rows: rows of {b} bytes (whole dwords only)")
+        rb.append(b)
+        sr.append(t.shape[0])
+    vp = ctypes.c_void_p * n
+    i64 = ctypes.c_int64 * n
+    _check(lib().hidvae_gather_rows(_p(idx), rows, n, vp(*[t.data_ptr() for t in tables]), vp(*[o.data_ptr() for o in outs]), i64(*rb), i64(*sr),
+                                    _stream()), "hidvae_gather_rows")
+    return outs

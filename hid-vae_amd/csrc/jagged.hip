@@ -71,3 +71,58 @@ extern "C" int hidvae_jagged_to_padded(const void *values, const int64_t *offset
     HV_LAUNCH_CHECK("jagged_to_padded");
     return HIDVAE_OK;
 }
+
+// ---- a batch gathered from the resident item tables in ONE launch (reference data/tags_processed.py:112-150: __getitem__ indexes
+// item_data, tags_emb and tags_indices with the batch's ids; train_hidvae.py:698-701 hands the result to the step).  Up to
+// HIDVAE_GATHER_MAX tables of any element type share the index vector: destination row r of table t = source row idx[r] of table t.
+// A workgroup takes one destination row of every table, dwords or 16-byte vectors; pure HBM traffic (12.3 KB per tagged item).
+namespace {
+
+struct GatherArgs {
+    const char *src[HIDVAE_GATHER_MAX];
+    char *dst[HIDVAE_GATHER_MAX];
+    int64_t row_bytes[HIDVAE_GATHER_MAX], src_rows[HIDVAE_GATHER_MAX];
+    int vec16[HIDVAE_GATHER_MAX];
+    int n;
+    const int64_t *idx;
+    int64_t rows;
+};
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
+    const int64_t r = blockIdx.x;
+    const int64_t i = a.idx[r];
+#pragma unroll
+    for (int t = 0; t < HIDVAE_GATHER_MAX; t++) {
+        if (t >= a.n) break;
+        if (i < 0 || i >= a.src_rows[t]) continue;  // (the caller's contract: ids in range; an id outside leaves the row as it was)
+        const char *s = a.src[t] + i * a.row_bytes[t];
+        char *d = a.dst[t] + r * a.row_bytes[t];
+        if (a.vec16[t]) {
+            for (int64_t k = threadIdx.x; k < a.row_bytes[t] / 16; k += 256) reinterpret_cast<uint4 *>(d)[k] = reinterpret_cast<const uint4 *>(s)[k];
+        } else {
+            for (int64_t k = threadIdx.x; k < a.row_bytes[t] / 4; k += 256) reinterpret_cast<unsigned *>(d)[k] = reinterpret_cast<const unsigned *>(s)[k];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int hidvae_gather_rows(const int64_t *idx, int64_t rows, int n_tables, const void *const *src, void *const *dst,
+                                  const int64_t *row_bytes, const int64_t *src_rows, void *stream) {
+    HV_REQUIRE(idx && src && dst && row_bytes && src_rows && rows >= 1, "gather_rows: bad arguments");
+    HV_REQUIRE(n_tables >= 1 && n_tables <= HIDVAE_GATHER_MAX, "gather_rows: %d tables (1 .. %d)", n_tables, HIDVAE_GATHER_MAX);
+    HV_REQUIRE(rows < (int64_t(1) << 31), "gather_rows: %lld rows", (long long)rows);
+    GatherArgs a{};
+    a.n = n_tables; a.idx = idx; a.rows = rows;
+    for (int t = 0; t < n_tables; t++) {
+        HV_REQUIRE(src[t] && dst[t] && row_bytes[t] >= 4 && row_bytes[t] % 4 == 0 && src_rows[t] >= 1,
+                   "gather_rows: table %d (rows of whole dwords, non-empty)", t);
+        HV_REQUIRE(((reinterpret_cast<uintptr_t>(src[t]) | reinterpret_cast<uintptr_t>(dst[t])) & 3) == 0, "gather_rows: table %d is not dword-aligned", t);
+        a.src[t] = static_cast<const char *>(src[t]); a.dst[t] = static_cast<char *>(dst[t]);
+        a.row_bytes[t] = row_bytes[t]; a.src_rows[t] = src_rows[t];
+        a.vec16[t] = row_bytes[t] % 16 == 0 && ((reinterpret_cast<uintptr_t>(src[t]) | reinterpret_cast<uintptr_t>(dst[t])) & 15) == 0;
+    }
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
+    HV_LAUNCH_CHECK("gather_rows");
+    return HIDVAE_OK;
+}

@@ -108,8 +108,16 @@ class ResidentItemData:
         lands where its consumer reads it -- GraphedTrainStep.input_buffers() -- instead of in a fresh tensor that is copied once more.
         -> out"""
         idx = idx.to(self.x.device)
+        tagged = self.has_tags and getattr(out, "tags_emb", None) is not None
+        if self.x.is_cuda:  # resident tables: one HIP launch for all of them (hidvae_gather_rows)
+            from .. import _C
+            tables = [self.x, self.tags_emb, self.tags_indices] if tagged else [self.x]
+            outs = [out.x, out.tags_emb, out.tags_indices] if tagged else [out.x]
+            if all(t.is_contiguous() and o.is_contiguous() and t.dtype == o.dtype for t, o in zip(tables, outs)):
+                _C.gather_rows(idx.contiguous(), tables, outs)
+                return out
         torch.index_select(self.x, 0, idx, out=out.x)
-        if self.has_tags and getattr(out, "tags_emb", None) is not None:
+        if tagged:
             torch.index_select(self.tags_emb, 0, idx, out=out.tags_emb)
             torch.index_select(self.tags_indices, 0, idx, out=out.tags_indices)
         return out

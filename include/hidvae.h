@@ -550,6 +550,15 @@ int hidvae_padded_to_jagged(const void *x, int64_t stride_b_bytes, int64_t strid
 int hidvae_jagged_to_padded(const void *values, const int64_t *offsets, void *x, int64_t stride_b_bytes, int64_t stride_n_bytes,
                             int64_t B, int64_t N, int64_t row_bytes, void *stream);
 
+/* ---- the training loop's batch formation (reference data/tags_processed.py:112-150: ItemData.__getitem__ indexes item_data,
+ * tags_emb and tags_indices with the batch's ids; train_hidvae.py:698-701 hands the batch to the step).  ONE launch gathers the rows
+ * idx[0 .. rows) of up to HIDVAE_GATHER_MAX resident tables (host arrays of n_tables device pointers: src[t] has src_rows[t] rows of
+ * row_bytes[t] bytes, whole dwords, dword-aligned; dst[t] receives `rows` rows) -- e.g. straight into the step's input buffers.
+ * idx: int64 on the device, every id in [0, src_rows[t]) (an id outside leaves that destination row untouched). */
+#define HIDVAE_GATHER_MAX 4
+int hidvae_gather_rows(const int64_t *idx, int64_t rows, int n_tables, const void *const *src, void *const *dst,
+                       const int64_t *row_bytes, const int64_t *src_rows, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -517,3 +517,40 @@ def test_linear_bwd_hand_over_is_stable_under_traffic(C):
         if it % 20 == 0 or it >= 590:
             assert all(torch.equal(a, b) for a, b in zip(out, ref)), f"launch {it} differs"
     torch.cuda.synchronize()
+
+
+def test_gather_rows_is_index_select_on_every_table(C):
+    """hidvae_gather_rows (reference data/tags_processed.py:112-150: the batch's ids index item_data, tags_emb and tags_indices): one
+    launch, every table, bit-exact against torch.index_select; ragged row sizes (16-byte and dword paths), repeated ids, one row, a
+    destination that is a training step's input buffer (ResidentItemData.gather_into), and the refusals"""
+    import types
+    from hidvae_amd.data.items import RandomBatches, ResidentItemData
+    g = torch.Generator().manual_seed(11)
+    for n, B, W in ((50, 16, 8), (1000, 1024, 768), (7, 1, 5), (300, 257, 33)):
+        x = torch.randn(n, W, generator=g).cuda()
+        te = torch.randn(n, 3, W, generator=g).cuda()
+        ti = torch.randint(-1, 40, (n, 3), generator=g).cuda()
+        idx = torch.randint(0, n, (B,), generator=g).cuda()
+        outs = [torch.full((B, W), -7.0, device="cuda"), torch.full((B, 3, W), -7.0, device="cuda"),
+                torch.full((B, 3), -7, dtype=torch.int64, device="cuda")]
+        C.gather_rows(idx, [x, te, ti], outs)
+        for t, o in zip((x, te, ti), outs):
+            assert torch.equal(o, torch.index_select(t, 0, idx))
+        one = torch.empty(B, W, device="cuda")
+        C.gather_rows(idx, [x], [one])
+        assert torch.equal(one, x[idx])
+    # the loader's path: the same batches as the indexing form, written into given buffers
+    data = ResidentItemData(x, te, ti)
+    a, b = RandomBatches(data, 64, seed=5), RandomBatches(data, 64, seed=5)
+    out = types.SimpleNamespace(x=torch.empty(64, W, device="cuda"), tags_emb=torch.empty(64, 3, W, device="cuda"),
+                                tags_indices=torch.empty(64, 3, dtype=torch.long, device="cuda"))
+    for _ in range(6):  # crosses a re-permutation
+        fresh, given = a.next(), b.next(out=out)
+        assert given is out
+        assert torch.equal(fresh.x, out.x) and torch.equal(fresh.tags_emb, out.tags_emb) and torch.equal(fresh.tags_indices, out.tags_indices)
+    with pytest.raises(RuntimeError):
+        C.gather_rows(idx.int(), [x], [one])
+    with pytest.raises(RuntimeError):
+        C.gather_rows(idx, [x], [torch.empty(B, W + 1, device="cuda")])
+    with pytest.raises(RuntimeError):
+        C.gather_rows(idx, [x.half()], [torch.empty(B, W, dtype=torch.half, device="cuda")])  # rows of 66 bytes: not whole dwords
