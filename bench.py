@@ -245,6 +245,20 @@ def kernel_rooflines(args, m, device):
                     bound="hbm", achieved=algi / t * 1e-3, peak=HBM_PEAK_GBS, unit="GB/s", frac=algi / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t,
                     algorithmic_bytes=algi, bytes_moved=algi, fp32_equivalent_mfma_frac=2.0 * big * L * K * 32 / t * 1e-6 / MFMA_F32_PEAK_TF,
                     items_per_s=big / t * 1e6))
+    # the loader's batch formation (ResidentItemData.gather_into -> hidvae_gather_rows): rows of the resident item tables picked by the
+    # batch's ids, all tables in one launch; algorithmic bytes = every gathered byte read once and written once + the ids
+    n_items = 8 * B
+    gx, gte = torch.randn(n_items, 768, device=device), torch.randn(n_items, L, 768, device=device)
+    gti = torch.randint(0, 38, (n_items, L), device=device)
+    gidx = torch.randperm(n_items, device=device)[:B].contiguous()
+    gout = [torch.empty(B, 768, device=device), torch.empty(B, L, 768, device=device), torch.empty(B, L, dtype=torch.int64, device=device)]
+    t = time_kernel(lambda: _C.gather_rows(gidx, [gx, gte, gti], gout))
+    algg = B * (2 * (768 * 4 * (1 + L) + 8 * L) + 8)
+    out.append(dict(entry="hidvae_gather_rows", kernel=f"gather_rows_kernel: a tagged batch of {B} items gathered from the resident tables (x, tags_emb, tags_indices) "
+                                                       "into the step's input buffers, one launch",
+                    bound="hbm", achieved=algg / t * 1e-3, peak=HBM_PEAK_GBS, unit="GB/s", frac=algg / t * 1e-3 / HBM_PEAK_GBS, traffic=None, us=t,
+                    algorithmic_bytes=algg))
+    del gx, gte, gti
     return out
 
 

@@ -22,6 +22,7 @@ QUOTED = [
     ("gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 1024", "gemm_ring_bwd_kernel", 129280),   # 505 ranges of 17 steps
     ("gemm_ring_bwd_kernel tag-head layer backward 691 x 768 at B = 2048", "gemm_ring_bwd_kernel", 128768),   # 503 ranges of 34 steps
     ("rq_forward_kernel streamed code-split (4x1024, B=4096)", "rq_forward_kernel<3, true, false, true, 4, true>", None),
+    ("gather_rows_kernel", "gather_rows_kernel", None),
     ("rq_forward ids-only at 1,048,576 items", "rq_forward_pf32_kernel<2, false, 16, 8, true, true>", None),
 ]
 

@@ -66,6 +66,13 @@ B2 = 2048
 gt2, xt2, yt2 = torch.randn(B2, 691, device=dev), torch.randn(B2, 768, device=dev), torch.rand(B2, 768, device=dev)
 for _ in range(10):
     _C.linear_bwd(gt2, xt2, wt, True, _C.EPI_DRELU, yt2, bias=True, dx_scale=1.6)   # 2048 x 691 x 768: gemm_ring_bwd_kernel
+# the loader's batch formation: rows of the resident item tables picked by the batch's ids, one launch (hidvae_gather_rows)
+n_items = 8 * B
+gx, gte, gti = torch.randn(n_items, 768, device=dev), torch.randn(n_items, L, 768, device=dev), torch.randint(0, 38, (n_items, L), device=dev)
+gidx = torch.randperm(n_items, device=dev)[:B].contiguous()
+gout = [torch.empty(B, 768, device=dev), torch.empty(B, L, 768, device=dev), torch.empty(B, L, dtype=torch.int64, device=dev)]
+for _ in range(10):
+    _C.gather_rows(gidx, [gx, gte, gti], gout)
 for _ in range(5):
     _C.rq_forward(y_big, cb, cc, True, 3, True, 0.4)
     _C.rq_ids(y_big, cb, cc, True)                                     # the tokenizer's corpus pass: only the ids leave the launch
