@@ -517,7 +517,7 @@ def run_workload(args, device, rank, world, dist):
         dp.broadcast_parameters(0)  # replicas start identical (DDP semantics)
     pool_x, pool_te, pool_ti = synth_pool(args, device, rank)
 
-    def pool_batch(i):  # "next_batch": one resident batch (the stepper copies it into its static step inputs)
+    def pool_batch(i):  # one prepared batch of the pool (warm-up, capture and the stamped timeline copy it into the step's inputs; the timed steps gather theirs, see step())
         b = types.SimpleNamespace(x=pool_x[i % args.pool])
         if args.tagged:
             b.tags_emb, b.tags_indices = pool_te[i % args.pool], pool_ti[i % args.pool]
@@ -800,6 +800,8 @@ def main():
                                    f"ROTATION_TRICK, {'tagged (projector+InfoNCE+predictor+focal/mixup: the step both h-configs run)' if args.tagged else 'untagged core'}"
                                    f" train step = fwd+bwd+{'RCCL all-reduce+' if world > 1 else ''}AdamW(cosine)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                       "batch_formation": "every timed step gathers its batch from the resident item tables into the step's input buffers "
+                                          "(ResidentItemData.gather_into: one hidvae_gather_rows launch, inside the timed region)",
                        "graph_queues": os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES"),
                        "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"),
                        "collectives_in_graph": bool(getattr(info["stepper"], "in_graph", False)),
