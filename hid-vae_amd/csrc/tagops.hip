@@ -1673,6 +1673,9 @@ __global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets
         if (i < B) inv[i] = -1;
     }
     __syncthreads();
+    // (a stage of distance j < 64 exchanges inside 64-element blocks, and a block is one wave's in every pass of the i loop: between two
+    //  such stages the wave's own program order through LDS is all the ordering there is to keep -- 14 workgroup barriers at 1024 rows
+    //  instead of 55)
     for (int k = 2; k <= n2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < n2; i += 1024) {
@@ -1685,7 +1688,14 @@ __global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets
                     if (gt == up) { key[i] = kb; key[p] = ka; idx[i] = ib; idx[p] = ia; }
                 }
             }
-            __syncthreads();
+            const int nj = j > 1 ? j >> 1 : k;  // the following stage's distance (k: the first stage of the next k; past the last: >= 64)
+            if (j >= 64 || nj >= 64) {
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
     // rank of each valid row among the valid rows: `per` consecutive rows per thread, scan of the per-thread counts
     const int per = n2 / 1024;
@@ -1694,15 +1704,18 @@ __global__ __launch_bounds__(1024) void mixup_plan_kernel(const int64_t *targets
         const int i = tid * per + r;
         cnt += (i < B && targets[(int64_t)i * ldt + lvl] >= 0) ? 1 : 0;
     }
-    part[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    // exclusive scan of the per-thread counts: inside the wave by shuffles, the sixteen wave totals through LDS
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= off) incl += v;
     }
-    int rank = part[tid] - cnt;
+    if ((tid & 63) == 63) part[tid >> 6] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < (tid >> 6); w++) before += part[w];
+    int rank = before + incl - cnt;
     for (int r = 0; r < per; r++) {
         const int i = tid * per + r;
         if (i >= B) break;
